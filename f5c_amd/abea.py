@@ -1,0 +1,210 @@
+"""Host-side mirror of the f5c `align_db` GPU branch over the C ABI of libabea_hip.so.
+
+`AbeaContext` ~ init_cuda/free_cuda (src/f5c.cu:23,204); `align_db_host` ~ align_cuda on a db_t
+(src/f5c.cu:647); `align_db_device` is the same computation on a device-resident flattened batch
+(torch tensors are used only as HBM buffers).  There is no CPU fallback: if the library or the GPU
+is missing these raise.
+"""
+import ctypes as C
+import os
+import numpy as np
+from .types import EVENT_DT, MODEL_DT, PAIR_DT, SCAL_DT, DIAG_DT
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libabea_hip.so")
+
+EXPORTS = ["abea_init", "abea_free", "abea_last_error", "abea_align_batch_host",
+           "abea_align_batch_device", "abea_get_stats", "abea_device_info", "abea_selftest"]
+
+
+class AbeaError(RuntimeError):
+    pass
+
+
+class _Cfg(C.Structure):
+    _fields_ = [("device_id", C.c_int32), ("kmer_size", C.c_uint32), ("model", C.c_void_p),
+                ("mem_frac", C.c_float), ("max_arena_bytes", C.c_uint64), ("verbosity", C.c_int32),
+                ("reserved", C.c_int32)]
+
+
+class _HostBatch(C.Structure):
+    _fields_ = [("n_reads", C.c_int32), ("read", C.c_void_p), ("read_len", C.c_void_p),
+                ("events", C.c_void_p), ("n_events", C.c_void_p), ("scalings", C.c_void_p),
+                ("n_samples", C.c_void_p), ("pairs", C.c_void_p), ("n_pairs", C.c_void_p),
+                ("diag", C.c_void_p)]
+
+
+class _DevBatch(C.Structure):
+    _fields_ = [("n_reads", C.c_int32), ("read_ptr", C.c_void_p), ("read_len", C.c_void_p),
+                ("event_ptr", C.c_void_p), ("n_events", C.c_void_p), ("pair_ptr", C.c_void_p),
+                ("scalings", C.c_void_p), ("reads", C.c_void_p), ("events", C.c_void_p),
+                ("pairs", C.c_void_p), ("n_pairs", C.c_void_p), ("diag", C.c_void_p)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("pre_ms", C.c_double), ("fill_ms", C.c_double), ("trace_ms", C.c_double),
+                ("h2d_ms", C.c_double), ("d2h_ms", C.c_double), ("host_ms", C.c_double),
+                ("total_ms", C.c_double),
+                ("n_reads_gpu", C.c_int64), ("n_reads_skipped", C.c_int64), ("n_sub_batches", C.c_int64),
+                ("sum_events", C.c_int64), ("sum_bands", C.c_int64), ("sum_pairs", C.c_int64),
+                ("fill_launches", C.c_int64),
+                ("arena_bytes", C.c_uint64), ("bytes_ref", C.c_uint64), ("bytes_min", C.c_uint64),
+                ("bytes_moved", C.c_uint64)]
+
+    def asdict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+_LIB = None
+
+
+def load_library():
+    """Load libabea_hip.so (built by __graft_entry__.build()). Raises if it is missing."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise AbeaError(f"{LIB_PATH} not built; run `python -c 'import __graft_entry__ as g; g.build()'` "
+                            "(there is no CPU fallback)")
+        L = C.CDLL(LIB_PATH)
+        L.abea_init.restype = C.c_int
+        L.abea_init.argtypes = [C.POINTER(C.c_void_p), C.POINTER(_Cfg)]
+        L.abea_free.restype = None
+        L.abea_free.argtypes = [C.c_void_p]
+        L.abea_last_error.restype = C.c_char_p
+        L.abea_align_batch_host.restype = C.c_int
+        L.abea_align_batch_host.argtypes = [C.c_void_p, C.POINTER(_HostBatch)]
+        L.abea_align_batch_device.restype = C.c_int
+        L.abea_align_batch_device.argtypes = [C.c_void_p, C.POINTER(_DevBatch)]
+        L.abea_get_stats.restype = C.c_int
+        L.abea_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
+        L.abea_device_info.restype = C.c_int
+        L.abea_device_info.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_int32),
+                                       C.POINTER(C.c_uint64)]
+        L.abea_selftest.restype = C.c_int
+        L.abea_selftest.argtypes = [C.c_void_p]
+        _LIB = L
+    return _LIB
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class AbeaContext:
+    """Device context: model copy + scratch arena + stream (init_cuda / free_cuda)."""
+
+    def __init__(self, model, kmer_size, device_id=0, mem_frac=0.9, max_arena_bytes=0, verbosity=0):
+        assert model.dtype == MODEL_DT and len(model) == 4 ** kmer_size
+        self._lib = load_library()
+        self._model = np.ascontiguousarray(model)
+        self.kmer_size = kmer_size
+        cfg = _Cfg(device_id, kmer_size, self._model.ctypes.data, mem_frac, max_arena_bytes, verbosity, 0)
+        h = C.c_void_p()
+        rc = self._lib.abea_init(C.byref(h), C.byref(cfg))
+        if rc != 0:
+            raise AbeaError(f"abea_init failed ({rc}): {self._lib.abea_last_error().decode()}")
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.abea_free(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            raise AbeaError(f"{what} failed ({rc}): {self._lib.abea_last_error().decode()}")
+
+    def selftest(self):
+        self._chk(self._lib.abea_selftest(self._h), "abea_selftest")
+
+    def device_info(self):
+        arch = C.create_string_buffer(64)
+        ncu = C.c_int32()
+        arena = C.c_uint64()
+        self._chk(self._lib.abea_device_info(self._h, arch, 64, C.byref(ncu), C.byref(arena)), "abea_device_info")
+        return dict(arch=arch.value.decode(), n_cu=ncu.value, arena_bytes=arena.value)
+
+    def stats(self):
+        s = Stats()
+        self._chk(self._lib.abea_get_stats(self._h, C.byref(s)), "abea_get_stats")
+        return s.asdict()
+
+    # ---- db_t view: arrays of per-read pointers (align_cuda, f5c.cu:647) ----
+    def align_db_host(self, seqs, events_list, scalings, n_samples=None, want_diag=True):
+        """seqs: list[bytes]; events_list: list[EVENT_DT array]; scalings: SCAL_DT array.
+        Returns (list of PAIR_DT arrays, n_pairs int32[n], diag DIAG_DT[n] or None)."""
+        n = len(seqs)
+        seq_bufs = [C.create_string_buffer(s, len(s) + 1) for s in seqs]
+        evs = [np.ascontiguousarray(e, dtype=EVENT_DT) for e in events_list]
+        outs = [np.zeros(len(e) + len(s), dtype=PAIR_DT) for e, s in zip(evs, seqs)]
+        read_pp = (C.c_void_p * n)(*[C.addressof(b) for b in seq_bufs])
+        ev_pp = (C.c_void_p * n)(*[e.ctypes.data if len(e) else None for e in evs])
+        out_pp = (C.c_void_p * n)(*[o.ctypes.data if len(o) else None for o in outs])
+        read_len = np.array([len(s) for s in seqs], dtype=np.int32)
+        n_events = np.array([len(e) for e in evs], dtype=np.uint64)
+        sc = np.ascontiguousarray(scalings, dtype=SCAL_DT)
+        n_pairs = np.zeros(n, dtype=np.int32)
+        diag = np.zeros(n, dtype=DIAG_DT) if want_diag else None
+        ns = np.ascontiguousarray(n_samples, dtype=np.int64) if n_samples is not None else None
+        hb = _HostBatch(n, C.cast(read_pp, C.c_void_p), _p(read_len), C.cast(ev_pp, C.c_void_p), _p(n_events),
+                        _p(sc), _p(ns) if ns is not None else None, C.cast(out_pp, C.c_void_p), _p(n_pairs),
+                        _p(diag) if want_diag else None)
+        self._chk(self._lib.abea_align_batch_host(self._h, C.byref(hb)), "abea_align_batch_host")
+        return [o[:k] for o, k in zip(outs, n_pairs)], n_pairs, diag
+
+    def align_flat_host(self, batch, want_diag=True):
+        """Convenience: run a flattened numpy batch (f5c_amd.synth layout) through the host entry point."""
+        n = len(batch["read_len"])
+        seqs, evs = [], []
+        for i in range(n):
+            s = int(batch["read_ptr"][i]); L = int(batch["read_len"][i])
+            seqs.append(batch["reads"][s:s + L].tobytes())
+            s = int(batch["event_ptr"][i]); E = int(batch["n_events"][i])
+            evs.append(batch["events"][s:s + E])
+        return self.align_db_host(seqs, evs, batch["scalings"], want_diag=want_diag)
+
+    # ---- device-resident flattened batch ----
+    def upload(self, batch, device=None):
+        """Copy a flattened numpy batch into HBM (torch tensors as plain device buffers)."""
+        import torch
+        dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+        n = len(batch["read_len"])
+        d = dict(n_reads=n,
+                 read_ptr=np.ascontiguousarray(batch["read_ptr"], dtype=np.int64),
+                 read_len=np.ascontiguousarray(batch["read_len"], dtype=np.int32),
+                 event_ptr=np.ascontiguousarray(batch["event_ptr"], dtype=np.int64),
+                 n_events=np.ascontiguousarray(batch["n_events"], dtype=np.int32),
+                 pair_ptr=np.ascontiguousarray(batch["pair_ptr"], dtype=np.int64),
+                 scalings=np.ascontiguousarray(batch["scalings"], dtype=SCAL_DT))
+        d["reads"] = torch.from_numpy(np.ascontiguousarray(batch["reads"]).view(np.uint8)).to(dev)
+        d["events"] = torch.from_numpy(np.ascontiguousarray(batch["events"]).view(np.uint8)).to(dev)
+        d["pairs"] = torch.zeros(max(1, batch["pair_cap"]) * 2, dtype=torch.int32, device=dev)
+        d["n_pairs"] = torch.zeros(max(1, n), dtype=torch.int32, device=dev)
+        d["diag"] = torch.zeros(max(1, n) * DIAG_DT.itemsize, dtype=torch.uint8, device=dev)
+        return d
+
+    def align_db_device(self, dbatch, want_diag=True):
+        """Run the hot path on a batch already resident in HBM (what bench.py times). Synchronous."""
+        db = _DevBatch(dbatch["n_reads"], _p(dbatch["read_ptr"]), _p(dbatch["read_len"]),
+                       _p(dbatch["event_ptr"]), _p(dbatch["n_events"]), _p(dbatch["pair_ptr"]),
+                       _p(dbatch["scalings"]),
+                       dbatch["reads"].data_ptr(), dbatch["events"].data_ptr(), dbatch["pairs"].data_ptr(),
+                       dbatch["n_pairs"].data_ptr(), dbatch["diag"].data_ptr() if want_diag else None)
+        self._chk(self._lib.abea_align_batch_device(self._h, C.byref(db)), "abea_align_batch_device")
+
+    @staticmethod
+    def download(dbatch):
+        """(pairs PAIR_DT[cap], n_pairs int32[n], diag DIAG_DT[n]) from a device batch."""
+        n = dbatch["n_reads"]
+        pairs = dbatch["pairs"].cpu().numpy().view(PAIR_DT)
+        n_pairs = dbatch["n_pairs"].cpu().numpy()[:n]
+        diag = dbatch["diag"].cpu().numpy().view(DIAG_DT)[:n]
+        return pairs, n_pairs, diag

@@ -1,0 +1,419 @@
+/* abea_capi.cpp — host side of libabea_hip.so (include/abea.h).
+ *
+ * Plays the role of the reference's init_cuda / align_cuda / free_cuda (src/f5c.cu) for the
+ * MI355X path: owns a one-shot device arena, builds per-read descriptors (per-read log
+ * constants via glibc), orders reads longest-first so the hardware workgroup
+ * dispatcher load-balances 1..50 kb mixes, splits a batch into arena-sized sub-batches and
+ * launches the three kernels of abea_kernels.hip on the library's own stream, timed with
+ * HIP events on that stream.  No CPU alignment fallback exists in this library.
+ */
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <numeric>
+#include <vector>
+#include "abea_device.h"
+
+static_assert(sizeof(abea_event_t) == 24, "event_t layout (f5c.h:129)");
+static_assert(sizeof(abea_model_t) == 12, "model_t layout (f5c.h:147)");
+static_assert(sizeof(abea_scalings_t) == 16, "scalings_t layout (f5c.h:158)");
+static_assert(sizeof(abea_pair_t) == 8, "AlignedPair layout (f5c.h:181)");
+static_assert(sizeof(abea_read_diag) == 40, "abea_read_diag layout");
+static_assert(sizeof(abea_kpar_t) == 16, "kpar layout");
+static_assert(sizeof(abea_fill_out) == 16, "fill_out layout");
+static_assert(sizeof(abea_read_desc) % 16 == 0, "desc alignment");
+
+extern "C" {
+__global__ void abea_selftest_kernel(int* out);
+__global__ void abea_pre_kernel(const abea_read_desc*, const char*, const abea_event_t*, const abea_model_t*, int,
+                                abea_kpar_t*, float*);
+__global__ void abea_fill_kernel(const abea_read_desc*, const float*, const abea_kpar_t*, uint4*, abea_fill_out*);
+__global__ void abea_trace_kernel(const abea_read_desc*, const float*, const abea_kpar_t*, const uint4*,
+                                  const abea_fill_out*, uint32_t*, abea_pair_t*, int32_t*, abea_read_diag*);
+}
+
+/* ------------------------------------------------------------------ errors */
+static thread_local char g_err[512] = "";
+static int fail(int code, const char* fmt, ...) {
+    va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof g_err, fmt, ap); va_end(ap);
+    return code;
+}
+#define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) \
+    return fail(ABEA_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
+
+extern "C" const char* abea_last_error(void) { return g_err; }
+
+static double now_ms() {
+    using namespace std::chrono;
+    return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+
+/* ------------------------------------------------------------------ context */
+struct abea_ctx {
+    int device = 0;
+    int n_cu = 0;
+    char arch[64] = {0};
+    uint32_t k = 0;
+    int verbosity = 0;
+    hipStream_t stream = nullptr;
+    abea_model_t* d_model = nullptr;
+    uint8_t* arena = nullptr;      size_t arena_bytes = 0;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    /* pinned staging for descriptors */
+    abea_read_desc* h_desc = nullptr; size_t h_desc_cap = 0;
+    /* host-batch staging (grow on demand) */
+    char* h_reads = nullptr;       size_t h_reads_cap = 0;
+    abea_event_t* h_events = nullptr; size_t h_events_cap = 0;
+    abea_pair_t* h_pairs = nullptr;  size_t h_pairs_cap = 0;
+    int32_t* h_npairs = nullptr;     size_t h_npairs_cap = 0;
+    abea_read_diag* h_diag = nullptr; size_t h_diag_cap = 0;
+    char* d_reads = nullptr;       size_t d_reads_cap = 0;
+    abea_event_t* d_events = nullptr; size_t d_events_cap = 0;
+    abea_pair_t* d_pairs = nullptr;  size_t d_pairs_cap = 0;
+    int32_t* d_npairs = nullptr;     size_t d_npairs_cap = 0;
+    abea_read_diag* d_diag = nullptr; size_t d_diag_cap = 0;
+    abea_stats stats;
+};
+
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+extern "C" int abea_init(abea_ctx** out, const abea_cfg* cfg) {
+    if (!out || !cfg || !cfg->model) return fail(ABEA_EINVAL, "abea_init: null argument");
+    if (cfg->kmer_size < 1 || cfg->kmer_size > ABEA_MAX_KMER_SIZE)
+        return fail(ABEA_EINVAL, "abea_init: kmer_size %u outside [1,%d]", cfg->kmer_size, ABEA_MAX_KMER_SIZE);
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0)
+        return fail(ABEA_ENODEV, "abea_init: no HIP device visible (this library has no CPU fallback)");
+    if (cfg->device_id < 0 || cfg->device_id >= n_dev)
+        return fail(ABEA_EINVAL, "abea_init: device_id %d but %d device(s)", cfg->device_id, n_dev);
+    HIP_TRY(hipSetDevice(cfg->device_id));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, cfg->device_id));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(ABEA_ENODEV, "abea_init: device %d is %s; the kernels are built for gfx950 only",
+                    cfg->device_id, prop.gcnArchName);
+    abea_ctx* c = new abea_ctx();
+    memset(&c->stats, 0, sizeof c->stats);
+    c->device = cfg->device_id;
+    c->n_cu = prop.multiProcessorCount;
+    snprintf(c->arch, sizeof c->arch, "%s", prop.gcnArchName);
+    c->k = cfg->kmer_size;
+    c->verbosity = cfg->verbosity;
+    HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    for (auto& e : c->ev) HIP_TRY(hipEventCreate(&e));
+    const size_t n_model = (size_t)1 << (2 * cfg->kmer_size);
+    HIP_TRY(hipMalloc(&c->d_model, n_model * sizeof(abea_model_t)));
+    HIP_TRY(hipMemcpy(c->d_model, cfg->model, n_model * sizeof(abea_model_t), hipMemcpyHostToDevice));
+    /* one-shot arena (f5c.cu:110-199 sizes its arrays once from free memory x MEM_FACTOR) */
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+    double frac = (cfg->mem_frac > 0.f && cfg->mem_frac <= 1.f) ? cfg->mem_frac : 0.9;
+    size_t want = (size_t)((double)free_b * frac);
+    if (cfg->max_arena_bytes && want > cfg->max_arena_bytes) want = (size_t)cfg->max_arena_bytes;
+    want = want / 4096 * 4096;
+    if (want < ((size_t)16 << 20)) { delete c; return fail(ABEA_ENOMEM, "abea_init: only %zu bytes free on device", free_b); }
+    HIP_TRY(hipMalloc(&c->arena, want));
+    c->arena_bytes = want;
+    if (c->verbosity > 0)
+        fprintf(stderr, "[abea_init] %s, %d CUs, arena %.2f GiB of %.2f GiB free\n", c->arch, c->n_cu,
+                want / 1073741824.0, free_b / 1073741824.0);
+    *out = c;
+    return ABEA_OK;
+}
+
+extern "C" void abea_free(abea_ctx* c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    hipFree(c->d_model); hipFree(c->arena);
+    hipFree(c->d_reads); hipFree(c->d_events); hipFree(c->d_pairs); hipFree(c->d_npairs); hipFree(c->d_diag);
+    hipHostFree(c->h_desc); hipHostFree(c->h_reads); hipHostFree(c->h_events); hipHostFree(c->h_pairs);
+    hipHostFree(c->h_npairs); hipHostFree(c->h_diag);
+    for (auto& e : c->ev) if (e) hipEventDestroy(e);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" int abea_device_info(abea_ctx* c, char* arch, size_t arch_len, int32_t* n_cu, uint64_t* arena_bytes) {
+    if (!c) return fail(ABEA_EINVAL, "null ctx");
+    if (arch && arch_len) snprintf(arch, arch_len, "%s", c->arch);
+    if (n_cu) *n_cu = c->n_cu;
+    if (arena_bytes) *arena_bytes = c->arena_bytes;
+    return ABEA_OK;
+}
+
+extern "C" int abea_get_stats(abea_ctx* c, abea_stats* out) {
+    if (!c || !out) return fail(ABEA_EINVAL, "null argument");
+    *out = c->stats;
+    return ABEA_OK;
+}
+
+extern "C" int abea_selftest(abea_ctx* c) {
+    if (!c) return fail(ABEA_EINVAL, "null ctx");
+    HIP_TRY(hipSetDevice(c->device));
+    int* d = (int*)c->arena;
+    int h[320];
+    hipLaunchKernelGGL(abea_selftest_kernel, dim3(1), dim3(64), 0, c->stream, d);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(h, d, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (int l = 0; l < 64; ++l) {
+        if (h[l] != l - 1) return fail(ABEA_EHIP, "selftest: wave_shr:1 lane %d got %d", l, h[l]);
+        if (h[64 + l] != (l == 63 ? -1 : l + 1)) return fail(ABEA_EHIP, "selftest: wave_shl:1 lane %d got %d", l, h[64 + l]);
+        if (h[128 + l] != 147) return fail(ABEA_EHIP, "selftest: readlane lane %d got %d", l, h[128 + l]);
+        if (h[192 + l] != (l == 49 ? 777 : l)) return fail(ABEA_EHIP, "selftest: writelane lane %d got %d", l, h[192 + l]);
+        if (h[256 + l] != 1) return fail(ABEA_EHIP, "selftest: fp64-reciprocal quotient differs from a/b at lane %d", l);
+    }
+    return ABEA_OK;
+}
+
+/* ------------------------------------------------------------------ batch planning */
+struct plan_read {
+    int32_t idx;          /* index in the caller's batch */
+    int32_t L, E, K;
+    int64_t n_bands;
+    bool run;
+};
+
+/* per-read scratch bytes (kpar, evm, codes, trace, fill_out, desc) */
+static size_t scratch_bytes(const plan_read& r) {
+    const size_t n_groups = (size_t)(r.n_bands + ABEA_GROUP - 1) / ABEA_GROUP;
+    return align_up((size_t)r.K * sizeof(abea_kpar_t), 16) + align_up((size_t)r.E * 4 + 256, 16) +
+           align_up(((size_t)(r.E + r.K) / 16 + 2) * 4, 16) + n_groups * 64 * sizeof(uint4) +
+           sizeof(abea_fill_out) + sizeof(abea_read_desc);
+}
+
+static int ensure_pinned(void** p, size_t* cap, size_t need) {
+    if (*cap >= need) return ABEA_OK;
+    if (*p) hipHostFree(*p);
+    *p = nullptr; *cap = 0;
+    size_t n = align_up(need + need / 4, 4096);
+    if (hipHostMalloc(p, n, hipHostMallocDefault) != hipSuccess) return fail(ABEA_EHIP, "hipHostMalloc(%zu) failed", n);
+    *cap = n;
+    return ABEA_OK;
+}
+static int ensure_dev(void** p, size_t* cap, size_t need) {
+    if (*cap >= need) return ABEA_OK;
+    if (*p) hipFree(*p);
+    *p = nullptr; *cap = 0;
+    size_t n = align_up(need + need / 4, 4096);
+    if (hipMalloc(p, n) != hipSuccess) return fail(ABEA_EHIP, "hipMalloc(%zu) failed", n);
+    *cap = n;
+    return ABEA_OK;
+}
+
+extern "C" int abea_align_batch_device(abea_ctx* c, const abea_device_batch* B) {
+    if (!c || !B) return fail(ABEA_EINVAL, "null argument");
+    const int32_t n = B->n_reads;
+    if (n < 0) return fail(ABEA_EINVAL, "n_reads < 0");
+    const double t_start = now_ms();
+    abea_stats st; memset(&st, 0, sizeof st);
+    st.arena_bytes = c->arena_bytes;
+    if (n == 0) { st.total_ms = 0; c->stats = st; return ABEA_OK; }
+    if (!B->read_ptr || !B->read_len || !B->event_ptr || !B->n_events || !B->pair_ptr || !B->scalings ||
+        !B->reads || !B->events || !B->pairs || !B->n_pairs)
+        return fail(ABEA_EINVAL, "abea_align_batch_device: null array");
+    HIP_TRY(hipSetDevice(c->device));      /* the caller's thread changes per batch (f5c.cu:692-694) */
+
+    /* ---- guards + ordering ---- */
+    std::vector<plan_read> reads((size_t)n);
+    std::vector<int32_t> order; order.reserve((size_t)n);
+    std::vector<int32_t> skipped;
+    for (int32_t i = 0; i < n; ++i) {
+        plan_read& r = reads[(size_t)i];
+        r.idx = i; r.L = B->read_len[i]; r.E = B->n_events[i];
+        r.K = r.L - (int32_t)c->k + 1;
+        /* align_single guard f5c.c:813-814 (E/L < 15.0f in float); reads shorter than k are UB in the
+         * reference (size_t underflow align.c:191) and rejected here */
+        r.run = r.E > 0 && r.K >= 1 && ((float)r.E / (float)r.L) < 15.0f;
+        r.n_bands = (int64_t)r.E + r.K + 2;
+        if (r.run) order.push_back(i); else skipped.push_back(i);
+    }
+    std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) {
+        return reads[(size_t)a].n_bands > reads[(size_t)b].n_bands; });
+    st.n_reads_skipped = (int64_t)skipped.size();
+    st.n_reads_gpu = (int64_t)order.size();
+
+    /* skipped reads ride along in the first launch as n_groups == 0 descriptors */
+    std::vector<int32_t> seq; seq.reserve((size_t)n);
+    seq.insert(seq.end(), order.begin(), order.end());
+    seq.insert(seq.end(), skipped.begin(), skipped.end());
+
+    volatile double eps = 1e-10, trim_p = 0.01;
+    const double lp_skip = log(eps), lp_trim = log(trim_p);        /* align.c:212-216 */
+
+    size_t pos = 0;
+    while (pos < seq.size()) {
+        /* ---- carve a sub-batch that fits the arena ---- */
+        size_t end = pos, bytes = 4096;
+        while (end < seq.size()) {
+            const plan_read& r = reads[(size_t)seq[end]];
+            size_t need = r.run ? scratch_bytes(r) : (sizeof(abea_read_desc) + sizeof(abea_fill_out));
+            if (bytes + need + 65536 > c->arena_bytes) break;
+            bytes += need; ++end;
+        }
+        if (end == pos)
+            return fail(ABEA_ENOMEM, "read %d (L=%d, E=%d) needs more scratch than the %zu-byte arena",
+                        seq[pos], reads[(size_t)seq[pos]].L, reads[(size_t)seq[pos]].E, c->arena_bytes);
+        const size_t m = end - pos;
+        int rc = ensure_pinned((void**)&c->h_desc, &c->h_desc_cap, m * sizeof(abea_read_desc));
+        if (rc) return rc;
+
+        /* ---- arena layout: [desc][fout][kpar][evm][codes][trace] ---- */
+        size_t n_kpar = 0, n_evm = 0, n_code = 0, n_trace = 0;
+        for (size_t j = 0; j < m; ++j) {
+            const plan_read& r = reads[(size_t)seq[pos + j]];
+            abea_read_desc& d = c->h_desc[j];
+            memset(&d, 0, sizeof d);
+            d.out_idx = r.idx;
+            d.read_off = B->read_ptr[r.idx]; d.event_off = B->event_ptr[r.idx]; d.pair_off = B->pair_ptr[r.idx];
+            d.read_len = r.L; d.n_events = r.E; d.n_kmers = r.K;
+            if (!r.run) { d.n_groups = 0; continue; }
+            d.n_groups = (int32_t)((r.n_bands + ABEA_GROUP - 1) / ABEA_GROUP);
+            d.scale = B->scalings[r.idx].scale; d.shift = B->scalings[r.idx].shift;
+            d.kpar_off = (int64_t)n_kpar;  n_kpar += (size_t)r.K;
+            d.evm_off = (int64_t)n_evm;    n_evm += align_up((size_t)r.E + 64, 4);
+            d.code_off = (int64_t)n_code;  n_code += align_up((size_t)(r.E + r.K) / 16 + 2, 4);
+            d.trace_off = (int64_t)n_trace; n_trace += (size_t)d.n_groups * 64;
+            /* align.c:207-216, doubles, glibc */
+            double events_per_kmer = (double)(size_t)r.E / (size_t)r.K;
+            double p_stay = 1 - (1 / (events_per_kmer + 1));
+            d.lp_skip = lp_skip;
+            d.lp_stay = log(p_stay);
+            d.lp_step = log(1.0 - exp(lp_skip) - exp(d.lp_stay));
+            d.lp_trim = lp_trim;
+            st.sum_events += r.E; st.sum_bands += r.n_bands;
+            /* SURVEY §8d algorithmic bytes; P is added after the run from n_pairs */
+            const uint64_t Bn = (uint64_t)r.n_bands;
+            st.bytes_ref += 24ull * r.E + (uint64_t)(r.L + 1) + 40 + 108ull * Bn + 4;
+            st.bytes_min += 4ull * r.E + (uint64_t)(r.L + 3) / 4 + 40 + 25ull * Bn + (Bn + 7) / 8 + 4;
+            /* this implementation: pre (24E + L + 12K model gather -> 16K + 4E), fill (16K + 4E in, 32 B/band trace out),
+             * post (trace blocks on the path ~ 32 B/band worst case, codes, 16K+4E again, 8P out) */
+            st.bytes_moved += 24ull * r.E + r.L + 12ull * r.K + 2 * (16ull * r.K + 4ull * r.E) + 64ull * Bn +
+                              16ull * r.K + 4ull * r.E;
+        }
+        uint8_t* p = c->arena;
+        abea_read_desc* d_desc = (abea_read_desc*)p;        p += align_up(m * sizeof(abea_read_desc), 256);
+        abea_fill_out* d_fout = (abea_fill_out*)p;          p += align_up(m * sizeof(abea_fill_out), 256);
+        abea_kpar_t* d_kpar = (abea_kpar_t*)p;              p += align_up(n_kpar * sizeof(abea_kpar_t), 256);
+        float* d_evm = (float*)p;                           p += align_up(n_evm * 4 + 512, 256);
+        uint32_t* d_codes = (uint32_t*)p;                   p += align_up(n_code * 4, 256);
+        uint4* d_trace = (uint4*)p;                         p += n_trace * sizeof(uint4);
+        if ((size_t)(p - c->arena) > c->arena_bytes)
+            return fail(ABEA_ENOMEM, "internal: sub-batch layout %zu exceeds arena %zu", (size_t)(p - c->arena), c->arena_bytes);
+
+        HIP_TRY(hipMemcpyAsync(d_desc, c->h_desc, m * sizeof(abea_read_desc), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipEventRecord(c->ev[0], c->stream));
+        hipLaunchKernelGGL(abea_pre_kernel, dim3((unsigned)m), dim3(256), 0, c->stream,
+                           d_desc, B->reads, B->events, c->d_model, (int)c->k, d_kpar, d_evm);
+        HIP_TRY(hipEventRecord(c->ev[1], c->stream));
+        hipLaunchKernelGGL(abea_fill_kernel, dim3((unsigned)m), dim3(64), 0, c->stream,
+                           d_desc, d_evm, d_kpar, d_trace, d_fout);
+        HIP_TRY(hipEventRecord(c->ev[2], c->stream));
+        hipLaunchKernelGGL(abea_trace_kernel, dim3((unsigned)m), dim3(64), 0, c->stream,
+                           d_desc, d_evm, d_kpar, d_trace, d_fout, d_codes, B->pairs, B->n_pairs, B->diag);
+        HIP_TRY(hipEventRecord(c->ev[3], c->stream));
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(c->stream));            /* h_desc and the arena are reused by the next sub-batch */
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, c->ev[0], c->ev[1])); st.pre_ms += ms;
+        HIP_TRY(hipEventElapsedTime(&ms, c->ev[1], c->ev[2])); st.fill_ms += ms;
+        HIP_TRY(hipEventElapsedTime(&ms, c->ev[2], c->ev[3])); st.trace_ms += ms;
+        st.n_sub_batches += 1; st.fill_launches += 1;
+        pos = end;
+    }
+    st.total_ms = now_ms() - t_start;
+    c->stats = st;
+    if (c->verbosity > 1)
+        fprintf(stderr, "[abea] %lld reads on GPU, %lld skipped, %lld sub-batch(es): pre %.3f ms fill %.3f ms post %.3f ms\n",
+                (long long)st.n_reads_gpu, (long long)st.n_reads_skipped, (long long)st.n_sub_batches,
+                st.pre_ms, st.fill_ms, st.trace_ms);
+    return ABEA_OK;
+}
+
+/* ------------------------------------------------------------------ host batch (db_t view) */
+extern "C" int abea_align_batch_host(abea_ctx* c, const abea_host_batch* H) {
+    if (!c || !H) return fail(ABEA_EINVAL, "null argument");
+    const int32_t n = H->n_reads;
+    if (n < 0) return fail(ABEA_EINVAL, "n_reads < 0");
+    if (n == 0) { memset(&c->stats, 0, sizeof c->stats); return ABEA_OK; }
+    if (!H->read || !H->read_len || !H->events || !H->n_events || !H->scalings || !H->pairs || !H->n_pairs)
+        return fail(ABEA_EINVAL, "abea_align_batch_host: null array");
+    const double t0 = now_ms();
+    HIP_TRY(hipSetDevice(c->device));
+
+    /* ---- flatten (the role of f5c.cu:744-802) ---- */
+    std::vector<int64_t> read_ptr((size_t)n), event_ptr((size_t)n), pair_ptr((size_t)n);
+    std::vector<int32_t> n_events((size_t)n), read_len((size_t)n);
+    size_t sum_read = 0, sum_ev = 0, sum_pair = 0;
+    for (int32_t i = 0; i < n; ++i) {
+        const bool good = (!H->n_samples || H->n_samples[i] > 0) && H->read[i] && H->events[i] && H->pairs[i] &&
+                          H->read_len[i] > 0 && H->n_events[i] > 0 && H->n_events[i] < (uint64_t)INT32_MAX;
+        read_len[(size_t)i] = good ? H->read_len[i] : 0;       /* bad read (nsample == 0): n_pairs = 0 (f5c.c:826-828) */
+        n_events[(size_t)i] = good ? (int32_t)H->n_events[i] : 0;
+        read_ptr[(size_t)i] = (int64_t)sum_read;  sum_read += (size_t)read_len[(size_t)i] + 1;
+        event_ptr[(size_t)i] = (int64_t)sum_ev;   sum_ev += (size_t)n_events[(size_t)i];
+        pair_ptr[(size_t)i] = (int64_t)sum_pair;  sum_pair += (size_t)n_events[(size_t)i] + (size_t)read_len[(size_t)i];
+    }
+    int rc;
+    if ((rc = ensure_pinned((void**)&c->h_reads, &c->h_reads_cap, sum_read + 16))) return rc;
+    if ((rc = ensure_pinned((void**)&c->h_events, &c->h_events_cap, (sum_ev + 1) * sizeof(abea_event_t)))) return rc;
+    if ((rc = ensure_pinned((void**)&c->h_pairs, &c->h_pairs_cap, (sum_pair + 1) * sizeof(abea_pair_t)))) return rc;
+    if ((rc = ensure_pinned((void**)&c->h_npairs, &c->h_npairs_cap, (size_t)n * sizeof(int32_t)))) return rc;
+    if ((rc = ensure_pinned((void**)&c->h_diag, &c->h_diag_cap, (size_t)n * sizeof(abea_read_diag)))) return rc;
+    if ((rc = ensure_dev((void**)&c->d_reads, &c->d_reads_cap, sum_read + 16))) return rc;
+    if ((rc = ensure_dev((void**)&c->d_events, &c->d_events_cap, (sum_ev + 1) * sizeof(abea_event_t)))) return rc;
+    if ((rc = ensure_dev((void**)&c->d_pairs, &c->d_pairs_cap, (sum_pair + 1) * sizeof(abea_pair_t)))) return rc;
+    if ((rc = ensure_dev((void**)&c->d_npairs, &c->d_npairs_cap, (size_t)n * sizeof(int32_t)))) return rc;
+    if ((rc = ensure_dev((void**)&c->d_diag, &c->d_diag_cap, (size_t)n * sizeof(abea_read_diag)))) return rc;
+
+    for (int32_t i = 0; i < n; ++i) {
+        const size_t L = (size_t)read_len[(size_t)i], E = (size_t)n_events[(size_t)i];
+        if (L) memcpy(c->h_reads + read_ptr[(size_t)i], H->read[i], L);
+        c->h_reads[read_ptr[(size_t)i] + (int64_t)L] = '\0';
+        if (E) memcpy(c->h_events + event_ptr[(size_t)i], H->events[i], E * sizeof(abea_event_t));
+    }
+    const double t1 = now_ms();
+    HIP_TRY(hipMemcpyAsync(c->d_reads, c->h_reads, sum_read, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->d_events, c->h_events, sum_ev * sizeof(abea_event_t), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const double t2 = now_ms();
+
+    abea_device_batch D;
+    memset(&D, 0, sizeof D);
+    D.n_reads = n;
+    D.read_ptr = read_ptr.data(); D.read_len = read_len.data();
+    D.event_ptr = event_ptr.data(); D.n_events = n_events.data(); D.pair_ptr = pair_ptr.data();
+    D.scalings = H->scalings;
+    D.reads = c->d_reads; D.events = c->d_events; D.pairs = c->d_pairs; D.n_pairs = c->d_npairs;
+    D.diag = H->diag ? c->d_diag : nullptr;
+    rc = abea_align_batch_device(c, &D);
+    if (rc) return rc;
+    abea_stats st = c->stats;
+
+    const double t3 = now_ms();
+    HIP_TRY(hipMemcpyAsync(c->h_npairs, c->d_npairs, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->h_pairs, c->d_pairs, sum_pair * sizeof(abea_pair_t), hipMemcpyDeviceToHost, c->stream));
+    if (H->diag)
+        HIP_TRY(hipMemcpyAsync(c->h_diag, c->d_diag, (size_t)n * sizeof(abea_read_diag), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const double t4 = now_ms();
+    /* un-flatten into the caller-owned per-read buffers (f5c.cu:1003-1030; pairs already ascending) */
+    for (int32_t i = 0; i < n; ++i) {
+        const int32_t np = c->h_npairs[i];
+        H->n_pairs[i] = np;
+        if (np > 0) memcpy(H->pairs[i], c->h_pairs + pair_ptr[(size_t)i], (size_t)np * sizeof(abea_pair_t));
+        if (H->diag) H->diag[i] = c->h_diag[i];
+        st.sum_pairs += np;
+    }
+    const double t5 = now_ms();
+    st.h2d_ms = t2 - t1; st.d2h_ms = t4 - t3; st.host_ms = (t1 - t0) + (t5 - t4);
+    st.total_ms = t5 - t0;
+    c->stats = st;
+    return ABEA_OK;
+}

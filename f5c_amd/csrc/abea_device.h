@@ -1,0 +1,39 @@
+/* abea_device.h — structures shared between the host driver (abea_capi.cpp) and the gfx950
+ * kernels (abea_kernels.hip).  Internal; the public ABI is include/abea.h. */
+#ifndef ABEA_DEVICE_H
+#define ABEA_DEVICE_H
+#include <stdint.h>
+#include "../../include/abea.h"
+
+#define ABEA_W          ABEA_BANDWIDTH   /* 100 cells per band */
+#define ABEA_GROUP      32               /* bands per trace group (one uint4 per lane) */
+#define ABEA_WAVE       64
+#define ABEA_MOVE_LANE  50               /* lane whose trace nibble carries the band-move bit */
+
+/* Per-k-mer emission parameters produced by the align-pre kernel (16 B, read-scaled):
+ *   gpm  = scale*level_mean + shift           (float mul, float add; align.c:137-138)
+ *   ck   = -0.918938f - level_log_stdv        (align.c:111,113 first two terms)
+ *   istd = 1.0 / (double)level_stdv           ((float)((double)(x-gpm)*istd) is the
+ *                                              correctly rounded float quotient (x-gpm)/stdv) */
+typedef struct __attribute__((aligned(16))) { float gpm; float ck; double istd; } abea_kpar_t;
+
+/* Per-read descriptor built on the host (per-read doubles come from glibc log/exp). */
+typedef struct __attribute__((aligned(16))) {
+    int64_t read_off;     /* chars  into reads   */
+    int64_t event_off;    /* events into events  */
+    int64_t pair_off;     /* pairs  into pairs   */
+    int64_t kpar_off;     /* abea_kpar_t into the k-mer parameter scratch */
+    int64_t evm_off;      /* floats into the event-mean scratch */
+    int64_t trace_off;    /* uint4  into the trace scratch (n_groups * 64 uint4) */
+    int64_t code_off;     /* uint32 into the traceback-code scratch */
+    int32_t read_len, n_events, n_kmers, n_groups;
+    float   scale, shift;
+    int32_t out_idx;      /* index of the read in the caller's n_pairs[] / diag[] */
+    int32_t pad;
+    double  lp_skip, lp_stay, lp_step, lp_trim;   /* align.c:212-216 */
+} abea_read_desc;
+
+/* What the fill kernel hands to the traceback kernel. */
+typedef struct { float best_score; int32_t best_event; int32_t best_llk; int32_t pad; } abea_fill_out;
+
+#endif

@@ -1,0 +1,402 @@
+/* abea_kernels.hip — hand-written gfx950 (CDNA4, wave64) kernels for adaptive banded event
+ * alignment.  Not a port of the reference's align.cu/align.hip: the band lives in VGPRs of ONE
+ * wavefront (2 cells per lane, lanes 0..49), neighbour exchange is a single DPP wave shift per
+ * band, the diagonal comes for free from the previous band's shifted copy, the band-move
+ * decision is two v_readlane + a scalar branch, trace is packed to 2 bit/cell and leaves the CU
+ * as one coalesced 1 KiB store per 32 bands.  No block barriers in the fill loop.
+ *
+ * Arithmetic follows the reference CPU path (src/align.c), not its GPU kernels: score sums are
+ * evaluated in fp64 and rounded once to fp32 (align.c:382-384), float expressions are kept
+ * un-fused (this file MUST be compiled with -ffp-contract=off), per-read log constants come from
+ * the host (glibc).  See DESIGN.md for the derivations cited in comments below.
+ *
+ * Kernels:  abea_pre_kernel   (align-pre: k-mer ranks -> read-scaled emission params, event means SoA)
+ *           abea_fill_kernel  (band fill + adaptive band movement + online end-point scan)
+ *           abea_trace_kernel (align-post: traceback walk, pair expansion, ordered QC sums)
+ */
+#include <hip/hip_runtime.h>
+#include "abea_device.h"
+
+#define NINF (-__builtin_inff())
+
+/* ---------------------------------------------------------------- cross-lane primitives */
+/* lane i <- lane i-1 ; lane 0 keeps `oldv`  (DPP wave_shr:1) */
+static __device__ __forceinline__ int dpp_from_lower_i(int oldv, int v) {
+    return __builtin_amdgcn_update_dpp(oldv, v, 0x138, 0xf, 0xf, false);
+}
+/* lane i <- lane i+1 ; lane 63 keeps `oldv` (DPP wave_shl:1) */
+static __device__ __forceinline__ int dpp_from_upper_i(int oldv, int v) {
+    return __builtin_amdgcn_update_dpp(oldv, v, 0x130, 0xf, 0xf, false);
+}
+static __device__ __forceinline__ float dpp_from_lower_f(float oldv, float v) {
+    return __int_as_float(dpp_from_lower_i(__float_as_int(oldv), __float_as_int(v)));
+}
+static __device__ __forceinline__ float dpp_from_upper_f(float oldv, float v) {
+    return __int_as_float(dpp_from_upper_i(__float_as_int(oldv), __float_as_int(v)));
+}
+static __device__ __forceinline__ double dpp_from_lower_d(double oldv, double v) {
+    int lo = dpp_from_lower_i(__double2loint(oldv), __double2loint(v));
+    int hi = dpp_from_lower_i(__double2hiint(oldv), __double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+static __device__ __forceinline__ double dpp_from_upper_d(double oldv, double v) {
+    int lo = dpp_from_upper_i(__double2loint(oldv), __double2loint(v));
+    int hi = dpp_from_upper_i(__double2hiint(oldv), __double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+static __device__ __forceinline__ float readlane_f(float v, int l) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+static __device__ __forceinline__ int readlane_i(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+/* v_writelane_b32 with an immediate lane (gfx9 allows one SGPR source; this clang has no writelane builtin) */
+template <int LANE> static __device__ __forceinline__ int writelane_i(int oldv, int val) {
+    int r = oldv;
+    const int s = __builtin_amdgcn_readfirstlane(val);
+    asm("v_writelane_b32 %0, %1, %2" : "+v"(r) : "s"(s), "n"(LANE));
+    return r;
+}
+template <int LANE> static __device__ __forceinline__ float writelane_f(float oldv, float val) {
+    return __int_as_float(writelane_i<LANE>(__float_as_int(oldv), __float_as_int(val)));
+}
+static __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+/* ---------------------------------------------------------------- selftest */
+extern "C" __global__ void abea_selftest_kernel(int* out) {
+    int l = threadIdx.x;
+    out[l]       = dpp_from_lower_i(-1, l);        /* expect l-1, lane 0 -> -1 */
+    out[64 + l]  = dpp_from_upper_i(-1, l);        /* expect l+1, lane 63 -> -1 */
+    out[128 + l] = readlane_i(l * 3, 49);          /* expect 147 */
+    out[192 + l] = writelane_i<49>(l, 777);        /* expect l, lane 49 -> 777 */
+    /* correctly rounded float quotient via one fp64 multiply (DESIGN.md "division") */
+    float a = 3.0f + l * 0.37f, b = 1.5f + l * 0.013f;
+    double ib = 1.0 / (double)b;
+    float q1 = (float)((double)a * ib);
+    float q2 = a / b;
+    out[256 + l] = (__float_as_int(q1) == __float_as_int(q2)) ? 1 : 0;
+}
+
+/* ---------------------------------------------------------------- align-pre */
+static __device__ __forceinline__ uint32_t base_code(char c) {
+    /* align.c:19-32: A0 C1 G2 T3, anything else ranks as 0 */
+    return c == 'C' ? 1u : (c == 'G' ? 2u : (c == 'T' ? 3u : 0u));
+}
+
+extern "C" __global__ __launch_bounds__(256)
+void abea_pre_kernel(const abea_read_desc* __restrict__ descs,
+                     const char* __restrict__ reads, const abea_event_t* __restrict__ events,
+                     const abea_model_t* __restrict__ model, int kmer_size,
+                     abea_kpar_t* __restrict__ kpar_all, float* __restrict__ evm_all) {
+    const abea_read_desc* d = descs + blockIdx.x;
+    if (d->n_groups == 0) return;                      /* skipped read */
+    const int K = d->n_kmers, E = d->n_events;
+    const float scale = d->scale, shift = d->shift;
+    const char* seq = reads + d->read_off;
+    abea_kpar_t* kp = kpar_all + d->kpar_off;
+    for (int i = threadIdx.x; i < K; i += blockDim.x) {
+        uint32_t rank = 0;                             /* align.c:36-47, first base most significant */
+        for (int j = 0; j < kmer_size; ++j) rank = (rank << 2) | base_code(seq[i + j]);
+        const abea_model_t m = model[rank];
+        abea_kpar_t p;
+        p.gpm  = __fadd_rn(__fmul_rn(scale, m.level_mean), shift);   /* align.c:137-138, mul then add, no FMA */
+        p.ck   = __fsub_rn(-0.918938f, m.level_log_stdv);            /* align.c:111-113 */
+        p.istd = 1.0 / (double)m.level_stdv;
+        kp[i] = p;
+    }
+    const abea_event_t* ev = events + d->event_off;
+    float* evm = evm_all + d->evm_off;
+    for (int i = threadIdx.x; i < E; i += blockDim.x) evm[i] = ev[i].mean;   /* align.c:131 reads .mean only */
+}
+
+/* ---------------------------------------------------------------- band fill */
+/* One DP cell (align.c:378-392).  D,U,L are the neighbour scores as exact doubles. */
+static __device__ __forceinline__ void abea_cell(float x, float gpm, float ck, double istd,
+                                                 double D, double U, double L,
+                                                 double lp_step, double lp_stay, double lp_skip,
+                                                 float& m, uint32_t& from) {
+    float dx = __fsub_rn(x, gpm);
+    float a  = (float)((double)dx * istd);                     /* == dx / stdv, correctly rounded */
+    float lp = __fadd_rn(ck, __fmul_rn(__fmul_rn(-0.5f, a), a));   /* align.c:113 */
+    double lpd = (double)lp;
+    float sd = (float)((D + lp_step) + lpd);                   /* align.c:382 */
+    float su = (float)((U + lp_stay) + lpd);                   /* align.c:383 */
+    float sl = (float)(L + lp_skip);                           /* align.c:384 */
+    /* align.c:386-392: ties prefer L over U over D; all -inf -> FROM_L */
+    float m1 = fmaxf(sd, su);
+    uint32_t f = (su >= sd) ? 1u : 0u;
+    m = fmaxf(m1, sl);
+    from = (sl >= m1) ? 2u : f;
+}
+
+extern "C" __global__ __launch_bounds__(64)
+void abea_fill_kernel(const abea_read_desc* __restrict__ descs,
+                      const float* __restrict__ evm_all, const abea_kpar_t* __restrict__ kpar_all,
+                      uint4* __restrict__ trace_all, abea_fill_out* __restrict__ fout) {
+    const abea_read_desc* d = descs + blockIdx.x;
+    const int n_groups = d->n_groups;
+    if (n_groups == 0) return;
+    const int lane = threadIdx.x;
+    const int E = d->n_events, K = d->n_kmers;
+    const int nb_pad = n_groups * ABEA_GROUP;
+    const double lp_skip = d->lp_skip, lp_stay = d->lp_stay, lp_step = d->lp_step, lp_trim = d->lp_trim;
+    const float* __restrict__ evm = evm_all + d->evm_off;
+    const abea_kpar_t* __restrict__ kpar = kpar_all + d->kpar_off;
+    uint4* __restrict__ trace = trace_all + d->trace_off;
+    const int o0 = 2 * lane, o1 = o0 + 1;              /* band offsets owned by this lane */
+
+    /* ---- state after bands 0 and 1 (align.c:277-291) ---- */
+    int ll_e = 50, ll_k = -51;                          /* lower-left of band 1 */
+    float Pf0 = NINF, Pf1 = NINF;                       /* band 1 scores (offset 50 = trim of event 0) */
+    if (lane == 25) Pf0 = (float)lp_trim;
+    double P0 = (double)Pf0, P1 = (double)Pf1;
+    /* band 1 was a "down" move from band 0, so in band-1 frame U[o]=band0[o], L[o]=band0[o-1];
+     * band 0 is -inf except offset 50 (start cell, 0.0f) */
+    double U0 = (lane == 25) ? 0.0 : (double)NINF, U1 = (double)NINF;
+    double L0 = (double)NINF, L1 = (lane == 25) ? 0.0 : (double)NINF;
+
+    /* per-cell inputs in band-1 frame: event = ll_e - o, kmer = ll_k + o */
+    float x0, x1, g0, g1, c0, c1; double i0, i1;
+    {
+        int e0 = ll_e - o0, e1 = ll_e - o1;
+        x0 = (e0 >= 0 && e0 < E) ? evm[e0] : 0.f;
+        x1 = (e1 >= 0 && e1 < E) ? evm[e1] : 0.f;
+        int k0 = ll_k + o0, k1 = ll_k + o1;
+        abea_kpar_t z; z.gpm = 0.f; z.ck = 0.f; z.istd = 0.0;
+        abea_kpar_t p0 = (k0 >= 0 && k0 < K) ? kpar[k0] : z;
+        abea_kpar_t p1 = (k1 >= 0 && k1 < K) ? kpar[k1] : z;
+        g0 = p0.gpm; c0 = p0.ck; i0 = p0.istd;
+        g1 = p1.gpm; c1 = p1.ck; i1 = p1.istd;
+    }
+    /* sequential feeds: events enter at offset 0 on "down" moves in index order, k-mers enter at
+     * offset 99 on "right" moves in index order -> 64-wide coalesced chunks held in
+     * one VGPR (4 for k-mers), double-buffered, picked out with v_readlane */
+    int ev_chunk = 0, k_chunk = 0;
+    float evA = evm[min(lane, E - 1)], evB = evm[min(64 + lane, E - 1)];
+    abea_kpar_t kA = kpar[min(lane, K - 1)], kB = kpar[min(64 + lane, K - 1)];
+
+    uint32_t acc = (lane == 25) ? 1u : 0u;             /* bands 0,1: only band 1 offset 50 = FROM_U */
+    uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    float best = NINF; int best_e = 0, best_llk = 0;
+
+    for (int b = 2; b < nb_pad; ++b) {
+        /* ---- Suzuki-Kasahara move (align.c:304-322) ---- */
+        const float s_ll = readlane_f(Pf0, 0), s_ur = readlane_f(Pf1, 49);
+        const bool right = uni((s_ll == NINF && s_ur == NINF) ? (b & 1) : (s_ll < s_ur ? 1 : 0)) != 0;
+        double D0, D1, nU0, nU1, nL0, nL1;
+        if (right) {
+            ll_k += 1;
+            const int kin = ll_k + 99;                 /* k-mer entering at offset 99 */
+            const int kc = kin >> 6;
+            if (kc != k_chunk) { kA = kB; k_chunk = kc; kB = kpar[min((kc + 1) * 64 + lane, K - 1)]; }
+            const int src = kin & 63;
+            const float ng = readlane_f(kA.gpm, src), nc = readlane_f(kA.ck, src);
+            const int nlo = readlane_i(__double2loint(kA.istd), src), nhi = readlane_i(__double2hiint(kA.istd), src);
+            /* k-mer params slide one offset down; lane 49 slot 1 takes the new k-mer */
+            float tg = writelane_f<49>(dpp_from_upper_f(0.f, g0), ng);
+            float tc = writelane_f<49>(dpp_from_upper_f(0.f, c0), nc);
+            int tlo = writelane_i<49>(dpp_from_upper_i(0, __double2loint(i0)), nlo);
+            int thi = writelane_i<49>(dpp_from_upper_i(0, __double2hiint(i0)), nhi);
+            g0 = g1; c0 = c1; i0 = i1;
+            g1 = tg; c1 = tc; i1 = __hiloint2double(thi, tlo);
+            /* neighbours (DESIGN.md "frames"): left = same offset, up = offset+1, diag = previous band's up */
+            nL0 = P0; nL1 = P1;
+            nU0 = P1; nU1 = dpp_from_upper_d((double)NINF, P0);
+            D0 = U0; D1 = U1;
+        } else {
+            ll_e += 1;
+            const int ein = ll_e;                      /* event entering at offset 0 */
+            const int ec = ein >> 6;
+            if (ec != ev_chunk) { evA = evB; ev_chunk = ec; evB = evm[min((ec + 1) * 64 + lane, E - 1)]; }
+            const float nx = readlane_f(evA, ein & 63);
+            float tx = dpp_from_lower_f(nx, x1);       /* lane 0 keeps nx */
+            x1 = x0; x0 = tx;
+            /* left = offset-1, up = same offset, diag = previous band's left */
+            nU0 = P0; nU1 = P1;
+            nL1 = P0; nL0 = dpp_from_lower_d((double)NINF, P1);
+            D0 = L0; D1 = L1;
+        }
+
+        /* ---- cells (align.c:337-409) ---- */
+        const int min_off = max(max(-ll_k, ll_e - (E - 1)), 0);
+        const int max_off = min(min(K - ll_k, ll_e + 1), ABEA_W);
+        float m0, m1; uint32_t f0, f1;
+        abea_cell(x0, g0, c0, i0, D0, nU0, nL0, lp_step, lp_stay, lp_skip, m0, f0);
+        abea_cell(x1, g1, c1, i1, D1, nU1, nL1, lp_step, lp_stay, lp_skip, m1, f1);
+        const bool v0 = (o0 >= min_off) && (o0 < max_off);
+        const bool v1 = (o1 >= min_off) && (o1 < max_off);
+        m0 = v0 ? m0 : NINF; f0 = v0 ? f0 : 0u;
+        m1 = v1 ? m1 : NINF; f1 = v1 ? f1 : 0u;
+
+        /* ---- trim column, k-mer -1 (align.c:324-333) ---- */
+        const int trim_o = -1 - ll_k;
+        if (trim_o >= 0 && trim_o < ABEA_W) {
+            const int te = ll_e - trim_o;
+            if (te >= 0 && te < E) {
+                const float tv = (float)(lp_trim * (double)(te + 1));
+                if (o0 == trim_o) { m0 = tv; f0 = 1u; }
+                if (o1 == trim_o) { m1 = tv; f1 = 1u; }
+            }
+        }
+
+        /* ---- rotate rows ---- */
+        U0 = nU0; U1 = nU1; L0 = nL0; L1 = nL1;
+        Pf0 = m0; Pf1 = m1; P0 = (double)m0; P1 = (double)m1;
+
+        /* ---- trace: 2 bit/cell, 4 bit/lane/band, band-move bit in lane 50 ---- */
+        uint32_t t = f0 | (f1 << 2);
+        if (lane == ABEA_MOVE_LANE) t = right ? 1u : 0u;
+        acc = (acc << 4) | t;
+        if ((b & 7) == 7) {
+            a0 = a1; a1 = a2; a2 = a3; a3 = acc;
+            if ((b & 31) == 31) trace[(size_t)(b >> 5) * 64 + lane] = make_uint4(a0, a1, a2, a3);
+        }
+
+        /* ---- online end-point scan (align.c:424-445): bands visit events in increasing order ---- */
+        const int oc = (K - 1) - ll_k;
+        if (oc >= 0 && oc < ABEA_W) {
+            const int e = ll_e - oc;
+            if (e >= 0 && e < E) {
+                const float sc = (oc & 1) ? readlane_f(Pf1, oc >> 1) : readlane_f(Pf0, oc >> 1);
+                const float s = (float)((double)sc + (double)(E - e) * lp_trim);
+                if (s > best) { best = s; best_e = e; best_llk = ll_k; }
+            }
+        }
+    }
+    if (lane == 0) {
+        abea_fill_out o; o.best_score = best; o.best_event = best_e; o.best_llk = best_llk; o.pad = 0;
+        fout[blockIdx.x] = o;
+    }
+}
+
+/* ---------------------------------------------------------------- align-post */
+static __device__ __forceinline__ uint32_t sel4(const uint4& v, int w) {
+    return w == 0 ? v.x : (w == 1 ? v.y : (w == 2 ? v.z : v.w));
+}
+
+static __device__ __forceinline__ int wave_excl_scan(int v, int lane, int& total) {
+    int s = v;
+    #pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        int t = __shfl_up(s, off, 64);
+        if (lane >= off) s += t;
+    }
+    total = __shfl(s, 63, 64);
+    return s - v;
+}
+
+extern "C" __global__ __launch_bounds__(64)
+void abea_trace_kernel(const abea_read_desc* __restrict__ descs,
+                       const float* __restrict__ evm_all, const abea_kpar_t* __restrict__ kpar_all,
+                       const uint4* __restrict__ trace_all, const abea_fill_out* __restrict__ fout,
+                       uint32_t* __restrict__ codes_all,
+                       abea_pair_t* __restrict__ pairs_all, int32_t* __restrict__ n_pairs,
+                       abea_read_diag* __restrict__ diag) {
+    __shared__ float lp_s[1024];
+    const abea_read_desc* d = descs + blockIdx.x;
+    const int lane = threadIdx.x;
+    const int out_idx = d->out_idx;
+    abea_read_diag dg;
+    dg.sum_emission = 0.0; dg.n_aligned = 0; dg.best_event = 0; dg.max_score = NINF;
+    dg.max_gap = 0; dg.spanned = 0; dg.flags = 0; dg.pad = 0;
+    if (d->n_groups == 0) {                              /* align_single guards (f5c.c:813-814) */
+        if (lane == 0) { n_pairs[out_idx] = 0; dg.flags = ABEA_RF_SKIPPED; if (diag) diag[out_idx] = dg; }
+        return;
+    }
+    const abea_fill_out fo = fout[blockIdx.x];
+    const int K = d->n_kmers;
+    if (fo.best_score == NINF) {                         /* no in-band end cell, SURVEY §9-I */
+        if (lane == 0) { n_pairs[out_idx] = 0; dg.flags = ABEA_RF_NO_END; if (diag) diag[out_idx] = dg; }
+        return;
+    }
+    const float* __restrict__ evm = evm_all + d->evm_off;
+    const abea_kpar_t* __restrict__ kpar = kpar_all + d->kpar_off;
+    const uint4* __restrict__ trace = trace_all + d->trace_off;
+    uint32_t* codes = codes_all + d->code_off;
+    abea_pair_t* pairs = pairs_all + d->pair_off;
+
+    /* ---- serial walk (align.c:452-499), wave-uniform; emits one 2-bit code per step ---- */
+    int e = fo.best_event, k = K - 1, llk = fo.best_llk;
+    int b = e + k + 2;
+    int n = 0, gap = 0, max_gap = 0, last_k = k;
+    uint32_t cwd = 0;
+    int cblk = -1, mgrp = -1;
+    uint4 cw = make_uint4(0, 0, 0, 0), mw = make_uint4(0, 0, 0, 0);
+    while (k >= 0 && e >= 0) {
+        last_k = k;
+        const int off = k - llk;                         /* band offset of (e,k): ll_k + off = k */
+        const int g = b >> 5;
+        const int blk = g * 64 + (off >> 1);
+        if (blk != cblk) { cw = trace[blk]; cblk = blk; }
+        if (g != mgrp) { mw = trace[g * 64 + ABEA_MOVE_LANE]; mgrp = g; }
+        const int sh = (7 - (b & 7)) * 4;
+        const uint32_t from = (sel4(cw, (b >> 3) & 3) >> (sh + ((off & 1) << 1))) & 3u;
+        const int mv_b = (sel4(mw, (b >> 3) & 3) >> sh) & 1;     /* 1 = band b was a right move */
+        cwd |= from << ((n & 15) << 1);
+        ++n;
+        if ((n & 15) == 0) { if (lane == 0) codes[(n >> 4) - 1] = cwd; cwd = 0; }
+        if (from == 0u) {                                /* FROM_D: two bands back */
+            const int b1 = b - 1, g1 = b1 >> 5;
+            if (g1 != mgrp) { mw = trace[g1 * 64 + ABEA_MOVE_LANE]; mgrp = g1; }
+            const int mv_b1 = (sel4(mw, (b1 >> 3) & 3) >> ((7 - (b1 & 7)) * 4)) & 1;
+            llk -= mv_b + mv_b1; e -= 1; k -= 1; b -= 2; gap = 0;
+        } else if (from == 1u) {                         /* FROM_U */
+            llk -= mv_b; e -= 1; b -= 1; gap = 0;
+        } else {                                         /* FROM_L */
+            llk -= mv_b; k -= 1; b -= 1; gap += 1; max_gap = max(max_gap, gap);
+        }
+    }
+    if ((n & 15) != 0 && lane == 0) codes[n >> 4] = cwd;
+    __syncthreads();                                     /* lane 0's code words -> all lanes */
+
+    /* ---- expansion: prefix sums turn codes into (k,e) pairs written in forward order;
+     *      log-emissions are summed in walk order, in double (align.c:473-476) ---- */
+    double sum = 0.0;
+    int base_k = K - 1, base_e = fo.best_event;
+    for (int c0 = 0; c0 < n; c0 += 1024) {
+        const int i0 = c0 + 16 * lane;
+        const int cnt = max(0, min(16, n - i0));
+        const uint32_t w = (cnt > 0) ? codes[(c0 >> 4) + lane] : 0u;
+        int dk = 0, de = 0;
+        #pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const uint32_t cd = (w >> (2 * j)) & 3u;
+            if (j < cnt) { dk += (cd != 1u); de += (cd != 2u); }
+        }
+        int tk, te;
+        const int pk = wave_excl_scan(dk, lane, tk), pe = wave_excl_scan(de, lane, te);
+        int kk = base_k - pk, ee = base_e - pe;
+        #pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            float lp = 0.f;
+            if (j < cnt) {
+                abea_pair_t p; p.ref_pos = kk; p.read_pos = ee;
+                pairs[n - 1 - (i0 + j)] = p;
+                const abea_kpar_t kp = kpar[kk];
+                const float dx = __fsub_rn(evm[ee], kp.gpm);
+                const float a = (float)((double)dx * kp.istd);
+                lp = __fadd_rn(kp.ck, __fmul_rn(__fmul_rn(-0.5f, a), a));
+                const uint32_t cd = (w >> (2 * j)) & 3u;
+                kk -= (cd != 1u); ee -= (cd != 2u);
+            }
+            lp_s[j * 64 + lane] = lp;                 /* [j][lane]: conflict-free stores */
+        }
+        __syncthreads();
+        const int m = min(1024, n - c0);
+        for (int i = 0; i < m; ++i) sum += (double)lp_s[(i & 15) * 64 + (i >> 4)];   /* uniform, strictly in walk order */
+        __syncthreads();
+        base_k -= tk; base_e -= te;
+    }
+
+    /* ---- QC (align.c:526-543) ---- */
+    const double avg = sum / (double)n;
+    const int spanned = (last_k == 0);                   /* first emitted pair is always k = K-1 */
+    const bool fail = (avg < -5.0) || !spanned || (max_gap > 50);
+    if (lane == 0) {
+        n_pairs[out_idx] = fail ? 0 : n;
+        if (diag) {
+            dg.sum_emission = sum; dg.n_aligned = n; dg.best_event = fo.best_event;
+            dg.max_score = fo.best_score; dg.max_gap = max_gap; dg.spanned = spanned;
+            dg.flags = fail ? ABEA_RF_QC_FAIL : 0;
+            diag[out_idx] = dg;
+        }
+    }
+}

@@ -1,0 +1,53 @@
+"""Pore-model tables (reference src/model.c): text format reader and the cached log(stdv)."""
+import math
+import numpy as np
+from .types import MODEL_DT
+
+
+def _finish(mean, stdv):
+    m = np.zeros(len(mean), dtype=MODEL_DT)
+    m["level_mean"] = mean
+    m["level_stdv"] = stdv
+    # model.c:93 / :179 — level_log_stdv = (float) log((double) level_stdv), libm log
+    m["level_log_stdv"] = np.array([math.log(float(s)) for s in m["level_stdv"]], dtype=np.float32)
+    return m
+
+
+def load_model_f32(path):
+    """Load a [4^k, 2] float32 (level_mean, level_stdv) table; returns (k, model_t[4^k])."""
+    tab = np.fromfile(path, dtype=np.float32).reshape(-1, 2)
+    k = int(round(math.log(len(tab), 4)))
+    assert 4 ** k == len(tab)
+    return k, _finish(tab[:, 0], tab[:, 1])
+
+
+def read_model_text(path):
+    """Reader for the nanopolish/f5c text model format (model.c:39-128): '#k' header, then
+    'kmer level_mean level_stdv ...' rows in lexicographic k-mer order."""
+    k = None
+    mean, stdv = [], []
+    for ln in open(path):
+        f = ln.split()
+        if not f:
+            continue
+        if f[0] == "#k":
+            k = int(f[1])
+        if ln[0] == "#" or f[0] == "kmer":
+            continue
+        mean.append(np.float32(f[1]))
+        stdv.append(np.float32(f[2]))
+    if k is None:
+        k = int(round(math.log(len(mean), 4)))
+    if len(mean) != 4 ** k:
+        raise ValueError(f"{path}: expected {4**k} k-mers, found {len(mean)}")
+    return k, _finish(np.array(mean, dtype=np.float32), np.array(stdv, dtype=np.float32))
+
+
+def synthetic_model(k, seed=9):
+    """Synthetic 4^k-entry table for configs with no table in the reference mount (R10 9-mer):
+    mean ~ N(90, 12^2) clamped [50,140], stdv ~ U[1.5, 4.0]."""
+    rng = np.random.default_rng(seed)
+    n = 4 ** k
+    mean = np.clip(rng.normal(90.0, 12.0, n), 50.0, 140.0).astype(np.float32)
+    stdv = rng.uniform(1.5, 4.0, n).astype(np.float32)
+    return _finish(mean, stdv)

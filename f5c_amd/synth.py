@@ -1,0 +1,221 @@
+"""Deterministic synthetic read/event batches in the flattened layout of the reference's device
+arrays (src/f5c.cu:672-690): the workloads BASELINE.json names.
+
+  reads      uint8  Σ(L+1)   sequences, each NUL-terminated
+  read_ptr   int64  [n]      offset of read i in `reads`
+  read_len   int32  [n]
+  events     event_t Σ E     AoS {start u64, length f32, mean f32, stdv f32}
+  event_ptr  int64  [n]
+  n_events   int32  [n]
+  pair_ptr   int64  [n]      offset of read i's output pairs; capacity n_events+read_len (f5c.c:724)
+  scalings   scalings_t [n]  method-of-moments estimate (align.c:58-106 restated with numpy)
+
+Read synthesis: bases i.i.d. ACGT; each k-mer emits d events, d = 0 with p=0.04 else 1+Poisson(1.08)
+(≈2 events/base, a few skips); event.mean = scale_t*model.mean + shift_t + N(0,(1.3*model.stdv)^2);
+≈1 % of reads get pure-noise signal (exercise the QC-fail path).  Generation is chunked and seeded
+per chunk ([seed, chunk]) so any box regenerates the identical batch.
+"""
+import numpy as np
+from .types import EVENT_DT, SCAL_DT
+
+_BASES = np.frombuffer(b"ACGT", dtype=np.uint8)
+
+CONFIGS = {
+    # name: (n_reads, seed, length law, k)   BASELINE.json configs[1..4]
+    "r9_10k_8kb": dict(n_reads=10_000, seed=20250002, law="gamma8k", k=6),
+    "r9_100k_mixed": dict(n_reads=100_000, seed=20250003, law="loguniform", k=6),
+    "r10_50k_10kb": dict(n_reads=50_000, seed=20250005, law="gamma10k", k=9),
+}
+
+
+def read_lengths(law, n, rng):
+    if law == "gamma8k":
+        L = rng.gamma(4.0, 8000.0 / 4.0, n)
+        return np.clip(L, 1000, 30000).astype(np.int64)
+    if law == "gamma10k":
+        L = rng.gamma(4.0, 10000.0 / 4.0, n)
+        return np.clip(L, 1000, 40000).astype(np.int64)
+    if law == "loguniform":
+        return np.exp(rng.uniform(np.log(1000.0), np.log(50000.0), n)).astype(np.int64)
+    if isinstance(law, (int, np.integer)):
+        return np.full(n, int(law), dtype=np.int64)
+    raise ValueError(law)
+
+
+def _kmer_ranks(codes, k):
+    """rank of the k-mer starting at every position of `codes` (valid for positions <= len-k)."""
+    n = len(codes) - k + 1
+    r = np.zeros(n, dtype=np.int64)
+    for j in range(k):
+        r = (r << 2) | codes[j:j + n]
+    return r
+
+
+def _chunk(lengths, model, k, rng, bad_frac):
+    n = len(lengths)
+    tot = int(lengths.sum())
+    codes = rng.integers(0, 4, tot, dtype=np.int64)
+    starts = np.concatenate([[0], np.cumsum(lengths)[:-1]])
+    K = lengths - k + 1
+    # k-mer start positions (exclude k-mers that would straddle two reads)
+    kpos = np.concatenate([np.arange(s, s + kk) for s, kk in zip(starts, K)])
+    kread = np.repeat(np.arange(n), K)
+    ranks = _kmer_ranks(np.concatenate([codes, np.zeros(k, dtype=np.int64)]), k)[kpos]
+    d = np.where(rng.random(len(kpos), dtype=np.float32) < 0.04, 0, 1 + rng.poisson(1.08, len(kpos))).astype(np.int64)
+    # every read needs at least one event
+    first = np.concatenate([[0], np.cumsum(K)[:-1]])
+    d[first] = np.maximum(d[first], 1)
+    E = np.bincount(kread, weights=d, minlength=n).astype(np.int64)
+    ev_rank = np.repeat(ranks, d)
+    ev_read = np.repeat(kread, d)
+    scale_t = rng.normal(1.0, 0.04, n)
+    shift_t = rng.normal(0.0, 6.0, n)
+    mu = model["level_mean"][ev_rank]
+    sd = model["level_stdv"][ev_rank]
+    noise = rng.standard_normal(len(ev_rank), dtype=np.float32)
+    mean = scale_t.astype(np.float32)[ev_read] * mu + shift_t.astype(np.float32)[ev_read] + noise * (1.3 * sd)
+    bad = rng.random(n) < bad_frac
+    if bad.any():
+        bmask = bad[ev_read]
+        mean[bmask] = 90.0 + 12.0 * rng.standard_normal(int(bmask.sum()), dtype=np.float32)
+    length = (1 + rng.poisson(8.0, len(ev_rank))).astype(np.float32)
+    ev = np.zeros(len(ev_rank), dtype=EVENT_DT)
+    ev["mean"] = mean.astype(np.float32)
+    ev["length"] = length
+    ev["stdv"] = 0.5 + 2.5 * rng.random(len(ev_rank), dtype=np.float32)
+    estart = np.concatenate([[0], np.cumsum(E)[:-1]])
+    cs = np.cumsum(length.astype(np.int64))
+    run = cs - length.astype(np.int64)
+    ev["start"] = (run - np.repeat(run[estart], E)).astype(np.uint64)
+    # method-of-moments scalings (align.c:58-106), float64 numpy reductions
+    m32 = ev["mean"].astype(np.float64)
+    ev_sum = np.bincount(ev_read, weights=m32, minlength=n)
+    km = model["level_mean"].astype(np.float64)[ranks]
+    km_sum = np.bincount(kread, weights=km, minlength=n)
+    km_sq = np.bincount(kread, weights=km * km, minlength=n)
+    shift = ev_sum / E - km_sum / K
+    ev_sq = np.bincount(ev_read, weights=(m32 - shift[ev_read]) ** 2, minlength=n)
+    scale = (ev_sq / E) / (km_sq / K)
+    sc = np.zeros(n, dtype=SCAL_DT)
+    sc["scale"] = scale.astype(np.float32)
+    sc["shift"] = shift.astype(np.float32)
+    sc["var"] = 1.0
+    # sequences with NUL terminators
+    seq = np.zeros(tot + n, dtype=np.uint8)
+    dst = np.arange(tot) + np.repeat(np.arange(n), lengths)
+    seq[dst] = _BASES[codes]
+    return seq, ev, E.astype(np.int32), sc, bad
+
+
+_G = {}
+
+
+def _chunk_job(c):
+    L, model, k, seed, bad_frac, chunk_reads = _G["args"]
+    rng = np.random.default_rng([seed, c + 1])
+    return _chunk(L[c * chunk_reads:(c + 1) * chunk_reads], model, k, rng, bad_frac)
+
+
+def make_batch(n_reads, model, k, seed, law="gamma8k", bad_frac=0.01, chunk_reads=256, lengths=None,
+               workers=1):
+    """Build a flattened batch. `lengths` overrides the length law (array of read lengths).
+    `workers` > 1 generates chunks in forked processes (same result: chunks are seeded independently)."""
+    rng0 = np.random.default_rng([seed, 0x5EED])
+    L = np.asarray(lengths, dtype=np.int64) if lengths is not None else read_lengths(law, n_reads, rng0)
+    n_reads = len(L)
+    n_chunks = (n_reads + chunk_reads - 1) // chunk_reads
+    _G["args"] = (L, model, k, seed, bad_frac, chunk_reads)
+    if workers > 1 and n_chunks > 1:
+        import multiprocessing as mp
+        with mp.get_context("fork").Pool(min(workers, n_chunks)) as pool:
+            parts = pool.map(_chunk_job, range(n_chunks), chunksize=1)
+    else:
+        parts = [_chunk_job(c) for c in range(n_chunks)]
+    seqs = [p[0] for p in parts]; evs = [p[1] for p in parts]; Es = [p[2] for p in parts]
+    scs = [p[3] for p in parts]; bads = [p[4] for p in parts]
+    E = np.concatenate(Es) if Es else np.zeros(0, np.int32)
+    batch = {
+        "reads": np.concatenate(seqs) if seqs else np.zeros(0, np.uint8),
+        "read_len": L.astype(np.int32),
+        "read_ptr": np.concatenate([[0], np.cumsum(L + 1)[:-1]]).astype(np.int64) if n_reads else np.zeros(0, np.int64),
+        "events": np.concatenate(evs) if evs else np.zeros(0, EVENT_DT),
+        "n_events": E,
+        "event_ptr": np.concatenate([[0], np.cumsum(E.astype(np.int64))[:-1]]).astype(np.int64) if n_reads else np.zeros(0, np.int64),
+        "scalings": np.concatenate(scs) if scs else np.zeros(0, SCAL_DT),
+        "bad": np.concatenate(bads) if bads else np.zeros(0, bool),
+    }
+    cap = E.astype(np.int64) + L
+    batch["pair_ptr"] = (np.concatenate([[0], np.cumsum(cap)[:-1]]).astype(np.int64)
+                         if n_reads else np.zeros(0, np.int64))
+    batch["pair_cap"] = int(cap.sum())
+    return batch
+
+
+def batch_from_reads(seqs, events_list, scalings):
+    """Flatten explicit reads: seqs = list of bytes, events_list = list of EVENT_DT arrays,
+    scalings = list of (scale, shift)."""
+    n = len(seqs)
+    L = np.array([len(s) for s in seqs], dtype=np.int64)
+    E = np.array([len(e) for e in events_list], dtype=np.int64)
+    reads = np.zeros(int(L.sum()) + n, dtype=np.uint8)
+    rp = np.concatenate([[0], np.cumsum(L + 1)[:-1]]).astype(np.int64) if n else np.zeros(0, np.int64)
+    for i, s in enumerate(seqs):
+        reads[rp[i]:rp[i] + L[i]] = np.frombuffer(s, dtype=np.uint8)
+    sc = np.zeros(n, dtype=SCAL_DT)
+    for i, (a, b) in enumerate(scalings):
+        sc["scale"][i] = a
+        sc["shift"][i] = b
+        sc["var"][i] = 1.0
+    cap = E + L
+    return {
+        "reads": reads, "read_len": L.astype(np.int32), "read_ptr": rp,
+        "events": (np.concatenate(events_list) if n and E.sum() else np.zeros(0, EVENT_DT)),
+        "n_events": E.astype(np.int32),
+        "event_ptr": np.concatenate([[0], np.cumsum(E)[:-1]]).astype(np.int64) if n else np.zeros(0, np.int64),
+        "scalings": sc,
+        "pair_ptr": np.concatenate([[0], np.cumsum(cap)[:-1]]).astype(np.int64) if n else np.zeros(0, np.int64),
+        "pair_cap": int(cap.sum()),
+        "bad": np.zeros(n, bool),
+    }
+
+
+def shard_batch(batch, rank, world):
+    """LPT shard of a batch over `world` GPUs: reads sorted by band count E+K
+    descending are dealt greedily to the lightest bin; returns the sub-batch of `rank` plus the
+    original read indices it holds."""
+    import heapq
+    n = len(batch["read_len"])
+    w = batch["n_events"].astype(np.int64) + batch["read_len"].astype(np.int64)
+    order = np.argsort(-w, kind="stable")
+    heap = [(0, r) for r in range(world)]
+    bins = [[] for _ in range(world)]
+    for i in order:
+        load, r = heapq.heappop(heap)
+        bins[r].append(int(i))
+        heapq.heappush(heap, (load + int(w[i]), r))
+    idx = np.array(sorted(bins[rank]), dtype=np.int64)
+    return take_reads(batch, idx), idx
+
+
+def take_reads(batch, idx):
+    """Sub-batch holding reads `idx` (in that order), re-flattened."""
+    idx = np.asarray(idx, dtype=np.int64)
+    L = batch["read_len"][idx].astype(np.int64)
+    E = batch["n_events"][idx].astype(np.int64)
+    n = len(idx)
+    rp = np.concatenate([[0], np.cumsum(L + 1)[:-1]]).astype(np.int64) if n else np.zeros(0, np.int64)
+    ep = np.concatenate([[0], np.cumsum(E)[:-1]]).astype(np.int64) if n else np.zeros(0, np.int64)
+    reads = np.zeros(int((L + 1).sum()), dtype=np.uint8)
+    events = np.zeros(int(E.sum()), dtype=EVENT_DT)
+    for j, i in enumerate(idx):
+        s = batch["read_ptr"][i]
+        reads[rp[j]:rp[j] + L[j]] = batch["reads"][s:s + L[j]]
+        s = batch["event_ptr"][i]
+        events[ep[j]:ep[j] + E[j]] = batch["events"][s:s + E[j]]
+    cap = E + L
+    return {
+        "reads": reads, "read_len": L.astype(np.int32), "read_ptr": rp, "events": events,
+        "n_events": E.astype(np.int32), "event_ptr": ep, "scalings": batch["scalings"][idx].copy(),
+        "pair_ptr": np.concatenate([[0], np.cumsum(cap)[:-1]]).astype(np.int64) if n else np.zeros(0, np.int64),
+        "pair_cap": int(cap.sum()), "bad": batch["bad"][idx].copy(),
+    }

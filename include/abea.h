@@ -1,0 +1,135 @@
+/* include/abea.h — C ABI of libabea_hip.so: MI355X-native adaptive banded event alignment.
+ *
+ * Drop-in boundary for the GPU branch of f5c's align_db() (reference src/f5c.c:833-845).
+ * Every entry point names the reference interface it replaces.  Plain pointers and sizes
+ * only; no C++/STL/htslib/torch types cross this boundary.  All functions return 0 on
+ * success and a negative ABEA_E* code on failure (abea_last_error() has the message);
+ * the f5c-facing shim (f5c_amd/csrc/f5c_shim.h) turns a failure into the reference's
+ * print-and-exit convention (src/error.h:38-92, src/f5cmisc.cuh:78-97).
+ *
+ * There is no CPU fallback inside this library: a read is either aligned on the GPU or
+ * reported as skipped (n_pairs = 0 by the reference's own guards).
+ */
+#ifndef ABEA_H
+#define ABEA_H
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ABEA_BANDWIDTH 100          /* ALN_BANDWIDTH, src/f5c.h:34 (compile-time in the reference too) */
+#define ABEA_MAX_KMER_SIZE 9        /* MAX_KMER_SIZE, src/f5c.h:30 */
+
+#define ABEA_OK            0
+#define ABEA_EINVAL       -1        /* bad argument */
+#define ABEA_EHIP         -2        /* HIP runtime error */
+#define ABEA_ENOMEM       -3        /* a single read does not fit the device arena */
+#define ABEA_ENODEV       -4        /* no usable gfx950 device */
+
+/* ---- POD mirrors of the f5c data contract (layout-identical, static_asserted in abea_capi.cpp) ---- */
+typedef struct { uint64_t start; float length; float mean; float stdv; } abea_event_t;          /* event_t     src/f5c.h:129-136 */
+typedef struct { float level_mean; float level_stdv; float level_log_stdv; } abea_model_t;       /* model_t     src/f5c.h:147-155 */
+typedef struct { float scale; float shift; float var; float log_var; } abea_scalings_t;          /* scalings_t  src/f5c.h:158-172 */
+typedef struct { int32_t ref_pos; int32_t read_pos; } abea_pair_t;                               /* AlignedPair src/f5c.h:181-184 */
+
+/* Per-read quantities align() computes but f5c does not return (src/align.c:415-445,526-535);
+ * optional output used by the parity tests for the "scores within 1e-4" check. */
+typedef struct {
+    double  sum_emission;   /* Σ log-emission along the path, reverse path order (align.c:476) */
+    int32_t n_aligned;      /* pairs emitted before QC (align.c:480) */
+    int32_t best_event;     /* end event chosen by the end-point scan (align.c:442) */
+    float   max_score;      /* its score (align.c:441); -inf if no end cell was in band */
+    int32_t max_gap;        /* align.c:497 */
+    int32_t spanned;        /* align.c:529-530 */
+    int32_t flags;          /* ABEA_RF_* */
+    int32_t pad;
+} abea_read_diag;
+#define ABEA_RF_SKIPPED   0x1   /* failed the align_single guards (f5c.c:813-814) or shorter than k: n_pairs = 0 */
+#define ABEA_RF_NO_END    0x2   /* no in-band end cell (max_score == -inf): n_pairs = 0 */
+#define ABEA_RF_QC_FAIL   0x4   /* align.c:534-543 */
+
+typedef struct abea_ctx abea_ctx;   /* opaque; owns the device arena, the model copy, a stream (cuda_data_t, src/f5c.h:356-386) */
+
+typedef struct {
+    int32_t  device_id;         /* opt.cuda_dev_id            src/f5c.h:124 */
+    uint32_t kmer_size;         /* core->kmer_size            src/f5c.h:399-ish; 4^k model entries */
+    const abea_model_t* model;  /* core->model (host)         src/f5c.c:286 */
+    float    mem_frac;          /* opt.cuda_mem_frac          fraction of free device memory for the arena (0 -> 0.9, MEM_FACTOR f5cmisc.cuh:48) */
+    uint64_t max_arena_bytes;   /* 0 = no cap; otherwise cap the arena (tests/bench keep room for the batch itself) */
+    int32_t  verbosity;         /* opt.verbosity */
+    int32_t  reserved;
+} abea_cfg;
+
+/* Replaces init_cuda(core_t*)   src/f5c.cu:23-202  (device select, model H2D, one-shot arena). */
+int  abea_init(abea_ctx** ctx, const abea_cfg* cfg);
+/* Replaces free_cuda(core_t*)   src/f5c.cu:204-234. */
+void abea_free(abea_ctx* ctx);
+/* Message of the last failure on the calling thread. */
+const char* abea_last_error(void);
+
+/* ---- host batch: the db_t fields align_cuda() reads and writes (src/f5c.cu:647-1061) ---- */
+typedef struct {
+    int32_t n_reads;                       /* db->n_bam_rec */
+    const char* const* read;               /* db->read[i]   NUL-terminated, upper case */
+    const int32_t* read_len;               /* db->read_len[i] */
+    const abea_event_t* const* events;     /* db->et[i].event */
+    const uint64_t* n_events;              /* db->et[i].n */
+    const abea_scalings_t* scalings;       /* db->scalings[i] (scale, shift used) */
+    const int64_t* n_samples;              /* db->sig[i]->nsample ; NULL = all reads good */
+    abea_pair_t* const* pairs;             /* db->event_align_pairs[i], caller-allocated, capacity n_events+read_len (f5c.c:724) */
+    int32_t* n_pairs;                      /* db->n_event_align_pairs[i] */
+    abea_read_diag* diag;                  /* optional [n_reads], may be NULL */
+} abea_host_batch;
+
+/* Replaces align_cuda(core_t*, db_t*)  src/f5c.cu:647-1061 : flatten + H2D + kernels + D2H. */
+int abea_align_batch_host(abea_ctx* ctx, const abea_host_batch* batch);
+
+/* ---- device-resident flattened batch: the layout of the reference's device arrays (src/f5c.cu:672-690) ---- */
+typedef struct {
+    int32_t n_reads;
+    /* index arrays: HOST pointers (the reference keeps host copies too: cuda_data_t *_host, f5c.h:357-366) */
+    const int64_t* read_ptr;     /* offset of read i in `reads` (chars)                 */
+    const int32_t* read_len;
+    const int64_t* event_ptr;    /* offset of read i in `events`                        */
+    const int32_t* n_events;
+    const int64_t* pair_ptr;     /* offset of read i in `pairs`; capacity n_events+read_len */
+    const abea_scalings_t* scalings;   /* HOST pointer, [n_reads] */
+    /* bulk arrays: DEVICE pointers */
+    const char* reads;           /* flattened sequences, Σ(read_len+1)                  */
+    const abea_event_t* events;  /* flattened AoS event tables, Σ n_events              */
+    abea_pair_t* pairs;          /* out                                                  */
+    int32_t* n_pairs;            /* out [n_reads]                                        */
+    abea_read_diag* diag;        /* out [n_reads], optional (NULL)                       */
+} abea_device_batch;
+
+/* Same computation with inputs/outputs already in HBM (what bench.py times). Synchronous. */
+int abea_align_batch_device(abea_ctx* ctx, const abea_device_batch* batch);
+
+/* ---- timing / accounting of the last batch (core_t timing fields, src/f5c.h:457-466) ---- */
+typedef struct {
+    double pre_ms, fill_ms, trace_ms;     /* HIP-event kernel times on the library's stream, summed over sub-batches */
+    double h2d_ms, d2h_ms, host_ms;       /* host batch only */
+    double total_ms;                      /* wall time of the call */
+    int64_t n_reads_gpu, n_reads_skipped, n_sub_batches;
+    int64_t sum_events, sum_bands, sum_pairs;
+    int64_t fill_launches;                /* number of fill-kernel launches (== n_sub_batches) */
+    uint64_t arena_bytes;
+    uint64_t bytes_ref;                   /* algorithmic bytes A_ref of the reads run */
+    uint64_t bytes_min;                   /* strict floor A_min */
+    uint64_t bytes_moved;                 /* bytes this implementation reads+writes in HBM by construction */
+} abea_stats;
+int abea_get_stats(abea_ctx* ctx, abea_stats* out);
+
+/* Library / device introspection: "gfx950", CU count; used by tests to assert the native path ran. */
+int abea_device_info(abea_ctx* ctx, char* arch, size_t arch_len, int32_t* n_cu, uint64_t* arena_bytes);
+
+/* Hardware self-test of the cross-lane primitives the fill kernel relies on (DPP wave shifts,
+ * readlane/writelane); returns 0 when the semantics are as assumed. */
+int abea_selftest(abea_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ABEA_H */

@@ -1,0 +1,384 @@
+/* oracle/abea_oracle.c — TEST INFRASTRUCTURE ONLY (see abea_oracle.h).
+ *
+ * A plain-C restatement of the reference CPU path of f5c's adaptive banded
+ * event alignment.  Written from the algorithm description (SURVEY.md §3.2,
+ * §9), each function cites the reference lines it follows.  It keeps the
+ * reference's cost profile on purpose (per-read malloc, full −inf/0 init pass,
+ * scalar cell loop) because bench.py times it as the "port" CPU baseline.
+ *
+ * Build: gcc -O2 -ffp-contract=off (reference flags Makefile:8 are -O2 with
+ * no FMA on x86-64; contraction must stay off so float expressions round
+ * exactly like the reference build).
+ */
+#include "abea_oracle.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <pthread.h>
+
+#define ORC_BW 100                 /* ALN_BANDWIDTH f5c.h:34 */
+#define ORC_FROM_D 0               /* align.c:194-196 */
+#define ORC_FROM_U 1
+#define ORC_FROM_L 2
+
+/* align.c:19-32 : A0 C1 G2 T3, anything else 0 (the reference also prints a warning) */
+static inline uint32_t base_rank(char b) {
+    switch (b) {
+        case 'C': return 1;
+        case 'G': return 2;
+        case 'T': return 3;
+        default:  return 0;
+    }
+}
+
+/* align.c:36-47 : first base most significant */
+uint32_t orc_kmer_rank(const char* s, uint32_t k) {
+    uint32_t r = 0;
+    for (uint32_t j = 0; j < k; ++j) r = (r << 2) | base_rank(s[j]);
+    return r;
+}
+
+/* align.c:58-106 : method-of-moments shift/scale, all accumulations in double, event order */
+orc_scalings_t orc_estimate_scalings(const char* seq, int32_t seq_len, const orc_model_t* model,
+                                     uint32_t k, const orc_event_t* ev, size_t n_events) {
+    orc_scalings_t out;
+    memset(&out, 0, sizeof out);
+    int32_t n_kmers = seq_len - (int32_t)k + 1;
+
+    double ev_sum = 0.0;
+    for (size_t i = 0; i < n_events; ++i) ev_sum += ev[i].mean;
+
+    double km_sum = 0.0, km_sq = 0.0;
+    for (int32_t i = 0; i < n_kmers; ++i) {
+        double l = model[orc_kmer_rank(seq + i, k)].level_mean;
+        km_sum += l;
+        km_sq += l * l;
+    }
+    double shift = ev_sum / n_events - km_sum / n_kmers;
+
+    double ev_sq = 0.0;
+    for (size_t i = 0; i < n_events; ++i) {
+        ev_sq += (ev[i].mean - shift) * (ev[i].mean - shift);
+    }
+    double scale = (ev_sq / n_events) / (km_sq / n_kmers);
+    out.shift = (float)shift;
+    out.scale = (float)scale;
+    return out;
+}
+
+/* align.c:108-154 : all-float, no FMA; var treated as 1, cached log(stdv) (CACHED_LOG f5c.h:82) */
+static inline float emission_lp(float x, float scale, float shift, const orc_model_t* m) {
+    float gp_mean = scale * m->level_mean + shift;
+    float gp_stdv = m->level_stdv * 1;
+    float gp_log_stdv = m->level_log_stdv;
+    float log_inv_sqrt_2pi = -0.918938f;
+    float a = (x - gp_mean) / gp_stdv;
+    return log_inv_sqrt_2pi - gp_log_stdv + (-0.5f * a * a);
+}
+
+typedef struct { int e; int k; } ll_t;      /* align.c:265-268 */
+
+int32_t orc_align(orc_pair_t* out, const char* seq, int32_t seq_len,
+                  const orc_event_t* ev, size_t n_events, const orc_model_t* model,
+                  uint32_t k, float scale, float shift, orc_diag_t* diag) {
+    const size_t E = n_events;
+    const size_t K = (size_t)seq_len - k + 1;                 /* align.c:191 */
+    const int W = ORC_BW, HALF = ORC_BW / 2;
+
+    /* align.c:207-216 : transition penalties, double, glibc log/exp */
+    double events_per_kmer = (double)E / K;
+    double p_stay = 1 - (1 / (events_per_kmer + 1));
+    double epsilon = 1e-10;
+    double lp_skip = log(epsilon);
+    double lp_stay = log(p_stay);
+    double lp_step = log(1.0 - exp(lp_skip) - exp(lp_stay));
+    double lp_trim = log(0.01);
+
+    const size_t n_bands = (E + 1) + (K + 1);                 /* align.c:219-221 */
+
+    size_t* ranks = (size_t*)malloc(sizeof(size_t) * K);      /* align.c:226-234 */
+    for (size_t i = 0; i < K; ++i) ranks[i] = orc_kmer_rank(seq + i, k);
+
+    float*   bands = (float*)malloc(sizeof(float) * n_bands * W);     /* align.c:242-245 */
+    uint8_t* trace = (uint8_t*)malloc(sizeof(uint8_t) * n_bands * W);
+    ll_t*    ll    = (ll_t*)malloc(sizeof(ll_t) * n_bands);           /* align.c:270-272 */
+    for (size_t b = 0; b < n_bands; ++b) {                            /* align.c:247-259 */
+        for (int j = 0; j < W; ++j) {
+            bands[b * W + j] = -INFINITY;
+            trace[b * W + j] = 0;
+        }
+    }
+#define BAND(b, o)  bands[(size_t)(b) * W + (o)]
+#define TRACE(b, o) trace[(size_t)(b) * W + (o)]
+
+    /* align.c:277-291 : first two bands */
+    ll[0].e = HALF - 1;  ll[0].k = -1 - HALF;
+    ll[1].e = ll[0].e + 1;  ll[1].k = ll[0].k;
+    BAND(0, (-1) - ll[0].k) = 0.0f;
+    {
+        int o = ll[1].e - 0;
+        BAND(1, o) = lp_trim;
+        TRACE(1, o) = ORC_FROM_U;
+    }
+
+    /* align.c:300-410 : fill */
+    for (size_t b = 2; b < n_bands; ++b) {
+        float s_ll = BAND(b - 1, 0), s_ur = BAND(b - 1, W - 1);
+        int ll_ob = s_ll == -INFINITY, ur_ob = s_ur == -INFINITY;
+        int right = (ll_ob && ur_ob) ? (b % 2 == 1) : (s_ll < s_ur);  /* align.c:309-314 */
+        if (right) { ll[b].e = ll[b - 1].e;     ll[b].k = ll[b - 1].k + 1; }
+        else       { ll[b].e = ll[b - 1].e + 1; ll[b].k = ll[b - 1].k; }
+
+        int trim_o = (-1) - ll[b].k;                                   /* align.c:324-333 */
+        if (trim_o >= 0 && trim_o < W) {
+            int64_t e = ll[b].e - trim_o;
+            if (e >= 0 && e < (int64_t)E) {
+                BAND(b, trim_o) = lp_trim * (e + 1);
+                TRACE(b, trim_o) = ORC_FROM_U;
+            } else {
+                BAND(b, trim_o) = -INFINITY;
+            }
+        }
+
+        /* align.c:337-346 ; note (int)(K) and (int)(E-1) as the reference's int conversions */
+        int kmin = 0 - ll[b].k, kmax = (int)K - ll[b].k;
+        int emin = ll[b].e - (int)(E - 1), emax = ll[b].e - (-1);
+        int lo = kmin > emin ? kmin : emin;  if (lo < 0) lo = 0;
+        int hi = kmax < emax ? kmax : emax;  if (hi > W) hi = W;
+
+        for (int o = lo; o < hi; ++o) {
+            int e = ll[b].e - o, kk = ll[b].k + o;
+            int o_up   = ll[b - 1].e - (e - 1);                        /* align.c:354-356 */
+            int o_left = (kk - 1) - ll[b - 1].k;
+            int o_diag = (kk - 1) - ll[b - 2].k;
+            float up   = (o_up   >= 0 && o_up   < W) ? BAND(b - 1, o_up)   : -INFINITY;
+            float left = (o_left >= 0 && o_left < W) ? BAND(b - 1, o_left) : -INFINITY;
+            float diag = (o_diag >= 0 && o_diag < W) ? BAND(b - 2, o_diag) : -INFINITY;
+
+            float lp = emission_lp(ev[e].mean, scale, shift, &model[ranks[kk]]);
+            float sd = diag + lp_step + lp;                            /* align.c:382-384 : double sums, one rounding */
+            float su = up + lp_stay + lp;
+            float sl = left + lp_skip;
+
+            float m = sd;  uint8_t from = ORC_FROM_D;                  /* align.c:386-392 */
+            m = su > m ? su : m;
+            from = m == su ? ORC_FROM_U : from;
+            m = sl > m ? sl : m;
+            from = m == sl ? ORC_FROM_L : from;
+            BAND(b, o) = m;
+            TRACE(b, o) = from;
+        }
+    }
+
+    /* align.c:424-445 : end-point scan, first strict max */
+    float max_score = -INFINITY;
+    int cur_e = 0, cur_k = (int)K - 1;
+    for (size_t e = 0; e < E; ++e) {
+        int b = ((int)e + 1) + (cur_k + 1);
+        int o = ll[b].e - (int)e;
+        if (o >= 0 && o < W) {
+            float s = BAND(b, o) + (E - e) * lp_trim;
+            if (s > max_score) { max_score = s; cur_e = (int)e; }
+        }
+    }
+    int best_event = cur_e;
+
+    /* align.c:452-499 : traceback */
+    double sum_emission = 0, n_aligned = 0;
+    int n_out = 0, gap = 0, max_gap = 0, oob = 0;
+    while (cur_k >= 0 && cur_e >= 0) {
+        out[n_out].ref_pos = cur_k;
+        out[n_out].read_pos = cur_e;
+        n_out++;
+        float lp = emission_lp(ev[cur_e].mean, scale, shift, &model[orc_kmer_rank(seq + cur_k, k)]);
+        sum_emission += lp;
+        n_aligned += 1;
+
+        int b = (cur_e + 1) + (cur_k + 1);
+        int o = ll[b].e - cur_e;
+        /* the reference indexes the flat trace array with an unchecked offset (align.c:177,486);
+         * reproduce the flat index when it stays inside the buffer, flag it otherwise */
+        int64_t flat = (int64_t)b * W + o;
+        if (flat < 0 || flat >= (int64_t)(n_bands * W)) { oob = 1; break; }
+        uint8_t from = trace[flat];
+        if (from == ORC_FROM_D)      { cur_k -= 1; cur_e -= 1; gap = 0; }
+        else if (from == ORC_FROM_U) { cur_e -= 1; gap = 0; }
+        else { cur_k -= 1; gap += 1; if (gap > max_gap) max_gap = gap; }
+    }
+
+    for (int i = 0, j = n_out - 1; i < j; ++i, --j) {                  /* align.c:503-513 */
+        orc_pair_t t = out[i]; out[i] = out[j]; out[j] = t;
+    }
+
+    /* align.c:526-543 : QC */
+    double avg = sum_emission / n_aligned;
+    int spanned = n_out > 0 && out[0].ref_pos == 0 && out[n_out - 1].ref_pos == (int)(K - 1);
+    int pre_qc = n_out;
+    if (oob || avg < -5.0 || !spanned || max_gap > 50) n_out = 0;
+
+    if (diag) {
+        diag->sum_emission = sum_emission;
+        diag->n_aligned = pre_qc;
+        diag->best_event = best_event;
+        diag->max_score = max_score;
+        diag->max_gap = max_gap;
+        diag->spanned = spanned;
+        diag->oob = oob;
+        diag->pad = 0;
+    }
+    free(ranks); free(bands); free(trace); free(ll);
+#undef BAND
+#undef TRACE
+    return n_out;
+}
+
+/* f5c.c:811-830 */
+int32_t orc_align_single(orc_pair_t* out, const char* seq, int32_t seq_len,
+                         const orc_event_t* ev, size_t n_events, int64_t nsample,
+                         const orc_model_t* model, uint32_t k, float scale, float shift, orc_diag_t* diag) {
+    if (diag) memset(diag, 0, sizeof *diag);
+    if (nsample > 0 && (n_events) / (float)(seq_len) < 15.0f && seq_len >= (int32_t)k && n_events > 0) {
+        return orc_align(out, seq, seq_len, ev, n_events, model, k, scale, shift, diag);
+    }
+    return 0;
+}
+
+/* ---- batch driver: pthread_db-shaped pool (f5c.c:575-679) ---- */
+typedef struct {
+    int32_t n_reads; const char* reads; const int64_t* read_ptr; const int32_t* read_len;
+    const orc_event_t* events; const int64_t* event_ptr; const int32_t* n_events;
+    const orc_scalings_t* scalings; const orc_model_t* model; uint32_t k;
+    orc_pair_t* pairs; const int64_t* pair_ptr; int32_t* n_pairs; orc_diag_t* diags;
+} batch_t;
+
+typedef struct worker_s {
+    const batch_t* B;
+    int32_t start, end;            /* static block, start advanced atomically (f5c.c:592,612) */
+    struct worker_s* all; int32_t n_workers; int32_t id;
+} worker_t;
+
+static void do_read(const batch_t* B, int32_t i) {
+    B->n_pairs[i] = orc_align_single(B->pairs + B->pair_ptr[i], B->reads + B->read_ptr[i], B->read_len[i],
+                                     B->events + B->event_ptr[i], (size_t)B->n_events[i], 1,
+                                     B->model, B->k, B->scalings[i].scale, B->scalings[i].shift,
+                                     B->diags ? &B->diags[i] : NULL);
+}
+
+static void* worker_main(void* arg) {
+    worker_t* w = (worker_t*)arg;
+    for (;;) {                                   /* own block */
+        int32_t i = __sync_fetch_and_add(&w->start, 1);
+        if (i >= w->end) break;
+        do_read(w->B, i);
+    }
+    for (;;) {                                   /* steal from the fullest (f5c.c:575-596) */
+        int32_t best = -1, left = 0;
+        for (int32_t t = 0; t < w->n_workers; ++t) {
+            int32_t rem = w->all[t].end - w->all[t].start;
+            if (rem > left) { left = rem; best = t; }
+        }
+        if (best < 0) break;
+        int32_t i = __sync_fetch_and_add(&w->all[best].start, 1);
+        if (i < w->all[best].end) do_read(w->B, i);
+    }
+    return NULL;
+}
+
+void orc_align_batch(int32_t n_reads, const char* reads, const int64_t* read_ptr, const int32_t* read_len,
+                     const orc_event_t* events, const int64_t* event_ptr, const int32_t* n_events,
+                     const orc_scalings_t* scalings, const orc_model_t* model, uint32_t k,
+                     orc_pair_t* pairs, const int64_t* pair_ptr, int32_t* n_pairs, orc_diag_t* diags,
+                     int32_t n_threads) {
+    batch_t B = { n_reads, reads, read_ptr, read_len, events, event_ptr, n_events, scalings, model, k,
+                  pairs, pair_ptr, n_pairs, diags };
+    if (n_threads < 1) n_threads = 1;
+    if (n_threads > n_reads) n_threads = n_reads > 0 ? n_reads : 1;
+    worker_t* ws = (worker_t*)calloc((size_t)n_threads, sizeof(worker_t));
+    pthread_t* th = (pthread_t*)calloc((size_t)n_threads, sizeof(pthread_t));
+    int32_t step = (n_reads + n_threads - 1) / n_threads;
+    for (int32_t t = 0; t < n_threads; ++t) {
+        ws[t].B = &B; ws[t].all = ws; ws[t].n_workers = n_threads; ws[t].id = t;
+        ws[t].start = t * step < n_reads ? t * step : n_reads;
+        ws[t].end = (t + 1) * step < n_reads ? (t + 1) * step : n_reads;
+    }
+    if (n_threads == 1) { worker_main(&ws[0]); }
+    else {
+        for (int32_t t = 0; t < n_threads; ++t) pthread_create(&th[t], NULL, worker_main, &ws[t]);
+        for (int32_t t = 0; t < n_threads; ++t) pthread_join(th[t], NULL);
+    }
+    free(ws); free(th);
+}
+
+/* ---- N1: postalign + recalibrate_model + QC flags (align.c:561-773, f5c.c:736-807) ---- */
+int32_t orc_scaling_single(const orc_pair_t* pairs, int32_t n_pairs, const char* seq, int32_t seq_len,
+                           const orc_event_t* ev, size_t n_events, const orc_model_t* model, uint32_t k,
+                           orc_scalings_t* sc, orc_index_pair_t* map, double* events_per_base,
+                           int32_t* read_stat_flag) {
+    (void)n_events;
+    int32_t n_kmers = seq_len - (int32_t)k + 1;
+    *events_per_base = 0;
+    if (n_pairs <= 0) { *read_stat_flag |= 0x002; return 0; }        /* FAILED_ALIGNMENT f5c.h:67 */
+
+    /* postalign align.c:571-602 */
+    for (int32_t i = 0; i < n_kmers; ++i) { map[i].start = -1; map[i].stop = -1; }
+    int32_t max_event = 0, min_event = INT32_MAX, prev_event = -1;
+    for (int32_t i = 0; i < n_pairs; ++i) {
+        int32_t ki = pairs[i].ref_pos, ei = pairs[i].read_pos;
+        if (ei != prev_event) {
+            if (map[ki].start == -1) map[ki].start = ei;
+            map[ki].stop = ei;
+        }
+        if (ei > max_event) max_event = ei;
+        if (ei < min_event) min_event = ei;
+        prev_event = ei;
+    }
+    *events_per_base = (double)(max_event - min_event) / n_kmers;
+
+    /* postalign align.c:606-657 fused with recalibrate_model align.c:677-723:
+     * walk k-mers in order, events start..stop, state 'M' when the k-mer rank changed */
+    int32_t n_align = 0, n_M = 0, prev_rank = -1;
+    double A00 = 0, A01 = 0, A11 = 0, b0 = 0, b1 = 0;
+    for (int32_t ki = 0; ki < n_kmers; ++ki) {
+        if (map[ki].start == -1) continue;
+        for (int32_t ei = map[ki].start; ei <= map[ki].stop; ++ei) {
+            int32_t rank = (int32_t)orc_kmer_rank(seq + ki, k);
+            if (prev_rank != rank) {
+                n_M++;
+                double e = ev[ei].mean, mu = model[rank].level_mean, sd = model[rank].level_stdv;
+                double inv_var = 1. / (sd * sd);
+                A00 += inv_var; A01 += mu * inv_var; A11 += mu * mu * inv_var;
+                b0 += e * inv_var; b1 += mu * e * inv_var;
+            }
+            n_align++;
+            prev_rank = rank;
+        }
+    }
+    int calibrated = 0;
+    if (n_M >= 200) {                                                 /* f5c.c:1185 min_num_events_to_rescale */
+        double A10 = A01;
+        double div = A00 * A11 - A01 * A10;
+        double x0 = -(A01 * b1 - A11 * b0) / div;
+        double x1 = (A00 * b1 - A10 * b0) / div;
+        double shift = x0, scale = x1, var = 0.;
+        prev_rank = -1;
+        for (int32_t ki = 0; ki < n_kmers; ++ki) {                    /* align.c:738-753 */
+            if (map[ki].start == -1) continue;
+            for (int32_t ei = map[ki].start; ei <= map[ki].stop; ++ei) {
+                int32_t rank = (int32_t)orc_kmer_rank(seq + ki, k);
+                if (prev_rank != rank) {
+                    double e = ev[ei].mean, mu = model[rank].level_mean, sd = model[rank].level_stdv;
+                    double yi = (e - shift - scale * mu);
+                    var += yi * yi / (sd * sd);
+                }
+                prev_rank = rank;
+            }
+        }
+        var /= n_M;
+        var = sqrt(var);
+        sc->shift = shift; sc->scale = scale; sc->var = var; sc->log_var = log(var);
+        calibrated = 1;
+    }
+    if (!calibrated || sc->var > 2.5) { *read_stat_flag |= 0x001; return n_align; }  /* FAILED_CALIBRATION */
+    if (*events_per_base > 5.0) { *read_stat_flag |= 0x004; }                         /* FAILED_QUALITY_CHK */
+    return n_align;
+}

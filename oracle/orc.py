@@ -1,0 +1,112 @@
+"""ctypes binding of oracle/libabea_oracle.so — TEST INFRASTRUCTURE ONLY.
+
+The product package (f5c_amd) never imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+EVENT_DT = np.dtype([("start", "<u8"), ("length", "<f4"), ("mean", "<f4"), ("stdv", "<f4")], align=True)
+MODEL_DT = np.dtype([("level_mean", "<f4"), ("level_stdv", "<f4"), ("level_log_stdv", "<f4")])
+PAIR_DT = np.dtype([("ref_pos", "<i4"), ("read_pos", "<i4")])
+SCAL_DT = np.dtype([("scale", "<f4"), ("shift", "<f4"), ("var", "<f4"), ("log_var", "<f4")])
+DIAG_DT = np.dtype([("sum_emission", "<f8"), ("n_aligned", "<i4"), ("best_event", "<i4"),
+                    ("max_score", "<f4"), ("max_gap", "<i4"), ("spanned", "<i4"), ("oob", "<i4"),
+                    ("pad", "<i4")], align=True)
+IDXPAIR_DT = np.dtype([("start", "<i4"), ("stop", "<i4")])
+assert EVENT_DT.itemsize == 24 and MODEL_DT.itemsize == 12 and PAIR_DT.itemsize == 8
+assert SCAL_DT.itemsize == 16 and DIAG_DT.itemsize == 40
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "libabea_oracle.so")
+    src = os.path.join(_HERE, "abea_oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-B" if force else "-s"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        L = C.CDLL(build())
+        vp = C.c_void_p
+        L.orc_kmer_rank.restype = C.c_uint32
+        L.orc_kmer_rank.argtypes = [C.c_char_p, C.c_uint32]
+        L.orc_estimate_scalings.restype = C.c_float * 4
+        L.orc_align.restype = C.c_int32
+        L.orc_align.argtypes = [vp, C.c_char_p, C.c_int32, vp, C.c_size_t, vp, C.c_uint32,
+                                C.c_float, C.c_float, vp]
+        L.orc_align_single.restype = C.c_int32
+        L.orc_align_single.argtypes = [vp, C.c_char_p, C.c_int32, vp, C.c_size_t, C.c_int64, vp,
+                                       C.c_uint32, C.c_float, C.c_float, vp]
+        L.orc_align_batch.restype = None
+        L.orc_align_batch.argtypes = [C.c_int32, vp, vp, vp, vp, vp, vp, vp, vp, C.c_uint32,
+                                      vp, vp, vp, vp, C.c_int32]
+        L.orc_scaling_single.restype = C.c_int32
+        L.orc_scaling_single.argtypes = [vp, C.c_int32, C.c_char_p, C.c_int32, vp, C.c_size_t, vp,
+                                         C.c_uint32, vp, vp, vp, vp]
+        _LIB = L
+    return _LIB
+
+
+class _Scal(C.Structure):
+    _fields_ = [("scale", C.c_float), ("shift", C.c_float), ("var", C.c_float), ("log_var", C.c_float)]
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def kmer_rank(s: bytes, k: int) -> int:
+    return lib().orc_kmer_rank(s, k)
+
+
+def estimate_scalings(seq: bytes, model, k, events):
+    L = lib()
+    L.orc_estimate_scalings.restype = _Scal
+    L.orc_estimate_scalings.argtypes = [C.c_char_p, C.c_int32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t]
+    r = L.orc_estimate_scalings(seq, len(seq), _p(model), k, _p(events), len(events))
+    return float(r.scale), float(r.shift)
+
+
+def align(seq: bytes, events, model, k, scale, shift, nsample=1):
+    """One read through align_single (+ guards). Returns (pairs[n], diag record)."""
+    assert events.dtype == EVENT_DT and model.dtype == MODEL_DT
+    out = np.zeros(len(events) + len(seq), dtype=PAIR_DT)
+    diag = np.zeros(1, dtype=DIAG_DT)
+    n = lib().orc_align_single(_p(out), seq, len(seq), _p(events), len(events), nsample, _p(model), k,
+                               np.float32(scale), np.float32(shift), _p(diag))
+    return out[:n].copy(), diag[0]
+
+
+def align_batch(batch, model, k, n_threads=1, want_diag=True):
+    """batch: dict with the flattened arrays (see f5c_amd.synth). Returns (pairs, n_pairs, diags)."""
+    n = len(batch["read_len"])
+    pairs = np.zeros(int(batch["pair_cap"]), dtype=PAIR_DT)
+    n_pairs = np.zeros(n, dtype=np.int32)
+    diags = np.zeros(n, dtype=DIAG_DT) if want_diag else None
+    lib().orc_align_batch(n, _p(batch["reads"]), _p(batch["read_ptr"]), _p(batch["read_len"]),
+                          _p(batch["events"]), _p(batch["event_ptr"]), _p(batch["n_events"]),
+                          _p(batch["scalings"]), _p(model), k, _p(pairs), _p(batch["pair_ptr"]),
+                          _p(n_pairs), _p(diags) if want_diag else None, n_threads)
+    return pairs, n_pairs, diags
+
+
+def scaling_single(pairs, seq: bytes, events, model, k, scale, shift):
+    sc = np.zeros(1, dtype=SCAL_DT)
+    sc["scale"] = scale
+    sc["shift"] = shift
+    K = len(seq) - k + 1
+    bmap = np.zeros(K, dtype=IDXPAIR_DT)
+    epb = np.zeros(1, dtype=np.float64)
+    flag = np.zeros(1, dtype=np.int32)
+    pairs = np.ascontiguousarray(pairs)
+    n = lib().orc_scaling_single(_p(pairs), len(pairs), seq, len(seq), _p(events), len(events), _p(model), k,
+                                 _p(sc), _p(bmap), _p(epb), _p(flag))
+    return dict(n_alignment=n, scalings=sc[0], base_to_event_map=bmap, events_per_base=float(epb[0]),
+                flag=int(flag[0]))

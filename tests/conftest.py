@@ -1,0 +1,49 @@
+import os
+import sys
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def r9():
+    from f5c_amd import load_model_f32
+    return load_model_f32(os.path.join(GOLDEN, "r9.4_450bps.6mer.f32"))
+
+
+@pytest.fixture(scope="session")
+def orc():
+    from oracle import orc as o
+    o.lib()
+    return o
+
+
+@pytest.fixture(scope="session")
+def single_read():
+    from f5c_amd.types import EVENT_DT
+    g = np.load(os.path.join(GOLDEN, "single_read.npz"))
+    ev = np.zeros(len(g["mean"]), dtype=EVENT_DT)
+    for f in ("start", "length", "mean", "stdv"):
+        ev[f] = g[f]
+    return dict(seq=g["seq"].tobytes(), events=ev, g=g)
+
+
+@pytest.fixture(scope="session")
+def ctx(r9):
+    """Shared device context for the gpu tests (small arena so sub-batching is exercised elsewhere)."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from f5c_amd import abea
+    k, model = r9
+    c = abea.AbeaContext(model, k, device_id=0, max_arena_bytes=4 << 30)
+    yield c
+    c.close()

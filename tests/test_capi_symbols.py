@@ -1,0 +1,49 @@
+"""CPU: the C-ABI library loads and exports every symbol include/abea.h declares."""
+import ctypes
+import os
+import re
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    hdr = open(os.path.join(ROOT, "include", "abea.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(abea_[a-z_]+)\s*\(", hdr)))
+
+
+def test_header_declares_expected_entry_points():
+    names = _declared()
+    for n in ("abea_init", "abea_free", "abea_align_batch_host", "abea_align_batch_device", "abea_last_error"):
+        assert n in names
+
+
+def test_library_exports_every_declared_symbol():
+    from f5c_amd import abea
+    if not os.path.exists(abea.LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+    lib = ctypes.CDLL(abea.LIB_PATH)
+    for n in _declared():
+        assert hasattr(lib, n), f"{n} declared in include/abea.h but not exported"
+    assert sorted(abea.EXPORTS) == _declared()
+
+
+def test_no_gpu_fails_loudly(r9):
+    """Without a GPU abea_init must fail with a message, never fall back to a CPU path."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from f5c_amd import abea
+    k, model = r9
+    with pytest.raises(abea.AbeaError):
+        abea.AbeaContext(model, k)
+
+
+def test_product_does_not_import_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "f5c_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src and "abea_oracle" not in src, f

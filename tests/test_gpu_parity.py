@@ -1,0 +1,170 @@
+"""GPU parity tests proper: the HIP path, called through the C ABI, against the CPU oracle and the
+committed golden fixtures.  Bar (BASELINE.json north_star): alignment indices bit-exact, float
+scores within 1e-4."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+SCORE_TOL = 1e-4          # north_star: "within 1e-4 on float scores"
+
+
+def _check_batch(batch, res, ora, label=""):
+    pairs, n_pairs, diag = res
+    o_pairs, o_n, o_diag = ora
+    bad = np.nonzero(n_pairs != o_n)[0]
+    assert len(bad) == 0, f"{label}: n_pairs differ on reads {bad[:10]}: gpu {n_pairs[bad[:10]]} cpu {o_n[bad[:10]]}"
+    for i in range(len(o_n)):
+        s = int(batch["pair_ptr"][i])
+        assert (pairs[s:s + o_n[i]] == o_pairs[s:s + o_n[i]]).all(), f"{label}: read {i} pair list differs"
+    ran = (diag["flags"] & 0x3) == 0
+    # integer diagnostics bit-exact, float scores within tolerance (they are in fact expected equal)
+    assert (diag["n_aligned"][ran] == o_diag["n_aligned"][ran]).all()
+    assert (diag["best_event"][ran] == o_diag["best_event"][ran]).all()
+    assert (diag["max_gap"][ran] == o_diag["max_gap"][ran]).all()
+    assert np.allclose(diag["max_score"][ran], o_diag["max_score"][ran], rtol=0, atol=SCORE_TOL)
+    assert np.allclose(diag["sum_emission"][ran], o_diag["sum_emission"][ran], rtol=0, atol=SCORE_TOL)
+
+
+def test_selftest_and_device(ctx):
+    ctx.selftest()
+    info = ctx.device_info()
+    assert info["arch"].startswith("gfx950") and info["n_cu"] >= 200
+
+
+def test_reference_known_answer_single_read(ctx, orc, r9, single_read):
+    """test/ecoli_2kb_region/single_read: 7206 aligned events, avg log-emission -2.872263."""
+    k, model = r9
+    scale, shift = orc.estimate_scalings(single_read["seq"], model, k, single_read["events"])
+    from f5c_amd.types import SCAL_DT
+    sc = np.zeros(1, dtype=SCAL_DT); sc["scale"] = scale; sc["shift"] = shift
+    plist, n_pairs, diag = ctx.align_db_host([single_read["seq"]], [single_read["events"]], sc)
+    g = single_read["g"]
+    assert n_pairs[0] == int(g["exp_n_aligned"]) == 7206
+    assert abs(diag["sum_emission"][0] / diag["n_aligned"][0] - float(g["exp_avg_log_emission"])) < 1e-6
+    o_pairs, _ = orc.align(single_read["seq"], single_read["events"], model, k, scale, shift)
+    assert (plist[0] == o_pairs).all()
+    assert tuple(plist[0][0]) == (0, 1) and tuple(plist[0][-1]) == (3654, 7163)
+
+
+@pytest.mark.parametrize("seed,law,n", [(11, 1500, 96), (12, "gamma8k", 48), (13, "loguniform", 64)])
+def test_synthetic_batches_bit_exact_device_api(ctx, orc, r9, seed, law, n):
+    from f5c_amd import synth
+    k, model = r9
+    batch = synth.make_batch(n, model, k, seed=seed, law=law, bad_frac=0.08)
+    d = ctx.upload(batch)
+    ctx.align_db_device(d)
+    res = ctx.download(d)
+    ora = orc.align_batch(batch, model, k, n_threads=8)
+    _check_batch(batch, res, ora, f"seed{seed}")
+    assert (ora[1] > 0).mean() > 0.8
+    st = ctx.stats()
+    assert st["n_reads_gpu"] == n and st["fill_ms"] > 0
+
+
+def test_host_api_equals_device_api(ctx, orc, r9):
+    from f5c_amd import synth
+    k, model = r9
+    batch = synth.make_batch(40, model, k, seed=21, law=2500, bad_frac=0.1)
+    plist, n_pairs, diag = ctx.align_flat_host(batch)
+    o_pairs, o_n, o_diag = orc.align_batch(batch, model, k, n_threads=8)
+    assert (n_pairs == o_n).all()
+    for i in range(40):
+        s = int(batch["pair_ptr"][i])
+        assert (plist[i] == o_pairs[s:s + o_n[i]]).all()
+
+
+def test_edge_cases(ctx, orc, r9):
+    """Ragged / degenerate inputs the reference handles: tiny reads, E>>K, E<<K, pure noise,
+    over-segmented (E/L>=15 -> 0), read shorter than k, a non-ACGT base."""
+    from f5c_amd import synth
+    from f5c_amd.types import EVENT_DT
+    k, model = r9
+    rng = np.random.default_rng(5)
+
+    def noise_events(n):
+        e = np.zeros(n, dtype=EVENT_DT)
+        e["mean"] = rng.normal(90, 12, n).astype(np.float32)
+        e["length"] = 5; e["stdv"] = 1
+        return e
+
+    def seq(n):
+        return bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), n))
+
+    good = synth.make_batch(6, model, k, seed=31, lengths=[60, 101, 150, 333, 1000, 2047], bad_frac=0.0)
+    seqs, evs, scs = [], [], []
+    for i in range(6):
+        s, L = int(good["read_ptr"][i]), int(good["read_len"][i])
+        es, E = int(good["event_ptr"][i]), int(good["n_events"][i])
+        seqs.append(good["reads"][s:s + L].tobytes()); evs.append(good["events"][es:es + E])
+        scs.append((good["scalings"]["scale"][i], good["scalings"]["shift"][i]))
+    extra = [
+        (seq(2000), noise_events(4000)),      # random signal
+        (seq(300), noise_events(3600)),       # E >> K
+        (seq(2000), noise_events(300)),       # E << K
+        (seq(60), noise_events(100)),         # tiny
+        (seq(100), noise_events(1500)),       # E/L == 15 -> skipped
+        (seq(5), noise_events(20)),           # shorter than k -> skipped
+        (seq(6), noise_events(3)),            # exactly one k-mer
+        (seq(7), noise_events(1)),            # one event
+        (seqs[4][:500] + b"N" + seqs[4][501:], evs[4]),   # non-ACGT base ranks as A
+    ]
+    for s_, e_ in extra:
+        seqs.append(s_); evs.append(e_); scs.append((1.0, 0.0))
+    batch = synth.batch_from_reads(seqs, evs, scs)
+    d = ctx.upload(batch)
+    ctx.align_db_device(d)
+    res = ctx.download(d)
+    ora = orc.align_batch(batch, model, k, n_threads=4)
+    assert not ora[2]["oob"].any(), "oracle hit the reference's undefined out-of-buffer trace read"
+    _check_batch(batch, res, ora, "edge")
+    assert res[2]["flags"][10] & 1 and res[2]["flags"][11] & 1     # skipped by the guards
+    assert (res[1][:6] > 0).sum() >= 4
+
+
+def test_sub_batching_small_arena(orc, r9):
+    """A batch larger than the arena is split into sub-batches with identical results."""
+    from f5c_amd import abea, synth
+    k, model = r9
+    batch = synth.make_batch(80, model, k, seed=41, law=3000, bad_frac=0.05)
+    with abea.AbeaContext(model, k, max_arena_bytes=24 << 20) as small:
+        d = small.upload(batch)
+        small.align_db_device(d)
+        res = small.download(d)
+        assert small.stats()["n_sub_batches"] > 1
+    ora = orc.align_batch(batch, model, k, n_threads=8)
+    _check_batch(batch, res, ora, "subbatch")
+
+
+def test_idempotent_and_order_independent(ctx, r9):
+    """Size-independent properties: same batch twice -> identical output; permuting the reads
+    permutes the outputs (reads are independent, f5c.c:811-830)."""
+    from f5c_amd import synth
+    k, model = r9
+    batch = synth.make_batch(64, model, k, seed=51, law="gamma8k", bad_frac=0.05)
+    d = ctx.upload(batch)
+    ctx.align_db_device(d); p1, n1, g1 = [x.copy() for x in ctx.download(d)]
+    ctx.align_db_device(d); p2, n2, g2 = ctx.download(d)
+    assert (n1 == n2).all() and (g1["sum_emission"] == g2["sum_emission"]).all()
+    perm = np.random.default_rng(0).permutation(64)
+    pb = synth.take_reads(batch, perm)
+    dp = ctx.upload(pb)
+    ctx.align_db_device(dp); p3, n3, g3 = ctx.download(dp)
+    assert (n3 == n1[perm]).all()
+    for j, i in enumerate(perm):
+        a = p1[int(batch["pair_ptr"][i]):int(batch["pair_ptr"][i]) + n1[i]]
+        b = p3[int(pb["pair_ptr"][j]):int(pb["pair_ptr"][j]) + n3[j]]
+        assert (a == b).all()
+
+
+def test_r10_9mer_synthetic_model(orc):
+    """BASELINE config 5: 9-mer model (262144 entries; synthetic table, none ships with the reference)."""
+    from f5c_amd import abea, synth, synthetic_model
+    model = synthetic_model(9, seed=9)
+    batch = synth.make_batch(24, model, 9, seed=61, law=3000, bad_frac=0.1)
+    with abea.AbeaContext(model, 9, max_arena_bytes=1 << 30) as c:
+        d = c.upload(batch)
+        c.align_db_device(d)
+        res = c.download(d)
+    ora = orc.align_batch(batch, model, 9, n_threads=8)
+    _check_batch(batch, res, ora, "r10")
+    assert (ora[1] > 0).mean() > 0.7
