@@ -172,7 +172,8 @@ class AbeaContext:
         return self.align_db_host(seqs, evs, batch["scalings"], want_diag=want_diag)
 
     # ---- device-resident flattened batch ----
-    def upload(self, batch, device=None):
+    @staticmethod
+    def upload(batch, device=None):
         """Copy a flattened numpy batch into HBM (torch tensors as plain device buffers)."""
         import torch
         dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
