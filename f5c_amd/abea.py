@@ -11,7 +11,7 @@ import numpy as np
 from .types import EVENT_DT, MODEL_DT, PAIR_DT, SCAL_DT, DIAG_DT
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libabea_hip.so")
+LIB_PATH = os.environ.get("ABEA_LIB_PATH", os.path.join(_HERE, "libabea_hip.so"))   # override only for kernel A/B experiments
 
 EXPORTS = ["abea_init", "abea_free", "abea_last_error", "abea_align_batch_host",
            "abea_align_batch_device", "abea_get_stats", "abea_device_info", "abea_selftest"]

@@ -15,6 +15,7 @@
  *           abea_trace_kernel (align-post: traceback walk, pair expansion, ordered QC sums)
  */
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "abea_device.h"
 
 #define NINF (-__builtin_inff())
@@ -127,10 +128,25 @@ static __device__ __forceinline__ void abea_cell(float x, float gpm, float ck, d
     from = (sl >= m1) ? 2u : f;
 }
 
+/* State layout of the fill kernel (one wavefront = one read):
+ *   lane l owns band offsets o0 = 2l and o1 = 2l+1.  Offsets 0..99 (lanes 0..49) are the band;
+ *   offsets 100..127 (lanes 50..63) never hold scores (kept at -inf) but DO hold k-mer parameters:
+ *   they are the FIFO through which upcoming k-mers slide towards offset 99, so a "right" move is
+ *   one DPP wave shift per register with the new k-mer entering at lane 63 through the DPP `old`
+ *   operand.  Events enter at offset 0 (lane 0) the same way on "down" moves.
+ *   The next event / k-mer is read ahead of time from a wave-private LDS ring (broadcast ds_read,
+ *   off the critical path); the ring is refilled 64 entries at a time from HBM with the global load
+ *   issued one refill period before its data is needed.
+ *   Neighbours (DESIGN.md "frames"): right move: left = P[o], up = P[o+1], diag = previous band's up;
+ *   down move: left = P[o-1], up = P[o], diag = previous band's left.
+ * Trace layout: per 32 bands one uint4 per lane: dword w, nibble 7-(b&7) = {from(o0) | from(o1)<<2};
+ *   lane 50's .x is replaced by the 32 band-move bits of the group (bit 31-(b&31), 1 = right). */
 extern "C" __global__ __launch_bounds__(64)
 void abea_fill_kernel(const abea_read_desc* __restrict__ descs,
                       const float* __restrict__ evm_all, const abea_kpar_t* __restrict__ kpar_all,
                       uint4* __restrict__ trace_all, abea_fill_out* __restrict__ fout) {
+    __shared__ abea_kpar_t k_ring[128];
+    __shared__ float e_ring[128];
     const abea_read_desc* d = descs + blockIdx.x;
     const int n_groups = d->n_groups;
     if (n_groups == 0) return;
@@ -141,124 +157,163 @@ void abea_fill_kernel(const abea_read_desc* __restrict__ descs,
     const float* __restrict__ evm = evm_all + d->evm_off;
     const abea_kpar_t* __restrict__ kpar = kpar_all + d->kpar_off;
     uint4* __restrict__ trace = trace_all + d->trace_off;
-    const int o0 = 2 * lane, o1 = o0 + 1;              /* band offsets owned by this lane */
+    const int o0 = 2 * lane, o1 = o0 + 1;              /* offsets owned by this lane */
+    const float cap = (lane < 50) ? __builtin_inff() : NINF;   /* min(score, cap) pins lanes >= 50 to -inf */
 
     /* ---- state after bands 0 and 1 (align.c:277-291) ---- */
     int ll_e = 50, ll_k = -51;                          /* lower-left of band 1 */
     float Pf0 = NINF, Pf1 = NINF;                       /* band 1 scores (offset 50 = trim of event 0) */
     if (lane == 25) Pf0 = (float)lp_trim;
     double P0 = (double)Pf0, P1 = (double)Pf1;
-    /* band 1 was a "down" move from band 0, so in band-1 frame U[o]=band0[o], L[o]=band0[o-1];
+    /* band 1 was a "down" move from band 0: in band-1 frame U[o] = band0[o], L[o] = band0[o-1];
      * band 0 is -inf except offset 50 (start cell, 0.0f) */
     double U0 = (lane == 25) ? 0.0 : (double)NINF, U1 = (double)NINF;
     double L0 = (double)NINF, L1 = (lane == 25) ? 0.0 : (double)NINF;
 
-    /* per-cell inputs in band-1 frame: event = ll_e - o, kmer = ll_k + o */
+    /* per-offset inputs in band-1 frame: event = ll_e - o (offsets 0..127), kmer = ll_k + o */
     float x0, x1, g0, g1, c0, c1; double i0, i1;
     {
-        int e0 = ll_e - o0, e1 = ll_e - o1;
+        const int e0 = ll_e - o0, e1 = ll_e - o1;
         x0 = (e0 >= 0 && e0 < E) ? evm[e0] : 0.f;
         x1 = (e1 >= 0 && e1 < E) ? evm[e1] : 0.f;
-        int k0 = ll_k + o0, k1 = ll_k + o1;
+        const int k0 = ll_k + o0, k1 = ll_k + o1;
         abea_kpar_t z; z.gpm = 0.f; z.ck = 0.f; z.istd = 0.0;
-        abea_kpar_t p0 = (k0 >= 0 && k0 < K) ? kpar[k0] : z;
-        abea_kpar_t p1 = (k1 >= 0 && k1 < K) ? kpar[k1] : z;
+        const abea_kpar_t p0 = (k0 >= 0 && k0 < K) ? kpar[k0] : z;
+        const abea_kpar_t p1 = (k1 >= 0 && k1 < K) ? kpar[k1] : z;
         g0 = p0.gpm; c0 = p0.ck; i0 = p0.istd;
         g1 = p1.gpm; c1 = p1.ck; i1 = p1.istd;
     }
-    /* sequential feeds: events enter at offset 0 on "down" moves in index order, k-mers enter at
-     * offset 99 on "right" moves in index order -> 64-wide coalesced chunks held in
-     * one VGPR (4 for k-mers), double-buffered, picked out with v_readlane */
-    int ev_chunk = 0, k_chunk = 0;
-    float evA = evm[min(lane, E - 1)], evB = evm[min(64 + lane, E - 1)];
-    abea_kpar_t kA = kpar[min(lane, K - 1)], kB = kpar[min(64 + lane, K - 1)];
+    /* LDS rings: entry i lives at slot i & 127 (chunk c = i >> 6 in half c & 1) */
+    int e_next = ll_e + 1;                              /* event entering at offset 0 on the next down move */
+    int k_next = ll_k + 128;                            /* k-mer entering at offset 127 on the next right move */
+    e_ring[lane] = evm[min(lane, E - 1)];
+    e_ring[64 + lane] = evm[min(64 + lane, E - 1)];
+    float e_pend = evm[min(128 + lane, E - 1)];         /* chunk 2, written when chunk 1 is entered */
+    k_ring[64 + lane] = kpar[min(64 + lane, K - 1)];    /* chunk 1 */
+    k_ring[lane] = kpar[min(128 + lane, K - 1)];        /* chunk 2 */
+    abea_kpar_t k_pend = kpar[min(192 + lane, K - 1)];  /* chunk 3 */
+    __syncthreads();
+    float nx = e_ring[e_next & 127];
+    abea_kpar_t nk = k_ring[k_next & 127];
 
     uint32_t acc = (lane == 25) ? 1u : 0u;             /* bands 0,1: only band 1 offset 50 = FROM_U */
     uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    uint32_t mvacc = 0;                                 /* band-move bits of the current group (scalar) */
     float best = NINF; int best_e = 0, best_llk = 0;
+    int b = 2;
 
-    for (int b = 2; b < nb_pad; ++b) {
-        /* ---- Suzuki-Kasahara move (align.c:304-322) ---- */
-        const float s_ll = readlane_f(Pf0, 0), s_ur = readlane_f(Pf1, 49);
-        const bool right = uni((s_ll == NINF && s_ur == NINF) ? (b & 1) : (s_ll < s_ur ? 1 : 0)) != 0;
+    auto step = [&](auto border_tag) {
+        constexpr bool BORDER = decltype(border_tag)::value;
+        /* ---- Suzuki-Kasahara move (align.c:304-322): right = ll < ur, alternate when both are -inf ---- */
+        const float s_ll = readlane_f(Pf0, 0);
+        bool right;
+        if (__float_as_uint(s_ll) != 0xff800000u) {
+            right = ((__ballot(s_ll < Pf1) >> 49) & 1ull) != 0;      /* lane 49 slot 1 = offset 99 */
+        } else {
+            const float s_ur = readlane_f(Pf1, 49);
+            right = (__float_as_uint(s_ur) == 0xff800000u) ? ((b & 1) != 0) : true;
+        }
         double D0, D1, nU0, nU1, nL0, nL1;
         if (right) {
             ll_k += 1;
-            const int kin = ll_k + 99;                 /* k-mer entering at offset 99 */
-            const int kc = kin >> 6;
-            if (kc != k_chunk) { kA = kB; k_chunk = kc; kB = kpar[min((kc + 1) * 64 + lane, K - 1)]; }
-            const int src = kin & 63;
-            const float ng = readlane_f(kA.gpm, src), nc = readlane_f(kA.ck, src);
-            const int nlo = readlane_i(__double2loint(kA.istd), src), nhi = readlane_i(__double2hiint(kA.istd), src);
-            /* k-mer params slide one offset down; lane 49 slot 1 takes the new k-mer */
-            float tg = writelane_f<49>(dpp_from_upper_f(0.f, g0), ng);
-            float tc = writelane_f<49>(dpp_from_upper_f(0.f, c0), nc);
-            int tlo = writelane_i<49>(dpp_from_upper_i(0, __double2loint(i0)), nlo);
-            int thi = writelane_i<49>(dpp_from_upper_i(0, __double2hiint(i0)), nhi);
+            /* k-mer parameters slide one offset down; nk (k-mer ll_k+127) enters at lane 63 slot 1 */
+            const float tg = dpp_from_upper_f(nk.gpm, g0);
+            const float tc = dpp_from_upper_f(nk.ck, c0);
+            const double ti = dpp_from_upper_d(nk.istd, i0);
             g0 = g1; c0 = c1; i0 = i1;
-            g1 = tg; c1 = tc; i1 = __hiloint2double(thi, tlo);
-            /* neighbours (DESIGN.md "frames"): left = same offset, up = offset+1, diag = previous band's up */
+            g1 = tg; c1 = tc; i1 = ti;
+            k_next += 1;
+            if ((k_next & 63) == 0) {                  /* entering chunk c: land chunk c+1, fetch chunk c+2 */
+                const int c = k_next >> 6;
+                k_ring[((c + 1) & 1) * 64 + lane] = k_pend;
+                k_pend = kpar[min((c + 2) * 64 + lane, K - 1)];
+                __syncthreads();
+            }
+            nk = k_ring[k_next & 127];
             nL0 = P0; nL1 = P1;
             nU0 = P1; nU1 = dpp_from_upper_d((double)NINF, P0);
             D0 = U0; D1 = U1;
+            mvacc = (mvacc << 1) | 1u;
         } else {
             ll_e += 1;
-            const int ein = ll_e;                      /* event entering at offset 0 */
-            const int ec = ein >> 6;
-            if (ec != ev_chunk) { evA = evB; ev_chunk = ec; evB = evm[min((ec + 1) * 64 + lane, E - 1)]; }
-            const float nx = readlane_f(evA, ein & 63);
-            float tx = dpp_from_lower_f(nx, x1);       /* lane 0 keeps nx */
+            const float tx = dpp_from_lower_f(nx, x1);  /* lane 0 keeps nx = event ll_e */
             x1 = x0; x0 = tx;
-            /* left = offset-1, up = same offset, diag = previous band's left */
+            e_next += 1;
+            if ((e_next & 63) == 0) {
+                const int c = e_next >> 6;
+                e_ring[((c + 1) & 1) * 64 + lane] = e_pend;
+                e_pend = evm[min((c + 2) * 64 + lane, E - 1)];
+                __syncthreads();
+            }
+            nx = e_ring[e_next & 127];
             nU0 = P0; nU1 = P1;
             nL1 = P0; nL0 = dpp_from_lower_d((double)NINF, P1);
             D0 = L0; D1 = L1;
+            mvacc = mvacc << 1;
         }
 
         /* ---- cells (align.c:337-409) ---- */
-        const int min_off = max(max(-ll_k, ll_e - (E - 1)), 0);
-        const int max_off = min(min(K - ll_k, ll_e + 1), ABEA_W);
         float m0, m1; uint32_t f0, f1;
         abea_cell(x0, g0, c0, i0, D0, nU0, nL0, lp_step, lp_stay, lp_skip, m0, f0);
         abea_cell(x1, g1, c1, i1, D1, nU1, nL1, lp_step, lp_stay, lp_skip, m1, f1);
-        const bool v0 = (o0 >= min_off) && (o0 < max_off);
-        const bool v1 = (o1 >= min_off) && (o1 < max_off);
-        m0 = v0 ? m0 : NINF; f0 = v0 ? f0 : 0u;
-        m1 = v1 ? m1 : NINF; f1 = v1 ? f1 : 0u;
-
-        /* ---- trim column, k-mer -1 (align.c:324-333) ---- */
-        const int trim_o = -1 - ll_k;
-        if (trim_o >= 0 && trim_o < ABEA_W) {
-            const int te = ll_e - trim_o;
-            if (te >= 0 && te < E) {
-                const float tv = (float)(lp_trim * (double)(te + 1));
-                if (o0 == trim_o) { m0 = tv; f0 = 1u; }
-                if (o1 == trim_o) { m1 = tv; f1 = 1u; }
+        if constexpr (BORDER) {
+            const int min_off = max(max(-ll_k, ll_e - (E - 1)), 0);
+            const int max_off = min(min(K - ll_k, ll_e + 1), ABEA_W);
+            const bool v0 = (o0 >= min_off) && (o0 < max_off);
+            const bool v1 = (o1 >= min_off) && (o1 < max_off);
+            m0 = v0 ? m0 : NINF; f0 = v0 ? f0 : 0u;
+            m1 = v1 ? m1 : NINF; f1 = v1 ? f1 : 0u;
+            /* trim column, k-mer -1 (align.c:324-333) */
+            const int trim_o = -1 - ll_k;
+            if (trim_o >= 0 && trim_o < ABEA_W) {
+                const int te = ll_e - trim_o;
+                if (te >= 0 && te < E) {
+                    const float tv = (float)(lp_trim * (double)(te + 1));
+                    if (o0 == trim_o) { m0 = tv; f0 = 1u; }
+                    if (o1 == trim_o) { m1 = tv; f1 = 1u; }
+                }
             }
+        } else {
+            m0 = fminf(m0, cap); m1 = fminf(m1, cap);   /* all 100 band cells are in range here */
         }
 
         /* ---- rotate rows ---- */
         U0 = nU0; U1 = nU1; L0 = nL0; L1 = nL1;
         Pf0 = m0; Pf1 = m1; P0 = (double)m0; P1 = (double)m1;
 
-        /* ---- trace: 2 bit/cell, 4 bit/lane/band, band-move bit in lane 50 ---- */
-        uint32_t t = f0 | (f1 << 2);
-        if (lane == ABEA_MOVE_LANE) t = right ? 1u : 0u;
-        acc = (acc << 4) | t;
+        /* ---- trace ---- */
+        acc = (acc << 4) | (f0 | (f1 << 2));
         if ((b & 7) == 7) {
             a0 = a1; a1 = a2; a2 = a3; a3 = acc;
-            if ((b & 31) == 31) trace[(size_t)(b >> 5) * 64 + lane] = make_uint4(a0, a1, a2, a3);
+            if ((b & 31) == 31) {
+                const uint32_t ax = (lane == ABEA_MOVE_LANE) ? mvacc : a0;
+                trace[(size_t)(b >> 5) * 64 + lane] = make_uint4(ax, a1, a2, a3);
+            }
         }
 
-        /* ---- online end-point scan (align.c:424-445): bands visit events in increasing order ---- */
-        const int oc = (K - 1) - ll_k;
-        if (oc >= 0 && oc < ABEA_W) {
-            const int e = ll_e - oc;
-            if (e >= 0 && e < E) {
-                const float sc = (oc & 1) ? readlane_f(Pf1, oc >> 1) : readlane_f(Pf0, oc >> 1);
-                const float s = (float)((double)sc + (double)(E - e) * lp_trim);
-                if (s > best) { best = s; best_e = e; best_llk = ll_k; }
+        if constexpr (BORDER) {
+            /* ---- online end-point scan (align.c:424-445): bands visit events in increasing order ---- */
+            const int oc = (K - 1) - ll_k;
+            if (oc >= 0 && oc < ABEA_W) {
+                const int e = ll_e - oc;
+                if (e >= 0 && e < E) {
+                    const float sc = (oc & 1) ? readlane_f(Pf1, oc >> 1) : readlane_f(Pf0, oc >> 1);
+                    const float s = (float)((double)sc + (double)(E - e) * lp_trim);
+                    if (s > best) { best = s; best_e = e; best_llk = ll_k; }
+                }
             }
+        }
+        ++b;
+    };
+
+    while (b < nb_pad) {
+        /* bands for which every one of the 100 cells is inside the matrix and neither the trim column
+         * nor the last k-mer column can be in band, whatever the moves: one of ll_e / ll_k grows per band */
+        int run = min(min(E - 2 - ll_e, K - 102 - ll_k), nb_pad - b);
+        if (ll_k >= 0 && ll_e >= 99 && run > 0) {
+            for (; run > 0; --run) step(std::false_type{});
+        } else {
+            step(std::true_type{});
         }
     }
     if (lane == 0) {
@@ -313,39 +368,57 @@ void abea_trace_kernel(const abea_read_desc* __restrict__ descs,
     uint32_t* codes = codes_all + d->code_off;
     abea_pair_t* pairs = pairs_all + d->pair_off;
 
-    /* ---- serial walk (align.c:452-499), wave-uniform; emits one 2-bit code per step ---- */
+    /* ---- serial walk (align.c:452-499): wave-uniform, runs on the scalar unit.  The trace of the
+     *      current 32-band group sits in 4 VGPRs (one uint4 per lane = the lane's two cells for 32
+     *      bands), the next lower group is prefetched, a step is one v_readlane + SALU bit picking.
+     *      Each step emits a 2-bit code; 16 codes -> one dword, 64 dwords -> one coalesced store. ---- */
     int e = fo.best_event, k = K - 1, llk = fo.best_llk;
     int b = e + k + 2;
     int n = 0, gap = 0, max_gap = 0, last_k = k;
-    uint32_t cwd = 0;
-    int cblk = -1, mgrp = -1;
-    uint4 cw = make_uint4(0, 0, 0, 0), mw = make_uint4(0, 0, 0, 0);
+    uint32_t cwd = 0, cv = 0;
+    int g = b >> 5;
+    uint4 cw = trace[(size_t)g * 64 + lane];
+    uint4 nx = trace[(size_t)max(g - 1, 0) * 64 + lane];
+    uint32_t mv = readlane_i(cw.x, ABEA_MOVE_LANE);       /* 32 band-move bits of the group, bit 31-(b&31) */
     while (k >= 0 && e >= 0) {
+        if ((b >> 5) != g) {                               /* stepped into the group below */
+            g = b >> 5;
+            cw = nx;
+            nx = trace[(size_t)max(g - 1, 0) * 64 + lane];
+            mv = readlane_i(cw.x, ABEA_MOVE_LANE);
+        }
         last_k = k;
-        const int off = k - llk;                         /* band offset of (e,k): ll_k + off = k */
-        const int g = b >> 5;
-        const int blk = g * 64 + (off >> 1);
-        if (blk != cblk) { cw = trace[blk]; cblk = blk; }
-        if (g != mgrp) { mw = trace[g * 64 + ABEA_MOVE_LANE]; mgrp = g; }
+        const int off = k - llk;                           /* band offset of (e,k): ll_k + off = k */
+        const int w = (b >> 3) & 3;
         const int sh = (7 - (b & 7)) * 4;
-        const uint32_t from = (sel4(cw, (b >> 3) & 3) >> (sh + ((off & 1) << 1))) & 3u;
-        const int mv_b = (sel4(mw, (b >> 3) & 3) >> sh) & 1;     /* 1 = band b was a right move */
+        const uint32_t cd = readlane_i(sel4(cw, w), off >> 1);
+        const uint32_t from = (cd >> (sh + ((off & 1) << 1))) & 3u;
+        const int mv_b = (mv >> (31 - (b & 31))) & 1;      /* 1 = band b was a right move */
         cwd |= from << ((n & 15) << 1);
         ++n;
-        if ((n & 15) == 0) { if (lane == 0) codes[(n >> 4) - 1] = cwd; cwd = 0; }
-        if (from == 0u) {                                /* FROM_D: two bands back */
-            const int b1 = b - 1, g1 = b1 >> 5;
-            if (g1 != mgrp) { mw = trace[g1 * 64 + ABEA_MOVE_LANE]; mgrp = g1; }
-            const int mv_b1 = (sel4(mw, (b1 >> 3) & 3) >> ((7 - (b1 & 7)) * 4)) & 1;
+        if ((n & 15) == 0) {
+            if (lane == (((n >> 4) - 1) & 63)) cv = cwd;
+            cwd = 0;
+            if ((n & 1023) == 0) codes[(size_t)((n >> 10) - 1) * 64 + lane] = cv;
+        }
+        if (from == 0u) {                                  /* FROM_D: two bands back */
+            const int b1 = b - 1;
+            const uint32_t mvw1 = ((b1 >> 5) != g) ? (uint32_t)readlane_i(nx.x, ABEA_MOVE_LANE) : mv;
+            const int mv_b1 = (mvw1 >> (31 - (b1 & 31))) & 1;
             llk -= mv_b + mv_b1; e -= 1; k -= 1; b -= 2; gap = 0;
-        } else if (from == 1u) {                         /* FROM_U */
+        } else if (from == 1u) {                           /* FROM_U */
             llk -= mv_b; e -= 1; b -= 1; gap = 0;
-        } else {                                         /* FROM_L */
+        } else {                                           /* FROM_L */
             llk -= mv_b; k -= 1; b -= 1; gap += 1; max_gap = max(max_gap, gap);
         }
     }
-    if ((n & 15) != 0 && lane == 0) codes[n >> 4] = cwd;
-    __syncthreads();                                     /* lane 0's code words -> all lanes */
+    if ((n & 15) != 0 && lane == ((n >> 4) & 63)) cv = cwd;
+    if ((n & 1023) != 0 && lane <= (((n - 1) >> 4) & 63)) codes[(size_t)(n >> 10) * 64 + lane] = cv;
+    __syncthreads();                                     /* this wave's code words -> all its lanes */
+#ifdef ABEA_EXP_WALK_ONLY
+    if (lane == 0) n_pairs[out_idx] = n;
+    return;
+#endif
 
     /* ---- expansion: prefix sums turn codes into (k,e) pairs written in forward order;
      *      log-emissions are summed in walk order, in double (align.c:473-476) ---- */
@@ -381,6 +454,7 @@ void abea_trace_kernel(const abea_read_desc* __restrict__ descs,
         }
         __syncthreads();
         const int m = min(1024, n - c0);
+        #pragma unroll 8
         for (int i = 0; i < m; ++i) sum += (double)lp_s[(i & 15) * 64 + (i >> 4)];   /* uniform, strictly in walk order */
         __syncthreads();
         base_k -= tk; base_e -= te;
