@@ -134,7 +134,7 @@ def main():
             "qc_pass_frac": round(float(allv[:, 9].sum() / total_reads), 4),
             "kernel_ms": {"pre": round(pre_ms / args.steps, 3), "fill": round(fill_ms / args.steps, 3),
                           "post": round(trace_ms / args.steps, 3), "fill_launches_per_step": launches // args.steps},
-            "roofline": {"bound": "hbm", "kernel": "abea_fill_kernel", "achieved": round(achieved, 2),
+            "roofline": {"bound": "hbm", "kernel": "abea_align_kernel", "achieved": round(achieved, 2),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                          "traffic": None,
                          "algorithmic_bytes_per_launch": int(a_ref_launch),

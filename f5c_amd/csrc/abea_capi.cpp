@@ -32,9 +32,8 @@ extern "C" {
 __global__ void abea_selftest_kernel(int* out);
 __global__ void abea_pre_kernel(const abea_read_desc*, const char*, const abea_event_t*, const abea_model_t*, int,
                                 abea_kpar_t*, float*);
-__global__ void abea_fill_kernel(const abea_read_desc*, const float*, const abea_kpar_t*, uint4*, abea_fill_out*);
-__global__ void abea_trace_kernel(const abea_read_desc*, const float*, const abea_kpar_t*, const uint4*,
-                                  const abea_fill_out*, uint32_t*, abea_pair_t*, int32_t*, abea_read_diag*);
+__global__ void abea_align_kernel(const abea_read_desc*, const float*, const abea_kpar_t*, uint4*, uint32_t*,
+                                  abea_pair_t*, int32_t*, abea_read_diag*);
 }
 
 /* ------------------------------------------------------------------ errors */
@@ -312,18 +311,14 @@ extern "C" int abea_align_batch_device(abea_ctx* c, const abea_device_batch* B) 
         hipLaunchKernelGGL(abea_pre_kernel, dim3((unsigned)m), dim3(256), 0, c->stream,
                            d_desc, B->reads, B->events, c->d_model, (int)c->k, d_kpar, d_evm);
         HIP_TRY(hipEventRecord(c->ev[1], c->stream));
-        hipLaunchKernelGGL(abea_fill_kernel, dim3((unsigned)m), dim3(64), 0, c->stream,
-                           d_desc, d_evm, d_kpar, d_trace, d_fout);
+        hipLaunchKernelGGL(abea_align_kernel, dim3((unsigned)m), dim3(64), 0, c->stream,
+                           d_desc, d_evm, d_kpar, d_trace, d_codes, B->pairs, B->n_pairs, B->diag);
         HIP_TRY(hipEventRecord(c->ev[2], c->stream));
-        hipLaunchKernelGGL(abea_trace_kernel, dim3((unsigned)m), dim3(64), 0, c->stream,
-                           d_desc, d_evm, d_kpar, d_trace, d_fout, d_codes, B->pairs, B->n_pairs, B->diag);
-        HIP_TRY(hipEventRecord(c->ev[3], c->stream));
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(c->stream));            /* h_desc and the arena are reused by the next sub-batch */
         float ms = 0;
         HIP_TRY(hipEventElapsedTime(&ms, c->ev[0], c->ev[1])); st.pre_ms += ms;
-        HIP_TRY(hipEventElapsedTime(&ms, c->ev[1], c->ev[2])); st.fill_ms += ms;
-        HIP_TRY(hipEventElapsedTime(&ms, c->ev[2], c->ev[3])); st.trace_ms += ms;
+        HIP_TRY(hipEventElapsedTime(&ms, c->ev[1], c->ev[2])); st.fill_ms += ms;   /* fused fill + traceback */
         st.n_sub_batches += 1; st.fill_launches += 1;
         pos = end;
     }

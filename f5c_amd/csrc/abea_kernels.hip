@@ -11,8 +11,8 @@
  * the host (glibc).  See DESIGN.md for the derivations cited in comments below.
  *
  * Kernels:  abea_pre_kernel   (align-pre: k-mer ranks -> read-scaled emission params, event means SoA)
- *           abea_fill_kernel  (band fill + adaptive band movement + online end-point scan)
- *           abea_trace_kernel (align-post: traceback walk, pair expansion, ordered QC sums)
+ *           abea_align_kernel (band fill + adaptive band movement + online end-point scan, then the
+ *                              align-post traceback walk, pair expansion and ordered QC sums, fused)
  */
 #include <hip/hip_runtime.h>
 #include <type_traits>
@@ -128,9 +128,18 @@ static __device__ __forceinline__ void abea_cell(float x, float gpm, float ck, d
     from = (sl >= m1) ? 2u : f;
 }
 
-/* State layout of the fill kernel (one wavefront = one read):
+/* ================================================================ the fused alignment kernel
+ * One wavefront = one read, from band 2 to the finished pair list:
+ *   phase 1  band fill + adaptive band movement + online end-point scan      (VALU/DPP bound)
+ *   phase 2  traceback walk over the packed trace, on the scalar unit        (SALU bound)
+ *   phase 3  expansion of the walk's 2-bit codes into (k-mer, event) pairs,
+ *            ordered fp64 emission sum, QC                                   (small, VALU)
+ * Fusing the phases lets the scalar-unit-bound walks of finished reads overlap the VALU-bound fills
+ * of the other waves resident on the same CU, and removes two kernel boundaries per batch.
+ *
+ * Phase-1 state layout:
  *   lane l owns band offsets o0 = 2l and o1 = 2l+1.  Offsets 0..99 (lanes 0..49) are the band;
- *   offsets 100..127 (lanes 50..63) never hold scores (kept at -inf) but DO hold k-mer parameters:
+ *   offsets 100..127 (lanes 50..63) never hold scores (pinned to -inf) but DO hold k-mer parameters:
  *   they are the FIFO through which upcoming k-mers slide towards offset 99, so a "right" move is
  *   one DPP wave shift per register with the new k-mer entering at lane 63 through the DPP `old`
  *   operand.  Events enter at offset 0 (lane 0) the same way on "down" moves.
@@ -139,26 +148,56 @@ static __device__ __forceinline__ void abea_cell(float x, float gpm, float ck, d
  *   issued one refill period before its data is needed.
  *   Neighbours (DESIGN.md "frames"): right move: left = P[o], up = P[o+1], diag = previous band's up;
  *   down move: left = P[o-1], up = P[o], diag = previous band's left.
- * Trace layout: per 32 bands one uint4 per lane: dword w, nibble 7-(b&7) = {from(o0) | from(o1)<<2};
- *   lane 50's .x is replaced by the 32 band-move bits of the group (bit 31-(b&31), 1 = right). */
+ * Trace layout (per read): per 32 bands one uint4 per lane = 128 bits, band (b & 31) at bits
+ *   [4*(b&31), 4*(b&31)+4) = {from(o0) | from(o1) << 2}.  Lane 50 instead carries the band moves:
+ *   .x = move bits of this group (bit b&31, 1 = right), .y = move bits of the group below. */
+
+static __device__ __forceinline__ int wave_excl_scan(int v, int lane, int& total) {
+    int s = v;
+    #pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        int t = __shfl_up(s, off, 64);
+        if (lane >= off) s += t;
+    }
+    total = __shfl(s, 63, 64);
+    return s - v;
+}
+
 extern "C" __global__ __launch_bounds__(64)
-void abea_fill_kernel(const abea_read_desc* __restrict__ descs,
-                      const float* __restrict__ evm_all, const abea_kpar_t* __restrict__ kpar_all,
-                      uint4* __restrict__ trace_all, abea_fill_out* __restrict__ fout) {
-    __shared__ abea_kpar_t k_ring[128];
-    __shared__ float e_ring[128];
+void abea_align_kernel(const abea_read_desc* __restrict__ descs,
+                       const float* __restrict__ evm_all, const abea_kpar_t* __restrict__ kpar_all,
+                       uint4* __restrict__ trace_all, uint32_t* __restrict__ codes_all,
+                       abea_pair_t* __restrict__ pairs_all, int32_t* __restrict__ n_pairs,
+                       abea_read_diag* __restrict__ diag) {
+    __shared__ uint4 smem[256];                        /* 4 KiB: phase 1 rings, phase 3 emission buffer */
+    abea_kpar_t* const k_ring = reinterpret_cast<abea_kpar_t*>(smem);        /* 128 x 16 B */
+    float* const e_ring = reinterpret_cast<float*>(smem + 128);              /* 128 x 4 B  */
+    float* const lp_s = reinterpret_cast<float*>(smem);                      /* 1024 x 4 B */
+
     const abea_read_desc* d = descs + blockIdx.x;
-    const int n_groups = d->n_groups;
-    if (n_groups == 0) return;
     const int lane = threadIdx.x;
+    const int out_idx = d->out_idx;
+    const int n_groups = d->n_groups;
+    abea_read_diag dg;
+    dg.sum_emission = 0.0; dg.n_aligned = 0; dg.best_event = 0; dg.max_score = NINF;
+    dg.max_gap = 0; dg.spanned = 0; dg.flags = 0; dg.pad = 0;
+    if (n_groups == 0) {                               /* align_single guards (f5c.c:813-814) */
+        if (lane == 0) { n_pairs[out_idx] = 0; dg.flags = ABEA_RF_SKIPPED; if (diag) diag[out_idx] = dg; }
+        return;
+    }
     const int E = d->n_events, K = d->n_kmers;
-    const int nb_pad = n_groups * ABEA_GROUP;
-    const double lp_skip = d->lp_skip, lp_stay = d->lp_stay, lp_step = d->lp_step, lp_trim = d->lp_trim;
     const float* __restrict__ evm = evm_all + d->evm_off;
     const abea_kpar_t* __restrict__ kpar = kpar_all + d->kpar_off;
     uint4* __restrict__ trace = trace_all + d->trace_off;
+
+    float best = NINF; int best_e = 0, best_llk = 0;
+
+    /* ============================================================ phase 1: band fill */
+    {
+    const int nb_pad = n_groups * ABEA_GROUP;
+    const double lp_skip = d->lp_skip, lp_stay = d->lp_stay, lp_step = d->lp_step, lp_trim = d->lp_trim;
     const int o0 = 2 * lane, o1 = o0 + 1;              /* offsets owned by this lane */
-    const float cap = (lane < 50) ? __builtin_inff() : NINF;   /* min(score, cap) pins lanes >= 50 to -inf */
+    const bool hi = lane >= 50;                        /* FIFO lanes: scores pinned to -inf */
 
     /* ---- state after bands 0 and 1 (align.c:277-291) ---- */
     int ll_e = 50, ll_k = -51;                          /* lower-left of band 1 */
@@ -196,10 +235,9 @@ void abea_fill_kernel(const abea_read_desc* __restrict__ descs,
     float nx = e_ring[e_next & 127];
     abea_kpar_t nk = k_ring[k_next & 127];
 
-    uint32_t acc = (lane == 25) ? 1u : 0u;             /* bands 0,1: only band 1 offset 50 = FROM_U */
+    uint32_t acc = (lane == 25) ? (1u << 28) : 0u;     /* bands 0,1: only band 1 offset 50 = FROM_U */
     uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-    uint32_t mvacc = 0;                                 /* band-move bits of the current group (scalar) */
-    float best = NINF; int best_e = 0, best_llk = 0;
+    uint32_t mvacc = 0, mvprev = 0;                     /* band-move bits of this group / the group below */
     int b = 2;
 
     auto step = [&](auto border_tag) {
@@ -233,7 +271,7 @@ void abea_fill_kernel(const abea_read_desc* __restrict__ descs,
             nL0 = P0; nL1 = P1;
             nU0 = P1; nU1 = dpp_from_upper_d((double)NINF, P0);
             D0 = U0; D1 = U1;
-            mvacc = (mvacc << 1) | 1u;
+            mvacc = (mvacc >> 1) | 0x80000000u;
         } else {
             ll_e += 1;
             const float tx = dpp_from_lower_f(nx, x1);  /* lane 0 keeps nx = event ll_e */
@@ -249,7 +287,7 @@ void abea_fill_kernel(const abea_read_desc* __restrict__ descs,
             nU0 = P0; nU1 = P1;
             nL1 = P0; nL0 = dpp_from_lower_d((double)NINF, P1);
             D0 = L0; D1 = L1;
-            mvacc = mvacc << 1;
+            mvacc = mvacc >> 1;
         }
 
         /* ---- cells (align.c:337-409) ---- */
@@ -274,20 +312,21 @@ void abea_fill_kernel(const abea_read_desc* __restrict__ descs,
                 }
             }
         } else {
-            m0 = fminf(m0, cap); m1 = fminf(m1, cap);   /* all 100 band cells are in range here */
+            m0 = hi ? NINF : m0; m1 = hi ? NINF : m1;   /* all 100 band cells are in range here */
         }
 
         /* ---- rotate rows ---- */
         U0 = nU0; U1 = nU1; L0 = nL0; L1 = nL1;
         Pf0 = m0; Pf1 = m1; P0 = (double)m0; P1 = (double)m1;
 
-        /* ---- trace ---- */
-        acc = (acc << 4) | (f0 | (f1 << 2));
+        /* ---- trace: newest band in the top nibble, 8 bands per dword, 4 dwords per store ---- */
+        acc = __builtin_amdgcn_alignbit(f0 | (f1 << 2), acc, 4);       /* (acc >> 4) | (t << 28) */
         if ((b & 7) == 7) {
             a0 = a1; a1 = a2; a2 = a3; a3 = acc;
             if ((b & 31) == 31) {
-                const uint32_t ax = (lane == ABEA_MOVE_LANE) ? mvacc : a0;
-                trace[(size_t)(b >> 5) * 64 + lane] = make_uint4(ax, a1, a2, a3);
+                const bool ml = lane == ABEA_MOVE_LANE;
+                trace[(size_t)(b >> 5) * 64 + lane] = make_uint4(ml ? mvacc : a0, ml ? mvprev : a1, a2, a3);
+                mvprev = mvacc;
             }
         }
 
@@ -316,114 +355,81 @@ void abea_fill_kernel(const abea_read_desc* __restrict__ descs,
             step(std::true_type{});
         }
     }
-    if (lane == 0) {
-        abea_fill_out o; o.best_score = best; o.best_event = best_e; o.best_llk = best_llk; o.pad = 0;
-        fout[blockIdx.x] = o;
     }
-}
+    __syncthreads();            /* this wave's trace stores are complete before it reads them back */
 
-/* ---------------------------------------------------------------- align-post */
-static __device__ __forceinline__ uint32_t sel4(const uint4& v, int w) {
-    return w == 0 ? v.x : (w == 1 ? v.y : (w == 2 ? v.z : v.w));
-}
-
-static __device__ __forceinline__ int wave_excl_scan(int v, int lane, int& total) {
-    int s = v;
-    #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        int t = __shfl_up(s, off, 64);
-        if (lane >= off) s += t;
-    }
-    total = __shfl(s, 63, 64);
-    return s - v;
-}
-
-extern "C" __global__ __launch_bounds__(64)
-void abea_trace_kernel(const abea_read_desc* __restrict__ descs,
-                       const float* __restrict__ evm_all, const abea_kpar_t* __restrict__ kpar_all,
-                       const uint4* __restrict__ trace_all, const abea_fill_out* __restrict__ fout,
-                       uint32_t* __restrict__ codes_all,
-                       abea_pair_t* __restrict__ pairs_all, int32_t* __restrict__ n_pairs,
-                       abea_read_diag* __restrict__ diag) {
-    __shared__ float lp_s[1024];
-    const abea_read_desc* d = descs + blockIdx.x;
-    const int lane = threadIdx.x;
-    const int out_idx = d->out_idx;
-    abea_read_diag dg;
-    dg.sum_emission = 0.0; dg.n_aligned = 0; dg.best_event = 0; dg.max_score = NINF;
-    dg.max_gap = 0; dg.spanned = 0; dg.flags = 0; dg.pad = 0;
-    if (d->n_groups == 0) {                              /* align_single guards (f5c.c:813-814) */
-        if (lane == 0) { n_pairs[out_idx] = 0; dg.flags = ABEA_RF_SKIPPED; if (diag) diag[out_idx] = dg; }
-        return;
-    }
-    const abea_fill_out fo = fout[blockIdx.x];
-    const int K = d->n_kmers;
-    if (fo.best_score == NINF) {                         /* no in-band end cell, SURVEY §9-I */
+    /* ============================================================ phase 2: traceback walk */
+    if (best == NINF) {                                  /* no in-band end cell, SURVEY §9-I */
         if (lane == 0) { n_pairs[out_idx] = 0; dg.flags = ABEA_RF_NO_END; if (diag) diag[out_idx] = dg; }
         return;
     }
-    const float* __restrict__ evm = evm_all + d->evm_off;
-    const abea_kpar_t* __restrict__ kpar = kpar_all + d->kpar_off;
-    const uint4* __restrict__ trace = trace_all + d->trace_off;
     uint32_t* codes = codes_all + d->code_off;
     abea_pair_t* pairs = pairs_all + d->pair_off;
 
-    /* ---- serial walk (align.c:452-499): wave-uniform, runs on the scalar unit.  The trace of the
-     *      current 32-band group sits in 4 VGPRs (one uint4 per lane = the lane's two cells for 32
-     *      bands), the next lower group is prefetched, a step is one v_readlane + SALU bit picking.
-     *      Each step emits a 2-bit code; 16 codes -> one dword, 64 dwords -> one coalesced store. ---- */
-    int e = fo.best_event, k = K - 1, llk = fo.best_llk;
-    int b = e + k + 2;
+    /* align.c:452-499, wave-uniform, on the scalar unit.  The trace of the current 32-band group sits
+     * in 4 VGPRs (one uint4 per lane); the 128 bits of the lane pair the path is in are held in SGPRs,
+     * so a step is pure SALU bit picking; v_readlane only when the path changes lane pair or group.
+     * Each step emits a 2-bit code; 16 codes -> one dword, 64 dwords -> one coalesced store. */
+    int e = best_e, k = K - 1, llk = best_llk;
     int n = 0, gap = 0, max_gap = 0, last_k = k;
     uint32_t cwd = 0, cv = 0;
-    int g = b >> 5;
-    uint4 cw = trace[(size_t)g * 64 + lane];
-    uint4 nx = trace[(size_t)max(g - 1, 0) * 64 + lane];
-    uint32_t mv = readlane_i(cw.x, ABEA_MOVE_LANE);       /* 32 band-move bits of the group, bit 31-(b&31) */
-    while (k >= 0 && e >= 0) {
-        if ((b >> 5) != g) {                               /* stepped into the group below */
-            g = b >> 5;
-            cw = nx;
-            nx = trace[(size_t)max(g - 1, 0) * 64 + lane];
-            mv = readlane_i(cw.x, ABEA_MOVE_LANE);
-        }
-        last_k = k;
-        const int off = k - llk;                           /* band offset of (e,k): ll_k + off = k */
-        const int w = (b >> 3) & 3;
-        const int sh = (7 - (b & 7)) * 4;
-        const uint32_t cd = readlane_i(sel4(cw, w), off >> 1);
-        const uint32_t from = (cd >> (sh + ((off & 1) << 1))) & 3u;
-        const int mv_b = (mv >> (31 - (b & 31))) & 1;      /* 1 = band b was a right move */
-        cwd |= from << ((n & 15) << 1);
-        ++n;
-        if ((n & 15) == 0) {
-            if (lane == (((n >> 4) - 1) & 63)) cv = cwd;
-            cwd = 0;
-            if ((n & 1023) == 0) codes[(size_t)((n >> 10) - 1) * 64 + lane] = cv;
-        }
-        if (from == 0u) {                                  /* FROM_D: two bands back */
-            const int b1 = b - 1;
-            const uint32_t mvw1 = ((b1 >> 5) != g) ? (uint32_t)readlane_i(nx.x, ABEA_MOVE_LANE) : mv;
-            const int mv_b1 = (mvw1 >> (31 - (b1 & 31))) & 1;
-            llk -= mv_b + mv_b1; e -= 1; k -= 1; b -= 2; gap = 0;
-        } else if (from == 1u) {                           /* FROM_U */
-            llk -= mv_b; e -= 1; b -= 1; gap = 0;
-        } else {                                           /* FROM_L */
-            llk -= mv_b; k -= 1; b -= 1; gap += 1; max_gap = max(max_gap, gap);
+    {
+        int b = e + k + 2;
+        int g = b >> 5;
+        uint4 cw = trace[(size_t)g * 64 + lane];
+        uint4 nxg = trace[(size_t)max(g - 1, 0) * 64 + lane];
+        uint64_t mv64 = ((uint64_t)(uint32_t)readlane_i(cw.x, ABEA_MOVE_LANE) << 32) |
+                        (uint32_t)readlane_i(cw.y, ABEA_MOVE_LANE);
+        int lp = (k - llk) >> 1;
+        uint64_t tlo = ((uint64_t)(uint32_t)readlane_i(cw.y, lp) << 32) | (uint32_t)readlane_i(cw.x, lp);
+        uint64_t thi = ((uint64_t)(uint32_t)readlane_i(cw.w, lp) << 32) | (uint32_t)readlane_i(cw.z, lp);
+        while ((k | e) >= 0) {
+            const int off = k - llk;                       /* band offset of (e,k): ll_k + off = k */
+            const int bi = b & 31;
+            const int bp = 4 * bi + 2 * (off & 1);
+            const uint64_t t64 = (bp & 64) ? thi : tlo;
+            const uint32_t from = (uint32_t)(t64 >> (bp & 63)) & 3u;
+            const uint32_t two = (uint32_t)(mv64 >> (31 + bi)) & 3u;   /* bit1 = move(b), bit0 = move(b-1) */
+            cwd |= from << ((n & 15) << 1);
+            ++n;
+            if ((n & 15) == 0) {
+                if (lane == (((n >> 4) - 1) & 63)) cv = cwd;
+                cwd = 0;
+                if ((n & 1023) == 0) codes[(size_t)((n >> 10) - 1) * 64 + lane] = cv;
+            }
+            last_k = k;
+            const int dk = (int)((from & 1u) ^ 1u);        /* D,L step the k-mer */
+            const int de = (int)((from >> 1) ^ 1u);        /* D,U step the event */
+            const int isL = (int)(from >> 1);
+            k -= dk; e -= de; b -= dk + de;
+            llk -= (int)(two >> 1) + ((from == 0u) ? (int)(two & 1u) : 0);
+            gap = isL ? gap + 1 : 0;
+            max_gap = max(max_gap, gap);
+            const int g2 = b >> 5, lp2 = (k - llk) >> 1;
+            if (g2 != g) {                                 /* stepped into the group below */
+                g = g2; lp = lp2;
+                cw = nxg;
+                nxg = trace[(size_t)max(g - 1, 0) * 64 + lane];
+                mv64 = ((uint64_t)(uint32_t)readlane_i(cw.x, ABEA_MOVE_LANE) << 32) |
+                       (uint32_t)readlane_i(cw.y, ABEA_MOVE_LANE);
+                tlo = ((uint64_t)(uint32_t)readlane_i(cw.y, lp) << 32) | (uint32_t)readlane_i(cw.x, lp);
+                thi = ((uint64_t)(uint32_t)readlane_i(cw.w, lp) << 32) | (uint32_t)readlane_i(cw.z, lp);
+            } else if (lp2 != lp) {
+                lp = lp2;
+                tlo = ((uint64_t)(uint32_t)readlane_i(cw.y, lp) << 32) | (uint32_t)readlane_i(cw.x, lp);
+                thi = ((uint64_t)(uint32_t)readlane_i(cw.w, lp) << 32) | (uint32_t)readlane_i(cw.z, lp);
+            }
         }
     }
     if ((n & 15) != 0 && lane == ((n >> 4) & 63)) cv = cwd;
     if ((n & 1023) != 0 && lane <= (((n - 1) >> 4) & 63)) codes[(size_t)(n >> 10) * 64 + lane] = cv;
     __syncthreads();                                     /* this wave's code words -> all its lanes */
-#ifdef ABEA_EXP_WALK_ONLY
-    if (lane == 0) n_pairs[out_idx] = n;
-    return;
-#endif
 
-    /* ---- expansion: prefix sums turn codes into (k,e) pairs written in forward order;
-     *      log-emissions are summed in walk order, in double (align.c:473-476) ---- */
+    /* ============================================================ phase 3: expansion + QC
+     * prefix sums turn codes into (k,e) pairs written in forward order; log-emissions are summed in
+     * walk order, in double (align.c:473-476) */
     double sum = 0.0;
-    int base_k = K - 1, base_e = fo.best_event;
+    int base_k = K - 1, base_e = best_e;
     for (int c0 = 0; c0 < n; c0 += 1024) {
         const int i0 = c0 + 16 * lane;
         const int cnt = max(0, min(16, n - i0));
@@ -467,8 +473,8 @@ void abea_trace_kernel(const abea_read_desc* __restrict__ descs,
     if (lane == 0) {
         n_pairs[out_idx] = fail ? 0 : n;
         if (diag) {
-            dg.sum_emission = sum; dg.n_aligned = n; dg.best_event = fo.best_event;
-            dg.max_score = fo.best_score; dg.max_gap = max_gap; dg.spanned = spanned;
+            dg.sum_emission = sum; dg.n_aligned = n; dg.best_event = best_e;
+            dg.max_score = best; dg.max_gap = max_gap; dg.spanned = spanned;
             dg.flags = fail ? ABEA_RF_QC_FAIL : 0;
             diag[out_idx] = dg;
         }

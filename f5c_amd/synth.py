@@ -25,6 +25,8 @@ CONFIGS = {
     "r9_10k_8kb": dict(n_reads=10_000, seed=20250002, law="gamma8k", k=6),
     "r9_100k_mixed": dict(n_reads=100_000, seed=20250003, law="loguniform", k=6),
     "r10_50k_10kb": dict(n_reads=50_000, seed=20250005, law="gamma10k", k=9),
+    # not a BASELINE config: fixed-length reads, isolates kernel throughput from the longest-read tail
+    "r9_uniform_8kb": dict(n_reads=10_000, seed=20250099, law=8000, k=6),
 }
 
 
