@@ -191,6 +191,9 @@ void abea_align_kernel(const abea_read_desc* __restrict__ descs,
     uint4* __restrict__ trace = trace_all + d->trace_off;
 
     float best = NINF; int best_e = 0, best_llk = 0;
+#ifdef ABEA_PROFILE_PHASES
+    const unsigned long long t_start = wall_clock64();
+#endif
 
     /* ============================================================ phase 1: band fill */
     {
@@ -357,6 +360,9 @@ void abea_align_kernel(const abea_read_desc* __restrict__ descs,
     }
     }
     __syncthreads();            /* this wave's trace stores are complete before it reads them back */
+#ifdef ABEA_PROFILE_PHASES
+    const unsigned long long t_fill = wall_clock64();
+#endif
 
     /* ============================================================ phase 2: traceback walk */
     if (best == NINF) {                                  /* no in-band end cell, SURVEY §9-I */
@@ -375,55 +381,54 @@ void abea_align_kernel(const abea_read_desc* __restrict__ descs,
     uint32_t cwd = 0, cv = 0;
     {
         int b = e + k + 2;
-        int g = b >> 5;
-        uint4 cw = trace[(size_t)g * 64 + lane];
-        uint4 nxg = trace[(size_t)max(g - 1, 0) * 64 + lane];
-        uint64_t mv64 = ((uint64_t)(uint32_t)readlane_i(cw.x, ABEA_MOVE_LANE) << 32) |
-                        (uint32_t)readlane_i(cw.y, ABEA_MOVE_LANE);
-        int lp = (k - llk) >> 1;
-        uint64_t tlo = ((uint64_t)(uint32_t)readlane_i(cw.y, lp) << 32) | (uint32_t)readlane_i(cw.x, lp);
-        uint64_t thi = ((uint64_t)(uint32_t)readlane_i(cw.w, lp) << 32) | (uint32_t)readlane_i(cw.z, lp);
-        while ((k | e) >= 0) {
-            const int off = k - llk;                       /* band offset of (e,k): ll_k + off = k */
-            const int bi = b & 31;
-            const int bp = 4 * bi + 2 * (off & 1);
-            const uint64_t t64 = (bp & 64) ? thi : tlo;
-            const uint32_t from = (uint32_t)(t64 >> (bp & 63)) & 3u;
-            const uint32_t two = (uint32_t)(mv64 >> (31 + bi)) & 3u;   /* bit1 = move(b), bit0 = move(b-1) */
-            cwd |= from << ((n & 15) << 1);
-            ++n;
-            if ((n & 15) == 0) {
-                if (lane == (((n >> 4) - 1) & 63)) cv = cwd;
-                cwd = 0;
-                if ((n & 1023) == 0) codes[(size_t)((n >> 10) - 1) * 64 + lane] = cv;
-            }
-            last_k = k;
-            const int dk = (int)((from & 1u) ^ 1u);        /* D,L step the k-mer */
-            const int de = (int)((from >> 1) ^ 1u);        /* D,U step the event */
-            const int isL = (int)(from >> 1);
-            k -= dk; e -= de; b -= dk + de;
-            llk -= (int)(two >> 1) + ((from == 0u) ? (int)(two & 1u) : 0);
-            gap = isL ? gap + 1 : 0;
-            max_gap = max(max_gap, gap);
-            const int g2 = b >> 5, lp2 = (k - llk) >> 1;
-            if (g2 != g) {                                 /* stepped into the group below */
-                g = g2; lp = lp2;
-                cw = nxg;
-                nxg = trace[(size_t)max(g - 1, 0) * 64 + lane];
-                mv64 = ((uint64_t)(uint32_t)readlane_i(cw.x, ABEA_MOVE_LANE) << 32) |
-                       (uint32_t)readlane_i(cw.y, ABEA_MOVE_LANE);
-                tlo = ((uint64_t)(uint32_t)readlane_i(cw.y, lp) << 32) | (uint32_t)readlane_i(cw.x, lp);
-                thi = ((uint64_t)(uint32_t)readlane_i(cw.w, lp) << 32) | (uint32_t)readlane_i(cw.z, lp);
-            } else if (lp2 != lp) {
-                lp = lp2;
-                tlo = ((uint64_t)(uint32_t)readlane_i(cw.y, lp) << 32) | (uint32_t)readlane_i(cw.x, lp);
-                thi = ((uint64_t)(uint32_t)readlane_i(cw.w, lp) << 32) | (uint32_t)readlane_i(cw.z, lp);
-            }
+        uint4 cw = trace[(size_t)(b >> 5) * 64 + lane];
+        bool alive = true;
+        while (alive) {                                    /* one iteration per 32-band trace group */
+            const int g = b >> 5;
+            const uint4 nxg = trace[(size_t)max(g - 1, 0) * 64 + lane];    /* prefetch the group below */
+            const uint64_t mv64 = ((uint64_t)(uint32_t)readlane_i(cw.x, ABEA_MOVE_LANE) << 32) |
+                                  (uint32_t)readlane_i(cw.y, ABEA_MOVE_LANE);
+            int lp = -1;
+            uint64_t tlo = 0, thi = 0;
+            do {
+                const int off = k - llk;                   /* band offset of (e,k): ll_k + off = k */
+                if ((off >> 1) != lp) {                    /* path moved to another lane pair */
+                    lp = off >> 1;
+                    tlo = ((uint64_t)(uint32_t)readlane_i(cw.y, lp) << 32) | (uint32_t)readlane_i(cw.x, lp);
+                    thi = ((uint64_t)(uint32_t)readlane_i(cw.w, lp) << 32) | (uint32_t)readlane_i(cw.z, lp);
+                }
+                const int bi = b & 31;
+                const int bp = 4 * bi + 2 * (off & 1);
+                const uint64_t t64 = (bp & 64) ? thi : tlo;
+                const uint32_t from = (uint32_t)(t64 >> (bp & 63)) & 3u;
+                const uint32_t two = (uint32_t)(mv64 >> (31 + bi)) & 3u;   /* bit1 = move(b), bit0 = move(b-1) */
+                cwd |= from << ((n & 15) << 1);
+                ++n;
+                if ((n & 15) == 0) {
+                    if (lane == (((n >> 4) - 1) & 63)) cv = cwd;
+                    cwd = 0;
+                    if ((n & 1023) == 0) codes[(size_t)((n >> 10) - 1) * 64 + lane] = cv;
+                }
+                last_k = k;
+                const uint32_t isL = from >> 1;
+                const uint32_t notD = (from | isL) & 1u;   /* 0 only for FROM_D */
+                const int dk = (int)((from & 1u) ^ 1u);    /* D,L step the k-mer */
+                const int de = (int)(isL ^ 1u);            /* D,U step the event */
+                k -= dk; e -= de; b -= dk + de;
+                llk -= (int)(two >> 1) + (int)(two & (notD ^ 1u));
+                gap = isL ? gap + 1 : 0;
+                max_gap = max(max_gap, gap);
+                alive = (k | e) >= 0;
+            } while (alive && (b >> 5) == g);
+            cw = nxg;
         }
     }
     if ((n & 15) != 0 && lane == ((n >> 4) & 63)) cv = cwd;
     if ((n & 1023) != 0 && lane <= (((n - 1) >> 4) & 63)) codes[(size_t)(n >> 10) * 64 + lane] = cv;
     __syncthreads();                                     /* this wave's code words -> all its lanes */
+#ifdef ABEA_PROFILE_PHASES
+    const unsigned long long t_walk = wall_clock64();
+#endif
 
     /* ============================================================ phase 3: expansion + QC
      * prefix sums turn codes into (k,e) pairs written in forward order; log-emissions are summed in
@@ -476,6 +481,11 @@ void abea_align_kernel(const abea_read_desc* __restrict__ descs,
             dg.sum_emission = sum; dg.n_aligned = n; dg.best_event = best_e;
             dg.max_score = best; dg.max_gap = max_gap; dg.spanned = spanned;
             dg.flags = fail ? ABEA_RF_QC_FAIL : 0;
+#ifdef ABEA_PROFILE_PHASES   /* experiment build only: overwrite the diagnostics with a phase timeline (100 MHz ticks) */
+            const unsigned long long t_end = wall_clock64();
+            dg.sum_emission = (double)t_start; dg.best_event = (int)(t_fill - t_start);
+            dg.max_gap = (int)(t_walk - t_fill); dg.spanned = (int)(t_end - t_walk);
+#endif
             diag[out_idx] = dg;
         }
     }

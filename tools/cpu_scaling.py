@@ -1,5 +1,5 @@
 import os, sys, time, numpy as np
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from f5c_amd import synth, load_model_f32
 from oracle import orc
 k, model = load_model_f32("tests/golden/r9.4_450bps.6mer.f32")

@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Experiment helper: per-read phase timeline of abea_align_kernel (needs the ABEA_PROFILE_PHASES build:
+   ABEA_LIB_PATH=build/libabea_prof.so python tools/phase_profile.py [--reads N] [--config C])."""
+import argparse, os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from f5c_amd import abea, synth, load_model_f32
+ap = argparse.ArgumentParser(); ap.add_argument("--reads", type=int, default=10000); ap.add_argument("--config", default="r9_10k_8kb")
+a = ap.parse_args()
+cfg = synth.CONFIGS[a.config]
+k, model = load_model_f32("tests/golden/r9.4_450bps.6mer.f32")
+b = synth.make_batch(a.reads, model, k, seed=cfg["seed"], law=cfg["law"], workers=32)
+d = abea.AbeaContext.upload(b)
+ctx = abea.AbeaContext(model, k)
+ctx.align_db_device(d); ctx.align_db_device(d)
+st = ctx.stats()
+_, n_pairs, dg = ctx.download(d)
+ok = dg["n_aligned"] > 0
+t0 = dg["sum_emission"][ok]; fill = dg["best_event"][ok].astype(np.float64); walk = dg["max_gap"][ok].astype(np.float64); exp = dg["spanned"][ok].astype(np.float64)
+bands = (b["n_events"] + b["read_len"] - k + 3)[ok].astype(np.float64); steps = dg["n_aligned"][ok].astype(np.float64)
+base = t0.min(); end = (t0 + fill + walk + exp)
+tick = 10e-9
+print(f"kernel {st['fill_ms']:.2f} ms; span by timestamps {(end.max()-base)*tick*1e3:.2f} ms; reads {ok.sum()}")
+print(f"sum fill {fill.sum()*tick*1e3:.1f} ms-wave, walk {walk.sum()*tick*1e3:.1f}, expand {exp.sum()*tick*1e3:.1f}")
+print(f"per band: median {np.median(fill/bands)*10:.1f} ns, p10 {np.percentile(fill/bands,10)*10:.1f}, p90 {np.percentile(fill/bands,90)*10:.1f}")
+print(f"per step: median {np.median(walk/steps)*10:.1f} ns, p10 {np.percentile(walk/steps,10)*10:.1f}, p90 {np.percentile(walk/steps,90)*10:.1f}")
+print(f"expand per step: median {np.median(exp/steps)*10:.1f} ns")
+T = (end.max() - base)
+for q in range(10):
+    lo, hi = base + T * q / 10, base + T * (q + 1) / 10
+    mid = (lo + hi) / 2
+    nf = ((t0 <= mid) & (t0 + fill > mid)).sum(); nw = ((t0 + fill <= mid) & (t0 + fill + walk > mid)).sum()
+    ne = ((t0 + fill + walk <= mid) & (end > mid)).sum()
+    print(f"  t={q*10+5:3d}%: waves filling {nf:5d} walking {nw:5d} expanding {ne:5d}")
+i = np.argmax(bands)
+print(f"longest read: {bands[i]:.0f} bands fill {fill[i]*tick*1e3:.2f} ms ({fill[i]/bands[i]*10:.0f} ns/band) walk {walk[i]*tick*1e3:.2f} ms ({walk[i]/steps[i]*10:.0f} ns/step) start {(t0[i]-base)*tick*1e3:.2f} end {(end[i]-base)*tick*1e3:.2f}")
