@@ -15,6 +15,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <pthread.h>
+#include <malloc.h>
 
 #define ORC_BW 100                 /* ALN_BANDWIDTH f5c.h:34 */
 #define ORC_FROM_D 0               /* align.c:194-196 */
@@ -241,6 +242,15 @@ int32_t orc_align_single(orc_pair_t* out, const char* seq, int32_t seq_len,
         return orc_align(out, seq, seq_len, ev, n_events, model, k, scale, shift, diag);
     }
     return 0;
+}
+
+/* Process-level allocator tuning for the CPU baseline (not part of the algorithm): align() mallocs
+ * ~12 MB per 8 kb read; with glibc defaults every one is an mmap/munmap + page faults under the
+ * process-wide mm lock, which stops scaling beyond ~64 threads.  on=1 keeps the buffers on the
+ * per-thread heaps (what MALLOC_MMAP_THRESHOLD_/MALLOC_TRIM_THRESHOLD_ would do for f5c itself). */
+void orc_malloc_tuning(int on) {
+    if (on) { mallopt(M_MMAP_THRESHOLD, 1 << 30); mallopt(M_TRIM_THRESHOLD, -1); mallopt(M_TOP_PAD, 64 << 20); }
+    else    { mallopt(M_MMAP_THRESHOLD, 128 * 1024); mallopt(M_TRIM_THRESHOLD, 128 * 1024); mallopt(M_TOP_PAD, 0); }
 }
 
 /* ---- batch driver: pthread_db-shaped pool (f5c.c:575-679) ---- */

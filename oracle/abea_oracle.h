@@ -59,6 +59,9 @@ void orc_align_batch(int32_t n_reads, const char* reads, const int64_t* read_ptr
                      orc_pair_t* pairs, const int64_t* pair_ptr, int32_t* n_pairs, orc_diag_t* diags,
                      int32_t n_threads);
 
+/* glibc allocator tuning for the multi-threaded CPU baseline (see abea_oracle.c) */
+void orc_malloc_tuning(int on);
+
 /* postalign + recalibrate_model (align.c:561-773, f5c.c:736-807) : "next" row N1 */
 typedef struct { int32_t start; int32_t stop; } orc_index_pair_t;        /* f5c.h:187-190 */
 int32_t orc_scaling_single(const orc_pair_t* pairs, int32_t n_pairs, const char* seq, int32_t seq_len,

@@ -97,6 +97,10 @@ def align_batch(batch, model, k, n_threads=1, want_diag=True):
     return pairs, n_pairs, diags
 
 
+def malloc_tuning(on: bool):
+    lib().orc_malloc_tuning(1 if on else 0)
+
+
 def scaling_single(pairs, seq: bytes, events, model, k, scale, shift):
     sc = np.zeros(1, dtype=SCAL_DT)
     sc["scale"] = scale
