@@ -15,6 +15,7 @@ LIB_PATH = os.environ.get("ABEA_LIB_PATH", os.path.join(_HERE, "libabea_hip.so")
 
 EXPORTS = ["abea_init", "abea_free", "abea_last_error", "abea_align_batch_host",
            "abea_align_batch_device", "abea_get_stats", "abea_device_info", "abea_selftest"]
+SHIM_EXPORTS = ["abea_f5c_init", "abea_f5c_align", "abea_f5c_free"]      # include/abea_f5c_shim.h
 
 
 class AbeaError(RuntimeError):

@@ -1,0 +1,55 @@
+/* include/abea_f5c_shim.h — align_db()-shaped shim over the C ABI (include/abea.h).
+ *
+ * What an f5c maintainer links instead of src/f5c.cu + src/align.cu (or their .hip twins): three
+ * void functions with the reference's own names' shape and error convention
+ *     init_cuda(core_t*)            src/f5c.cu:23    -> abea_f5c_init(abea_f5c_core*)
+ *     align_cuda(core_t*, db_t*)    src/f5c.cu:647   -> abea_f5c_align(abea_f5c_core*, abea_f5c_db*)
+ *     free_cuda(core_t*)            src/f5c.cu:204   -> abea_f5c_free(abea_f5c_core*)
+ * operating on POD views that name exactly the core_t / db_t fields the reference's GPU path touches
+ * (SURVEY.md §8b).  INTEGRATION.md shows the ~25-line glue that fills the views inside f5c.
+ * Errors: like the reference (src/error.h:38-92, f5cmisc.cuh:78-97) the shim prints to stderr and
+ * exit(EXIT_FAILURE)s; it never returns a status.
+ */
+#ifndef ABEA_F5C_SHIM_H
+#define ABEA_F5C_SHIM_H
+#include "abea.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct {                       /* event_table, src/f5c.h:139-144 */
+    size_t n; size_t start; size_t end; abea_event_t* event;
+} abea_f5c_event_table;
+
+typedef struct {                       /* the slice of core_t used by init_cuda/align_cuda/free_cuda */
+    const abea_model_t* model;         /* core->model                         f5c.h:424 */
+    uint32_t kmer_size;                /* core->kmer_size                     f5c.h:426 */
+    int32_t  cuda_dev_id;              /* core->opt.cuda_dev_id               f5c.h:124 */
+    float    cuda_mem_frac;            /* core->opt.cuda_mem_frac             f5c.h:125 */
+    int32_t  verbosity;                /* core->opt.verbosity */
+    void*    cuda;                     /* core->cuda (opaque; owned by the shim) f5c.h:455 */
+    /* timing accumulators, seconds, same meaning as core_t's (f5c.h:457-466) */
+    double align_kernel_time, align_pre_kernel_time, align_core_kernel_time, align_post_kernel_time;
+    double align_cuda_memcpy, align_cuda_preprocess, align_cuda_postprocess, align_cuda_total_kernel;
+} abea_f5c_core;
+
+typedef struct {                       /* the slice of db_t align_cuda reads/writes, src/f5c.h:290-352 */
+    int32_t n_bam_rec;
+    char** read;                       /* db->read[i] */
+    int32_t* read_len;
+    const int64_t* nsample;            /* db->sig[i]->nsample gathered into an array; NULL = all good */
+    abea_f5c_event_table* et;          /* db->et */
+    abea_scalings_t* scalings;         /* db->scalings */
+    abea_pair_t** event_align_pairs;   /* db->event_align_pairs (caller-allocated, f5c.c:724) */
+    int32_t* n_event_align_pairs;      /* db->n_event_align_pairs */
+    int64_t sum_bases;                 /* db->sum_bases (statistics only) */
+} abea_f5c_db;
+
+void abea_f5c_init(abea_f5c_core* core);
+void abea_f5c_align(abea_f5c_core* core, abea_f5c_db* db);
+void abea_f5c_free(abea_f5c_core* core);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -7,10 +7,10 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared():
-    hdr = open(os.path.join(ROOT, "include", "abea.h")).read()
+def _declared(header="abea.h"):
+    hdr = open(os.path.join(ROOT, "include", header)).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
-    return sorted(set(re.findall(r"\b(abea_[a-z_]+)\s*\(", hdr)))
+    return sorted(set(re.findall(r"\b(abea_[a-z0-9_]+)\s*\(", hdr)))
 
 
 def test_header_declares_expected_entry_points():
@@ -28,6 +28,9 @@ def test_library_exports_every_declared_symbol():
     for n in _declared():
         assert hasattr(lib, n), f"{n} declared in include/abea.h but not exported"
     assert sorted(abea.EXPORTS) == _declared()
+    for n in _declared("abea_f5c_shim.h"):
+        assert hasattr(lib, n), f"{n} declared in include/abea_f5c_shim.h but not exported"
+    assert sorted(abea.SHIM_EXPORTS) == _declared("abea_f5c_shim.h")
 
 
 def test_no_gpu_fails_loudly(r9):

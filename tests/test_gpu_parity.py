@@ -168,3 +168,38 @@ def test_r10_9mer_synthetic_model(orc):
     ora = orc.align_batch(batch, model, 9, n_threads=8)
     _check_batch(batch, res, ora, "r10")
     assert (ora[1] > 0).mean() > 0.7
+
+
+def test_cpp_caller_through_f5c_shim(orc, r9, tmp_path):
+    """Host code in the reference's language: a plain g++-built C++ caller shaped like process_db
+    (per-read malloc'ed buffers, event_table structs) goes through include/abea_f5c_shim.h
+    (init_cuda / align_cuda / free_cuda shaped) and prints --print-banded-aln style pair lists."""
+    import os, struct, subprocess
+    from f5c_amd import synth, abea
+    k, model = r9
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "shim_driver")
+    subprocess.check_call(["g++", "-std=c++11", "-O2", os.path.join(root, "tests", "shim_driver.cpp"), "-o", exe,
+                           "-L", os.path.dirname(abea.LIB_PATH), "-labea_hip",
+                           "-Wl,-rpath," + os.path.dirname(os.path.abspath(abea.LIB_PATH))])
+    batch = synth.make_batch(20, model, k, seed=71, law=1800, bad_frac=0.15)
+    n = len(batch["read_len"])
+    blob = struct.pack("<4i", n, k, len(model), 0) + model.tobytes() + batch["read_len"].tobytes() + \
+        batch["n_events"].tobytes() + batch["scalings"].tobytes()
+    for i in range(n):
+        s, L = int(batch["read_ptr"][i]), int(batch["read_len"][i])
+        blob += batch["reads"][s:s + L].tobytes()
+    blob += batch["events"].tobytes()
+    (tmp_path / "batch.bin").write_bytes(blob)
+    subprocess.check_call([exe, str(tmp_path / "batch.bin"), str(tmp_path / "out.txt")])
+    o_pairs, o_n, _ = orc.align_batch(batch, model, k, n_threads=4)
+    lines = (tmp_path / "out.txt").read_text().splitlines()
+    assert len(lines) == n
+    for i, ln in enumerate(lines):
+        f = ln.split("\t")
+        assert int(f[0]) == i
+        got = [tuple(int(v) for v in t.strip("{}").split(",")) for t in f[1:] if t]
+        s = int(batch["pair_ptr"][i])
+        exp = [tuple(int(v) for v in p) for p in o_pairs[s:s + o_n[i]]]
+        assert got == exp, f"read {i}"
+    assert (o_n > 0).sum() >= 12
