@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 #include <type_traits>
 #include "abea_device.h"
+#include "abea_fill_interior.inc"
 
 #define NINF (-__builtin_inff())
 
@@ -60,6 +61,13 @@ template <int LANE> static __device__ __forceinline__ float writelane_f(float ol
     return __int_as_float(writelane_i<LANE>(__float_as_int(oldv), __float_as_int(val)));
 }
 static __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+static __device__ __forceinline__ double uni_d(double v) {
+    return __hiloint2double(uni(__double2hiint(v)), uni(__double2loint(v)));
+}
+static __device__ __forceinline__ const void* uni_p(const void* p) {
+    const unsigned long long a = (unsigned long long)p;
+    return (const void*)(((unsigned long long)(unsigned)uni((int)(a >> 32)) << 32) | (unsigned)uni((int)a));
+}
 
 /* ---------------------------------------------------------------- selftest */
 extern "C" __global__ void abea_selftest_kernel(int* out) {
@@ -233,10 +241,12 @@ void abea_align_kernel(const abea_read_desc* __restrict__ descs,
     float e_pend = evm[min(128 + lane, E - 1)];         /* chunk 2, written when chunk 1 is entered */
     k_ring[64 + lane] = kpar[min(64 + lane, K - 1)];    /* chunk 1 */
     k_ring[lane] = kpar[min(128 + lane, K - 1)];        /* chunk 2 */
-    abea_kpar_t k_pend = kpar[min(192 + lane, K - 1)];  /* chunk 3 */
+    float kpg, kpc; double kpi;                         /* chunk 3, in flight */
+    { const abea_kpar_t t = kpar[min(192 + lane, K - 1)]; kpg = t.gpm; kpc = t.ck; kpi = t.istd; }
     __syncthreads();
     float nx = e_ring[e_next & 127];
-    abea_kpar_t nk = k_ring[k_next & 127];
+    float nkg, nkc; double nki;                         /* incoming k-mer (uniform) */
+    { const abea_kpar_t t = k_ring[k_next & 127]; nkg = t.gpm; nkc = t.ck; nki = t.istd; }
 
     uint32_t acc = (lane == 25) ? (1u << 28) : 0u;     /* bands 0,1: only band 1 offset 50 = FROM_U */
     uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
@@ -258,19 +268,21 @@ void abea_align_kernel(const abea_read_desc* __restrict__ descs,
         if (right) {
             ll_k += 1;
             /* k-mer parameters slide one offset down; nk (k-mer ll_k+127) enters at lane 63 slot 1 */
-            const float tg = dpp_from_upper_f(nk.gpm, g0);
-            const float tc = dpp_from_upper_f(nk.ck, c0);
-            const double ti = dpp_from_upper_d(nk.istd, i0);
+            const float tg = dpp_from_upper_f(nkg, g0);
+            const float tc = dpp_from_upper_f(nkc, c0);
+            const double ti = dpp_from_upper_d(nki, i0);
             g0 = g1; c0 = c1; i0 = i1;
             g1 = tg; c1 = tc; i1 = ti;
             k_next += 1;
             if ((k_next & 63) == 0) {                  /* entering chunk c: land chunk c+1, fetch chunk c+2 */
                 const int c = k_next >> 6;
-                k_ring[((c + 1) & 1) * 64 + lane] = k_pend;
-                k_pend = kpar[min((c + 2) * 64 + lane, K - 1)];
+                abea_kpar_t t; t.gpm = kpg; t.ck = kpc; t.istd = kpi;
+                k_ring[((c + 1) & 1) * 64 + lane] = t;
+                t = kpar[min((c + 2) * 64 + lane, K - 1)];
+                kpg = t.gpm; kpc = t.ck; kpi = t.istd;
                 __syncthreads();
             }
-            nk = k_ring[k_next & 127];
+            { const abea_kpar_t t = k_ring[k_next & 127]; nkg = t.gpm; nkc = t.ck; nki = t.istd; }
             nL0 = P0; nL1 = P1;
             nU0 = P1; nU1 = dpp_from_upper_d((double)NINF, P0);
             D0 = U0; D1 = U1;
@@ -353,7 +365,43 @@ void abea_align_kernel(const abea_read_desc* __restrict__ descs,
          * nor the last k-mer column can be in band, whatever the moves: one of ll_e / ll_k grows per band */
         int run = min(min(E - 2 - ll_e, K - 102 - ll_k), nb_pad - b);
         if (ll_k >= 0 && ll_e >= 99 && run > 0) {
+#ifdef ABEA_NO_ASM
             for (; run > 0; --run) step(std::false_type{});
+#else
+            /* hand-scheduled interior loop (tools/gen_fill_asm.py): same semantics as step(false) x run */
+            uint32_t toff = (uint32_t)lane * 16u + (uint32_t)(b >> 5) * 1024u;
+            uint32_t t0, t1; uint64_t cm0a, cm0b, cm1a, cm1b;
+            /* "s" operands must be provably wave-uniform */
+            int s_ll_e = uni(ll_e), s_ll_k = uni(ll_k), s_e_next = uni(e_next), s_k_next = uni(k_next);
+            int s_b = uni(b), s_run = uni(run);
+            uint32_t s_mvacc = (uint32_t)uni((int)mvacc), s_mvprev = (uint32_t)uni((int)mvprev);
+            const double u_step = uni_d(lp_step), u_stay = uni_d(lp_stay), u_skip = uni_d(lp_skip);
+            const float* u_evm = (const float*)uni_p(evm);
+            const abea_kpar_t* u_kpar = (const abea_kpar_t*)uni_p(kpar);
+            uint4* u_trace = (uint4*)uni_p(trace);
+            const uint32_t kring_a = (uint32_t)(uintptr_t)k_ring, ering_a = (uint32_t)(uintptr_t)e_ring;
+            const int Km1 = K - 1, Em1 = E - 1;
+            const uint64_t hi_mask = 0xFFFC000000000000ull, m50 = 1ull << ABEA_MOVE_LANE;
+            asm volatile(ABEA_FILL_INTERIOR_ASM
+                : [Pf0] "+v"(Pf0), [Pf1] "+v"(Pf1), [x0] "+v"(x0), [x1] "+v"(x1),
+                  [g0] "+v"(g0), [c0] "+v"(c0), [g1] "+v"(g1), [c1] "+v"(c1),
+                  [nkg] "+v"(nkg), [nkc] "+v"(nkc), [nx] "+v"(nx), [e_pend] "+v"(e_pend),
+                  [kpg] "+v"(kpg), [kpc] "+v"(kpc), [a1] "+v"(a1), [a2] "+v"(a2), [a3] "+v"(a3),
+                  [acc] "+v"(acc), [toff] "+v"(toff),
+                  [i0] "+v"(i0), [i1] "+v"(i1), [nki] "+v"(nki), [kpi] "+v"(kpi),
+                  [L0] "+v"(L0), [L1] "+v"(L1), [U0] "+v"(U0), [U1] "+v"(U1),
+                  [ll_e] "+s"(s_ll_e), [ll_k] "+s"(s_ll_k), [e_next] "+s"(s_e_next), [k_next] "+s"(s_k_next),
+                  [mvacc] "+s"(s_mvacc), [mvprev] "+s"(s_mvprev), [b] "+s"(s_b), [run] "+s"(s_run),
+                  [t0] "=&s"(t0), [t1] "=&s"(t1), [cm0a] "=&s"(cm0a), [cm0b] "=&s"(cm0b),
+                  [cm1a] "=&s"(cm1a), [cm1b] "=&s"(cm1b)
+                : [lane] "v"(lane), [lp_step] "s"(u_step), [lp_stay] "s"(u_stay), [lp_skip] "s"(u_skip),
+                  [Km1] "s"(uni(Km1)), [Em1] "s"(uni(Em1)), [kring] "s"(kring_a), [ering] "s"(ering_a),
+                  [hi_mask] "s"(hi_mask), [m50] "s"(m50), [evm] "s"(u_evm), [kpar] "s"(u_kpar), [trace] "s"(u_trace)
+                : ABEA_FILL_INTERIOR_CLOBBERS);
+            ll_e = s_ll_e; ll_k = s_ll_k; e_next = s_e_next; k_next = s_k_next; b = s_b; run = s_run;
+            mvacc = s_mvacc; mvprev = s_mvprev;
+            P0 = (double)Pf0; P1 = (double)Pf1;
+#endif
         } else {
             step(std::true_type{});
         }

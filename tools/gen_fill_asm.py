@@ -1,0 +1,361 @@
+#!/usr/bin/env python3
+"""Generate f5c_amd/csrc/abea_fill_interior.inc: the hand-scheduled gfx950 band-fill loop for the
+interior stretch of a read (every band cell in range, no trim column, no end-scan), as ONE inline-asm
+statement.  Run:  python tools/gen_fill_asm.py
+
+Why asm: the loop is issue-bound; hipcc's version carries ~25 phi-copy v_movs, a 10-branch decision
+diamond and conservative vmcnt(0) waits per band.  This version keeps the loop state in
+fixed VGPRs v64..v127, is unrolled over (band parity, previous move, this move) = 8 straight-line bodies so
+that the diagonal / up / left operands are pure register NAMES (no copies), and places its own waits.
+
+Score state per band: the float scores mf0,mf1 of the previous band, and a "triple" of exact doubles
+  c0 = (double)mf0, c1 = (double)mf1, cs = (double)shift(mf)   (shift = lane+1's mf0 for a right move,
+                                                                lane-1's mf1 for a down move)
+  right move: left = (c0,c1)  up = (c1,cs);   down move: left = (cs,c0)  up = (c0,c1)
+  diagonal of this band = up (right move) / left (down move) of the PREVIOUS band's triple.
+Two triples ping-pong with band parity.
+
+Hazards honoured by construction (gfx940/950, no assembler help inside inline asm):
+  VALU write VGPR -> v_readlane of it: >=1 wait state;  -> DPP read of it: >=2
+  VALU write SGPR/VCC -> VALU read of it (v_cndmask mask, v_cmp operand): >=2
+  global_store_dwordx4 data registers are private copies (v106..v109), rewritten only 32 bands later
+"""
+import os
+
+VB = 64  # first fixed VGPR (v64..v119)
+MF0, MF1, SHR, SHD = 64, 65, 66, 67
+TR = [dict(c0=68, c1=70, cs=72), dict(c0=74, c1=76, cs=78)]
+X0, X1 = 80, 81
+G0, C0, G1, C1 = 82, 83, 84, 85
+I0, I1 = 86, 88
+NK = 90            # v[90:93] = incoming k-mer {gpm, ck, istd}
+NX = 94
+EPEND = 95
+KPEND = 96         # v[96:99]
+A0, A1, A2, ACC = 100, 101, 102, 103
+NINF = 104
+LANE = 105
+LPD = [106, 108]
+TD = [110, 112]    # per-cell f64 temps
+TU = [114, 116]
+Q = 106            # store quad v[106:109] aliases the LPD temps (free at the end of a band)
+TMP = 118          # 32-bit address temp
+TOFF = 119         # trace store offset (lane*16 + group*1024)
+F = [111, 113]     # from codes: high halves of the TD pairs (free once sd is rounded)
+VEND = 120         # one past the last fixed VGPR
+# extra per-cell 32-bit temps reuse the low halves of f64 temps where noted
+
+out = []
+lbl_id = [0]
+
+
+def emit(s):
+    out.append(s)
+
+
+def v(n):
+    return f"v{n}"
+
+
+def vp(n):
+    return f"v[{n}:{n+1}]"
+
+
+def vq(n):
+    return f"v[{n}:{n+3}]"
+
+
+def newid():
+    lbl_id[0] += 1
+    return lbl_id[0]
+
+
+DPP_SHL = "wave_shl:1 row_mask:0xf bank_mask:0xf"
+DPP_SHR = "wave_shr:1 row_mask:0xf bank_mask:0xf"
+
+
+def cell_ops(j, D, U, L):
+    """Instruction list for cell j (0/1); D,U,L = first register of the f64 pairs."""
+    x = X0 + j
+    g, ck, i = (G0, C0, I0) if j == 0 else (G1, C1, I1)
+    lpd, td, tu = LPD[j], TD[j], TU[j]
+    t32 = td          # 32-bit scratch: low half of td before td is used
+    sd, su, sl = td, tu, lpd   # after the adds the pair's low dword holds the float result (cvt in place)
+    cm1, cm2 = f"%[cm{j}a]", f"%[cm{j}b]"
+    mf = MF0 + j
+    ops = [
+        f"v_sub_f32 {v(t32)}, {v(x)}, {v(g)}",
+        f"v_cvt_f64_f32 {vp(lpd)}, {v(t32)}",
+        f"v_mul_f64 {vp(lpd)}, {vp(lpd)}, {vp(i)}",
+        f"v_cvt_f32_f64 {v(t32)}, {vp(lpd)}",
+        f"v_mul_f32 {v(tu)}, -0.5, {v(t32)}",
+        f"v_mul_f32 {v(tu)}, {v(tu)}, {v(t32)}",
+        f"v_add_f32 {v(tu)}, {v(ck)}, {v(tu)}",
+        f"v_cvt_f64_f32 {vp(lpd)}, {v(tu)}",
+        f"v_add_f64 {vp(td)}, {vp(D)}, %[lp_step]",
+        f"v_add_f64 {vp(tu)}, {vp(U)}, %[lp_stay]",
+        f"v_add_f64 {vp(td)}, {vp(td)}, {vp(lpd)}",
+        f"v_add_f64 {vp(tu)}, {vp(tu)}, {vp(lpd)}",
+        f"v_add_f64 {vp(lpd)}, {vp(L)}, %[lp_skip]",
+        f"v_cvt_f32_f64 {v(sd)}, {vp(td)}",
+        f"v_cvt_f32_f64 {v(su)}, {vp(tu)}",
+        f"v_cvt_f32_f64 {v(sl)}, {vp(lpd)}",
+        f"v_max3_f32 {v(F[j])}, {v(sd)}, {v(su)}, {v(sl)}",          # F[j] temporarily holds the max
+        f"v_cmp_ge_f32 {cm1}, {v(su)}, {v(sd)}",
+        f"v_cmp_eq_f32 {cm2}, {v(sl)}, {v(F[j])}",
+        # >= 2 wait states before the masks are read: the mf write and a nop-equivalent come first
+        f"v_cndmask_b32 {v(mf)}, {v(F[j])}, {v(NINF)}, %[hi_mask]",  # lanes >= 50 pinned to -inf
+        "s_nop 0",
+        f"v_cndmask_b32 {v(F[j])}, 0, 1, {cm1}",
+        f"v_cndmask_b32 {v(F[j])}, {v(F[j])}, 2, {cm2}",
+    ]
+    return ops
+
+
+def interleave(a, b):
+    """Alternate two independent instruction streams (fills dependent-issue and hazard slots)."""
+    res = []
+    for i in range(max(len(a), len(b))):
+        if i < len(a):
+            res.append(a[i])
+        if i < len(b):
+            res.append(b[i])
+    return res
+
+
+def decide(p_next, m_last):
+    """Tail of a band (or the entry stub): pick the move of the NEXT band and jump to its body.
+    Expects: %[t0] = readlane(mf0, lane 0) already issued, vcc = (t0 < mf1) per lane already issued."""
+    tag = f"{p_next}{m_last}"
+    emit("s_cmp_eq_u32 %[run], 0")
+    emit(f"s_cbranch_scc1 exit_{tag}_%=")
+    emit("s_cmp_eq_u32 %[t0], 0xff800000")
+    emit(f"s_cbranch_scc1 llinf_{tag}_{newid()}_%=")
+    lbl = f"llinf_{tag}_{lbl_id[0]}_%="
+    emit("s_bitcmp1_b32 vcc_hi, 17")                     # lane 49: ll < ur  -> right (align.c:313)
+    emit(f"s_cbranch_scc1 body_{tag}R_%=")
+    emit(f"s_branch body_{tag}D_%=")
+    return lbl
+
+
+def llinf_block(lbl, p_next, m_last):
+    tag = f"{p_next}{m_last}"
+    emit(f"{lbl}:")
+    emit(f"v_readlane_b32 %[t1], {v(MF1)}, 49")
+    emit("s_cmp_eq_u32 %[t1], 0xff800000")
+    emit(f"s_cbranch_scc0 body_{tag}R_%=")               # ll = -inf < finite ur
+    emit("s_bitcmp1_b32 %[b], 0")                         # both -inf: alternate, right on odd bands (align.c:311)
+    emit(f"s_cbranch_scc1 body_{tag}R_%=")
+    emit(f"s_branch body_{tag}D_%=")
+
+
+def body(p, ml, m):
+    """Band body for parity p, previous move ml, this move m ('R'/'D')."""
+    T, Tp = TR[p], TR[p ^ 1]
+    tag = f"{p}{ml}{m}"
+    emit(f"body_{tag}_%=:")
+    if m == 'R':
+        emit("s_add_u32 %[ll_k], %[ll_k], 1")
+        emit(f"v_mov_b32_dpp {v(SHR)}, {v(MF0)} {DPP_SHL}")
+        emit("s_waitcnt lgkmcnt(1)" if ml == 'D' else "s_waitcnt lgkmcnt(0)")     # incoming k-mer landed
+        emit(f"v_mov_b32_dpp {v(NK)}, {v(G0)} {DPP_SHL}")
+        emit(f"v_mov_b32_dpp {v(NK+1)}, {v(C0)} {DPP_SHL}")
+        emit(f"v_mov_b32_dpp {v(NK+2)}, {v(I0)} {DPP_SHL}")
+        emit(f"v_mov_b32_dpp {v(NK+3)}, {v(I0+1)} {DPP_SHL}")
+        emit(f"v_mov_b64 {vp(G0)}, {vp(G1)}")
+        emit(f"v_mov_b64 {vp(I0)}, {vp(I1)}")
+        emit(f"v_mov_b64 {vp(G1)}, {vp(NK)}")
+        emit(f"v_mov_b64 {vp(I1)}, {vp(NK+2)}")
+        emit("s_lshr_b32 %[mvacc], %[mvacc], 1")
+        emit("s_or_b32 %[mvacc], %[mvacc], 0x80000000")
+        emit("s_add_u32 %[k_next], %[k_next], 1")
+        emit("s_and_b32 %[t0], %[k_next], 63")
+        emit("s_cmp_eq_u32 %[t0], 0")
+        emit(f"s_cbranch_scc1 krefill_{tag}_%=")
+        emit(f"kcont_{tag}_%=:")
+        emit("s_and_b32 %[t0], %[k_next], 127")
+        emit("s_lshl_b32 %[t0], %[t0], 4")
+        emit("s_add_u32 %[t0], %[t0], %[kring]")
+        emit(f"v_mov_b32 {v(TMP)}, %[t0]")
+        emit(f"v_cvt_f64_f32 {vp(T['c0'])}, {v(MF0)}")
+        emit(f"ds_read_b128 {vq(NK)}, {v(TMP)}")
+        sh = SHR
+        U = (T['c1'], T['cs']); L = (T['c0'], T['c1'])
+        D = (Tp['c1'], Tp['cs']) if ml == 'R' else (Tp['c0'], Tp['c1'])
+    else:
+        emit("s_add_u32 %[ll_e], %[ll_e], 1")
+        emit(f"v_mov_b32_dpp {v(SHD)}, {v(MF1)} {DPP_SHR}")
+        emit("s_waitcnt lgkmcnt(1)" if ml == 'R' else "s_waitcnt lgkmcnt(0)")     # incoming event landed
+        emit(f"v_mov_b32_dpp {v(NX)}, {v(X1)} {DPP_SHR}")
+        emit(f"v_mov_b32 {v(X1)}, {v(X0)}")
+        emit("s_lshr_b32 %[mvacc], %[mvacc], 1")
+        emit(f"v_mov_b32 {v(X0)}, {v(NX)}")
+        emit("s_add_u32 %[e_next], %[e_next], 1")
+        emit("s_and_b32 %[t0], %[e_next], 63")
+        emit("s_cmp_eq_u32 %[t0], 0")
+        emit(f"s_cbranch_scc1 erefill_{tag}_%=")
+        emit(f"econt_{tag}_%=:")
+        emit("s_and_b32 %[t0], %[e_next], 127")
+        emit("s_lshl_b32 %[t0], %[t0], 2")
+        emit("s_add_u32 %[t0], %[t0], %[ering]")
+        emit(f"v_mov_b32 {v(TMP)}, %[t0]")
+        emit(f"v_cvt_f64_f32 {vp(T['c0'])}, {v(MF0)}")
+        emit(f"ds_read_b32 {v(NX)}, {v(TMP)}")
+        sh = SHD
+        U = (T['c0'], T['c1']); L = (T['cs'], T['c0'])
+        D = (Tp['c0'], Tp['c1']) if ml == 'R' else (Tp['cs'], Tp['c0'])
+    # exact doubles of the previous band's scores (c0 issued above)
+    emit(f"v_cvt_f64_f32 {vp(T['c1'])}, {v(MF1)}")
+    emit(f"v_cvt_f64_f32 {vp(T['cs'])}, {v(sh)}")
+    ops0 = cell_ops(0, D[0], U[0], L[0]); ops1 = cell_ops(1, D[1], U[1], L[1])
+    # split off the two trailing from-code selects of each cell: they go after the next band's decision
+    # reads have been issued (hides the v_readlane / v_cmp -> SALU latency)
+    tail0, tail1 = ops0[-2:], ops1[-2:]
+    for ins in interleave(ops0[:-3], ops1[:-3]):         # drops the s_nop as well
+        emit(ins)
+    emit(f"v_readlane_b32 %[t0], {v(MF0)}, 0")          # mf0 was written 2 instructions ago
+    emit(tail0[0]); emit(tail1[0])
+    emit(f"v_cmp_lt_f32 vcc, %[t0], {v(MF1)}")          # t0 written 3 instructions ago
+    emit(tail0[1]); emit(tail1[1])
+    # trace nibble: newest band in the top nibble
+    emit(f"v_lshl_or_b32 {v(F[0])}, {v(F[1])}, 2, {v(F[0])}")
+    emit("s_and_b32 %[t1], %[b], 7")
+    emit(f"v_alignbit_b32 {v(ACC)}, {v(F[0])}, {v(ACC)}, 4")
+    emit("s_cmp_eq_u32 %[t1], 7")
+    emit(f"s_cbranch_scc1 rot_{tag}_%=")                 # every 8th band, out of line
+    emit(f"rotret_{tag}_%=:")
+    emit("s_add_u32 %[b], %[b], 1")
+    emit("s_sub_u32 %[run], %[run], 1")
+    lbl = decide(p ^ 1, m)
+    llinf_block(lbl, p ^ 1, m)
+    # ---- out-of-line: dword rotation / group store
+    emit(f"rot_{tag}_%=:")
+    emit("s_and_b32 %[t1], %[b], 31")
+    emit("s_cmp_lg_u32 %[t1], 31")
+    emit(f"s_cbranch_scc1 nostore_{tag}_%=")
+    emit(f"v_mov_b32 {v(Q)}, %[mvacc]")
+    emit(f"v_mov_b32 {v(Q+1)}, %[mvprev]")
+    emit(f"v_mov_b32 {v(Q+2)}, {v(A2)}")
+    emit(f"v_mov_b32 {v(Q+3)}, {v(ACC)}")
+    emit(f"v_cndmask_b32 {v(Q)}, {v(A0)}, {v(Q)}, %[m50]")
+    emit(f"v_cndmask_b32 {v(Q+1)}, {v(A1)}, {v(Q+1)}, %[m50]")
+    emit("s_nop 1")
+    emit(f"global_store_dwordx4 {v(TOFF)}, {vq(Q)}, %[trace]")
+    emit("s_nop 1")                                       # store data registers are rewritten by the next band
+    emit(f"v_add_u32 {v(TOFF)}, 0x400, {v(TOFF)}")
+    emit("s_mov_b32 %[mvprev], %[mvacc]")
+    emit(f"nostore_{tag}_%=:")
+    emit(f"v_mov_b32 {v(A0)}, {v(A1)}")
+    emit(f"v_mov_b32 {v(A1)}, {v(A2)}")
+    emit(f"v_mov_b32 {v(A2)}, {v(ACC)}")
+    emit(f"s_branch rotret_{tag}_%=")
+    # ---- out-of-line: ring refills
+    if m == 'R':
+        emit(f"krefill_{tag}_%=:")                       # entering chunk c = k_next >> 6: land chunk c+1, fetch c+2
+        emit("s_waitcnt vmcnt(0)")
+        emit("s_lshr_b32 %[t0], %[k_next], 6")
+        emit("s_add_u32 %[t1], %[t0], 1")
+        emit("s_and_b32 %[t1], %[t1], 1")
+        emit("s_lshl_b32 %[t1], %[t1], 10")
+        emit("s_add_u32 %[t1], %[t1], %[kring]")
+        emit(f"v_lshl_add_u32 {v(TMP)}, {v(LANE)}, 4, %[t1]")
+        emit("s_nop 1")
+        emit(f"ds_write_b128 {v(TMP)}, {vq(KPEND)}")
+        emit("s_add_u32 %[t0], %[t0], 2")
+        emit("s_lshl_b32 %[t0], %[t0], 6")
+        emit(f"v_add_u32 {v(TMP)}, %[t0], {v(LANE)}")
+        emit(f"v_min_i32 {v(TMP)}, %[Km1], {v(TMP)}")
+        emit(f"v_lshlrev_b32 {v(TMP)}, 4, {v(TMP)}")
+        emit("s_waitcnt lgkmcnt(0)")
+        emit("s_nop 1")
+        emit(f"global_load_dwordx4 {vq(KPEND)}, {v(TMP)}, %[kpar]")
+        emit(f"s_branch kcont_{tag}_%=")
+    else:
+        emit(f"erefill_{tag}_%=:")
+        emit("s_waitcnt vmcnt(0)")
+        emit("s_lshr_b32 %[t0], %[e_next], 6")
+        emit("s_add_u32 %[t1], %[t0], 1")
+        emit("s_and_b32 %[t1], %[t1], 1")
+        emit("s_lshl_b32 %[t1], %[t1], 8")
+        emit("s_add_u32 %[t1], %[t1], %[ering]")
+        emit(f"v_lshl_add_u32 {v(TMP)}, {v(LANE)}, 2, %[t1]")
+        emit("s_nop 1")
+        emit(f"ds_write_b32 {v(TMP)}, {v(EPEND)}")
+        emit("s_add_u32 %[t0], %[t0], 2")
+        emit("s_lshl_b32 %[t0], %[t0], 6")
+        emit(f"v_add_u32 {v(TMP)}, %[t0], {v(LANE)}")
+        emit(f"v_min_i32 {v(TMP)}, %[Em1], {v(TMP)}")
+        emit(f"v_lshlrev_b32 {v(TMP)}, 2, {v(TMP)}")
+        emit("s_waitcnt lgkmcnt(0)")
+        emit("s_nop 1")
+        emit(f"global_load_dword {v(EPEND)}, {v(TMP)}, %[evm]")
+        emit(f"s_branch econt_{tag}_%=")
+
+
+def exit_stub(p, ml):
+    tag = f"{p}{ml}"
+    Tl = TR[p ^ 1]
+    emit(f"exit_{tag}_%=:")
+    if ml == 'R':
+        mv = [("L0", Tl['c0']), ("L1", Tl['c1']), ("U0", Tl['c1']), ("U1", Tl['cs'])]
+    else:
+        mv = [("U0", Tl['c0']), ("U1", Tl['c1']), ("L0", Tl['cs']), ("L1", Tl['c0'])]
+    for name, reg in mv:
+        emit(f"v_mov_b64 %[{name}], {vp(reg)}")
+    emit("s_branch done_%=")
+
+
+def main():
+    # ---- entry: operands -> fixed registers
+    ent = [
+        (MF0, "Pf0"), (MF1, "Pf1"), (X0, "x0"), (X1, "x1"), (G0, "g0"), (C0, "c0"), (G1, "g1"), (C1, "c1"),
+        (NK, "nkg"), (NK + 1, "nkc"), (NX, "nx"), (EPEND, "e_pend"), (KPEND, "kpg"), (KPEND + 1, "kpc"),
+        (A0, "a1"), (A1, "a2"), (A2, "a3"), (ACC, "acc"), (TOFF, "toff"), (LANE, "lane"),
+    ]
+    for reg, name in ent:
+        emit(f"v_mov_b32 {v(reg)}, %[{name}]")
+    for reg, name in [(I0, "i0"), (I1, "i1"), (NK + 2, "nki"), (KPEND + 2, "kpi"),
+                      (TR[1]['c0'], "L0"), (TR[1]['c1'], "L1"), (TR[1]['cs'], "U1")]:
+        emit(f"v_mov_b64 {vp(reg)}, %[{name}]")
+    emit(f"v_mov_b32 {v(NINF)}, 0xff800000")
+    emit(f"v_mov_b32 {v(SHR)}, 0xff800000")
+    emit(f"v_mov_b32 {v(SHD)}, 0xff800000")
+    emit("s_nop 1")
+    emit(f"v_readlane_b32 %[t0], {v(MF0)}, 0")
+    emit("s_nop 1")
+    emit(f"v_cmp_lt_f32 vcc, %[t0], {v(MF1)}")
+    lbl = decide(0, 'R')
+    llinf_block(lbl, 0, 'R')
+    for p in (0, 1):
+        for ml in "RD":
+            for m in "RD":
+                body(p, ml, m)
+    for p in (0, 1):
+        for ml in "RD":
+            exit_stub(p, ml)
+    # ---- exit: fixed registers -> operands
+    emit("done_%=:")
+    emit("s_waitcnt vmcnt(0) lgkmcnt(0)")
+    for reg, name in ent:
+        if name in ("lane",):
+            continue
+        emit(f"v_mov_b32 %[{name}], {v(reg)}")
+    for reg, name in [(I0, "i0"), (I1, "i1"), (NK + 2, "nki"), (KPEND + 2, "kpi")]:
+        emit(f"v_mov_b64 %[{name}], {vp(reg)}")
+    emit("s_nop 1")
+
+    text = "\n".join(f'    "{ln}\\n\\t"' for ln in out)
+    clob = ", ".join(f'"v{i}"' for i in range(VB, VEND))
+    inc = f"""/* GENERATED by tools/gen_fill_asm.py — do not edit. See that file for the register map and hazards. */
+#define ABEA_FILL_INTERIOR_ASM \\
+{text.replace(chr(10), " " + chr(92) + chr(10))}
+#define ABEA_FILL_INTERIOR_CLOBBERS {clob}, "vcc", "scc", "memory"
+"""
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "f5c_amd", "csrc",
+                        "abea_fill_interior.inc")
+    open(path, "w").write(inc)
+    print(f"wrote {path}: {len(out)} asm lines")
+
+
+if __name__ == "__main__":
+    main()
