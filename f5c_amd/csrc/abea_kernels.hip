@@ -158,7 +158,7 @@ static __device__ __forceinline__ void abea_cell(float x, float gpm, float ck, d
  *   down move: left = P[o-1], up = P[o], diag = previous band's left.
  * Trace layout (per read): per 32 bands one uint4 per lane = 128 bits, band (b & 31) at bits
  *   [4*(b&31), 4*(b&31)+4) = {from(o0) | from(o1) << 2}.  Lane 50 instead carries the band moves:
- *   .x = move bits of this group (bit b&31, 1 = right), .y = move bits of the group below. */
+ *   .x = move bits of this group (bit 31-(b&31), 1 = right), .y = move bits of the group below. */
 
 static __device__ __forceinline__ int wave_excl_scan(int v, int lane, int& total) {
     int s = v;
@@ -286,7 +286,7 @@ void abea_align_kernel(const abea_read_desc* __restrict__ descs,
             nL0 = P0; nL1 = P1;
             nU0 = P1; nU1 = dpp_from_upper_d((double)NINF, P0);
             D0 = U0; D1 = U1;
-            mvacc = (mvacc >> 1) | 0x80000000u;
+            mvacc = (mvacc << 1) | 1u;
         } else {
             ll_e += 1;
             const float tx = dpp_from_lower_f(nx, x1);  /* lane 0 keeps nx = event ll_e */
@@ -302,7 +302,7 @@ void abea_align_kernel(const abea_read_desc* __restrict__ descs,
             nU0 = P0; nU1 = P1;
             nL1 = P0; nL0 = dpp_from_lower_d((double)NINF, P1);
             D0 = L0; D1 = L1;
-            mvacc = mvacc >> 1;
+            mvacc = mvacc << 1;
         }
 
         /* ---- cells (align.c:337-409) ---- */
@@ -371,15 +371,19 @@ void abea_align_kernel(const abea_read_desc* __restrict__ descs,
             /* hand-scheduled interior loop (tools/gen_fill_asm.py): same semantics as step(false) x run */
             uint32_t toff = (uint32_t)lane * 16u + (uint32_t)(b >> 5) * 1024u;
             uint32_t t0, t1; uint64_t cm0a, cm0b, cm1a, cm1b;
+            const uint32_t kring_a = (uint32_t)(uintptr_t)k_ring, ering_a = (uint32_t)(uintptr_t)e_ring;
             /* "s" operands must be provably wave-uniform */
-            int s_ll_e = uni(ll_e), s_ll_k = uni(ll_k), s_e_next = uni(e_next), s_k_next = uni(k_next);
-            int s_b = uni(b), s_run = uni(run);
+            int s_ll_e = uni(ll_e), s_ll_k = uni(ll_k);
+            int s_b = uni(b);
+            const int s_b_end = uni(b + run);
+            uint32_t s_k_addr = (uint32_t)uni((int)(kring_a + ((uint32_t)k_next & 127u) * 16u));
+            uint32_t s_e_addr = (uint32_t)uni((int)(ering_a + ((uint32_t)e_next & 127u) * 4u));
+            if ((kring_a & 4095u) != 0u || (ering_a & 1023u) != 0u) __builtin_trap();   /* ring wrap uses s_bitset0 */
             uint32_t s_mvacc = (uint32_t)uni((int)mvacc), s_mvprev = (uint32_t)uni((int)mvprev);
             const double u_step = uni_d(lp_step), u_stay = uni_d(lp_stay), u_skip = uni_d(lp_skip);
             const float* u_evm = (const float*)uni_p(evm);
             const abea_kpar_t* u_kpar = (const abea_kpar_t*)uni_p(kpar);
             uint4* u_trace = (uint4*)uni_p(trace);
-            const uint32_t kring_a = (uint32_t)(uintptr_t)k_ring, ering_a = (uint32_t)(uintptr_t)e_ring;
             const int Km1 = K - 1, Em1 = E - 1;
             const uint64_t hi_mask = 0xFFFC000000000000ull, m50 = 1ull << ABEA_MOVE_LANE;
             asm volatile(ABEA_FILL_INTERIOR_ASM
@@ -390,15 +394,15 @@ void abea_align_kernel(const abea_read_desc* __restrict__ descs,
                   [acc] "+v"(acc), [toff] "+v"(toff),
                   [i0] "+v"(i0), [i1] "+v"(i1), [nki] "+v"(nki), [kpi] "+v"(kpi),
                   [L0] "+v"(L0), [L1] "+v"(L1), [U0] "+v"(U0), [U1] "+v"(U1),
-                  [ll_e] "+s"(s_ll_e), [ll_k] "+s"(s_ll_k), [e_next] "+s"(s_e_next), [k_next] "+s"(s_k_next),
-                  [mvacc] "+s"(s_mvacc), [mvprev] "+s"(s_mvprev), [b] "+s"(s_b), [run] "+s"(s_run),
+                  [ll_e] "+s"(s_ll_e), [ll_k] "+s"(s_ll_k), [e_addr] "+s"(s_e_addr), [k_addr] "+s"(s_k_addr),
+                  [mvacc] "+s"(s_mvacc), [mvprev] "+s"(s_mvprev), [b] "+s"(s_b),
                   [t0] "=&s"(t0), [t1] "=&s"(t1), [cm0a] "=&s"(cm0a), [cm0b] "=&s"(cm0b),
                   [cm1a] "=&s"(cm1a), [cm1b] "=&s"(cm1b)
                 : [lane] "v"(lane), [lp_step] "s"(u_step), [lp_stay] "s"(u_stay), [lp_skip] "s"(u_skip),
-                  [Km1] "s"(uni(Km1)), [Em1] "s"(uni(Em1)), [kring] "s"(kring_a), [ering] "s"(ering_a),
+                  [Km1] "s"(uni(Km1)), [Em1] "s"(uni(Em1)), [kring] "s"(kring_a), [ering] "s"(ering_a), [b_end] "s"(s_b_end),
                   [hi_mask] "s"(hi_mask), [m50] "s"(m50), [evm] "s"(u_evm), [kpar] "s"(u_kpar), [trace] "s"(u_trace)
                 : ABEA_FILL_INTERIOR_CLOBBERS);
-            ll_e = s_ll_e; ll_k = s_ll_k; e_next = s_e_next; k_next = s_k_next; b = s_b; run = s_run;
+            ll_e = s_ll_e; ll_k = s_ll_k; e_next = ll_e + 1; k_next = ll_k + 128; b = s_b; run = 0;
             mvacc = s_mvacc; mvprev = s_mvprev;
             P0 = (double)Pf0; P1 = (double)Pf1;
 #endif
@@ -434,8 +438,8 @@ void abea_align_kernel(const abea_read_desc* __restrict__ descs,
         while (alive) {                                    /* one iteration per 32-band trace group */
             const int g = b >> 5;
             const uint4 nxg = trace[(size_t)max(g - 1, 0) * 64 + lane];    /* prefetch the group below */
-            const uint64_t mv64 = ((uint64_t)(uint32_t)readlane_i(cw.x, ABEA_MOVE_LANE) << 32) |
-                                  (uint32_t)readlane_i(cw.y, ABEA_MOVE_LANE);
+            const uint64_t mv64 = ((uint64_t)(uint32_t)readlane_i(cw.y, ABEA_MOVE_LANE) << 32) |
+                                  (uint32_t)readlane_i(cw.x, ABEA_MOVE_LANE);
             int lp = -1;
             uint64_t tlo = 0, thi = 0;
             do {
@@ -449,7 +453,7 @@ void abea_align_kernel(const abea_read_desc* __restrict__ descs,
                 const int bp = 4 * bi + 2 * (off & 1);
                 const uint64_t t64 = (bp & 64) ? thi : tlo;
                 const uint32_t from = (uint32_t)(t64 >> (bp & 63)) & 3u;
-                const uint32_t two = (uint32_t)(mv64 >> (31 + bi)) & 3u;   /* bit1 = move(b), bit0 = move(b-1) */
+                const uint32_t two = (uint32_t)(mv64 >> (31 - bi)) & 3u;   /* bit0 = move(b), bit1 = move(b-1) */
                 cwd |= from << ((n & 15) << 1);
                 ++n;
                 if ((n & 15) == 0) {
@@ -463,7 +467,7 @@ void abea_align_kernel(const abea_read_desc* __restrict__ descs,
                 const int dk = (int)((from & 1u) ^ 1u);    /* D,L step the k-mer */
                 const int de = (int)(isL ^ 1u);            /* D,U step the event */
                 k -= dk; e -= de; b -= dk + de;
-                llk -= (int)(two >> 1) + (int)(two & (notD ^ 1u));
+                llk -= (int)(two & 1u) + (int)((two >> 1) & (notD ^ 1u));
                 gap = isL ? gap + 1 : 0;
                 max_gap = max(max_gap, gap);
                 alive = (k | e) >= 0;

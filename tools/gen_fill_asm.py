@@ -127,13 +127,13 @@ def decide(p_next, m_last):
     """Tail of a band (or the entry stub): pick the move of the NEXT band and jump to its body.
     Expects: %[t0] = readlane(mf0, lane 0) already issued, vcc = (t0 < mf1) per lane already issued."""
     tag = f"{p_next}{m_last}"
-    emit("s_cmp_eq_u32 %[run], 0")
+    emit("s_cmp_eq_u32 %[b], %[b_end]")
     emit(f"s_cbranch_scc1 exit_{tag}_%=")
-    emit("s_cmp_eq_u32 %[t0], 0xff800000")
+    emit("s_bitcmp1_b32 vcc_hi, 17")                     # lane 49: ll < ur  -> right (align.c:313); -inf < finite too
+    emit(f"s_cbranch_scc1 body_{tag}R_%=")
+    emit("s_cmp_eq_u32 %[t0], 0xff800000")               # not (ll < ur): both may be -inf
     emit(f"s_cbranch_scc1 llinf_{tag}_{newid()}_%=")
     lbl = f"llinf_{tag}_{lbl_id[0]}_%="
-    emit("s_bitcmp1_b32 vcc_hi, 17")                     # lane 49: ll < ur  -> right (align.c:313)
-    emit(f"s_cbranch_scc1 body_{tag}R_%=")
     emit(f"s_branch body_{tag}D_%=")
     return lbl
 
@@ -166,17 +166,13 @@ def body(p, ml, m):
         emit(f"v_mov_b64 {vp(I0)}, {vp(I1)}")
         emit(f"v_mov_b64 {vp(G1)}, {vp(NK)}")
         emit(f"v_mov_b64 {vp(I1)}, {vp(NK+2)}")
-        emit("s_lshr_b32 %[mvacc], %[mvacc], 1")
-        emit("s_or_b32 %[mvacc], %[mvacc], 0x80000000")
-        emit("s_add_u32 %[k_next], %[k_next], 1")
-        emit("s_and_b32 %[t0], %[k_next], 63")
-        emit("s_cmp_eq_u32 %[t0], 0")
-        emit(f"s_cbranch_scc1 krefill_{tag}_%=")
+        emit("s_lshl1_add_u32 %[mvacc], %[mvacc], 1")       # band-move bits, oldest band in the top bit
+        emit("s_add_u32 %[k_addr], %[k_addr], 16")          # LDS address of the next incoming k-mer (2 KiB ring at 0)
+        emit("s_bitset0_b32 %[k_addr], 11")
+        emit("s_and_b32 %[t0], %[k_addr], 1023")            # entering a new 64-entry chunk?
+        emit(f"s_cbranch_scc0 krefill_{tag}_%=")
         emit(f"kcont_{tag}_%=:")
-        emit("s_and_b32 %[t0], %[k_next], 127")
-        emit("s_lshl_b32 %[t0], %[t0], 4")
-        emit("s_add_u32 %[t0], %[t0], %[kring]")
-        emit(f"v_mov_b32 {v(TMP)}, %[t0]")
+        emit(f"v_mov_b32 {v(TMP)}, %[k_addr]")
         emit(f"v_cvt_f64_f32 {vp(T['c0'])}, {v(MF0)}")
         emit(f"ds_read_b128 {vq(NK)}, {v(TMP)}")
         sh = SHR
@@ -188,17 +184,14 @@ def body(p, ml, m):
         emit("s_waitcnt lgkmcnt(1)" if ml == 'R' else "s_waitcnt lgkmcnt(0)")     # incoming event landed
         emit(f"v_mov_b32_dpp {v(NX)}, {v(X1)} {DPP_SHR}")
         emit(f"v_mov_b32 {v(X1)}, {v(X0)}")
-        emit("s_lshr_b32 %[mvacc], %[mvacc], 1")
+        emit("s_lshl_b32 %[mvacc], %[mvacc], 1")
         emit(f"v_mov_b32 {v(X0)}, {v(NX)}")
-        emit("s_add_u32 %[e_next], %[e_next], 1")
-        emit("s_and_b32 %[t0], %[e_next], 63")
-        emit("s_cmp_eq_u32 %[t0], 0")
-        emit(f"s_cbranch_scc1 erefill_{tag}_%=")
+        emit("s_add_u32 %[e_addr], %[e_addr], 4")           # LDS address of the next incoming event (512 B ring at 2048)
+        emit("s_bitset0_b32 %[e_addr], 9")
+        emit("s_and_b32 %[t0], %[e_addr], 255")
+        emit(f"s_cbranch_scc0 erefill_{tag}_%=")
         emit(f"econt_{tag}_%=:")
-        emit("s_and_b32 %[t0], %[e_next], 127")
-        emit("s_lshl_b32 %[t0], %[t0], 2")
-        emit("s_add_u32 %[t0], %[t0], %[ering]")
-        emit(f"v_mov_b32 {v(TMP)}, %[t0]")
+        emit(f"v_mov_b32 {v(TMP)}, %[e_addr]")
         emit(f"v_cvt_f64_f32 {vp(T['c0'])}, {v(MF0)}")
         emit(f"ds_read_b32 {v(NX)}, {v(TMP)}")
         sh = SHD
@@ -219,20 +212,17 @@ def body(p, ml, m):
     emit(tail0[1]); emit(tail1[1])
     # trace nibble: newest band in the top nibble
     emit(f"v_lshl_or_b32 {v(F[0])}, {v(F[1])}, 2, {v(F[0])}")
-    emit("s_and_b32 %[t1], %[b], 7")
-    emit(f"v_alignbit_b32 {v(ACC)}, {v(F[0])}, {v(ACC)}, 4")
-    emit("s_cmp_eq_u32 %[t1], 7")
-    emit(f"s_cbranch_scc1 rot_{tag}_%=")                 # every 8th band, out of line
-    emit(f"rotret_{tag}_%=:")
     emit("s_add_u32 %[b], %[b], 1")
-    emit("s_sub_u32 %[run], %[run], 1")
+    emit(f"v_alignbit_b32 {v(ACC)}, {v(F[0])}, {v(ACC)}, 4")
+    emit("s_and_b32 %[t1], %[b], 7")
+    emit(f"s_cbranch_scc0 rot_{tag}_%=")                 # band b-1 completed a dword: every 8th band, out of line
+    emit(f"rotret_{tag}_%=:")
     lbl = decide(p ^ 1, m)
     llinf_block(lbl, p ^ 1, m)
     # ---- out-of-line: dword rotation / group store
     emit(f"rot_{tag}_%=:")
     emit("s_and_b32 %[t1], %[b], 31")
-    emit("s_cmp_lg_u32 %[t1], 31")
-    emit(f"s_cbranch_scc1 nostore_{tag}_%=")
+    emit(f"s_cbranch_scc1 nostore_{tag}_%=")             # group complete only when the new b is a multiple of 32
     emit(f"v_mov_b32 {v(Q)}, %[mvacc]")
     emit(f"v_mov_b32 {v(Q+1)}, %[mvprev]")
     emit(f"v_mov_b32 {v(Q+2)}, {v(A2)}")
@@ -253,7 +243,8 @@ def body(p, ml, m):
     if m == 'R':
         emit(f"krefill_{tag}_%=:")                       # entering chunk c = k_next >> 6: land chunk c+1, fetch c+2
         emit("s_waitcnt vmcnt(0)")
-        emit("s_lshr_b32 %[t0], %[k_next], 6")
+        emit("s_add_u32 %[t0], %[ll_k], 128")               # k_next = ll_k + 128 (k-mer entering at offset 127)
+        emit("s_lshr_b32 %[t0], %[t0], 6")
         emit("s_add_u32 %[t1], %[t0], 1")
         emit("s_and_b32 %[t1], %[t1], 1")
         emit("s_lshl_b32 %[t1], %[t1], 10")
@@ -273,7 +264,8 @@ def body(p, ml, m):
     else:
         emit(f"erefill_{tag}_%=:")
         emit("s_waitcnt vmcnt(0)")
-        emit("s_lshr_b32 %[t0], %[e_next], 6")
+        emit("s_add_u32 %[t0], %[ll_e], 1")                 # e_next = ll_e + 1 (event entering at offset 0)
+        emit("s_lshr_b32 %[t0], %[t0], 6")
         emit("s_add_u32 %[t1], %[t0], 1")
         emit("s_and_b32 %[t1], %[t1], 1")
         emit("s_lshl_b32 %[t1], %[t1], 8")
