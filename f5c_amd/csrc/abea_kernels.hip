@@ -18,6 +18,7 @@
 #include <type_traits>
 #include "abea_device.h"
 #include "abea_fill_interior.inc"
+#include "abea_walk.inc"
 
 #define NINF (-__builtin_inff())
 
@@ -428,6 +429,7 @@ void abea_align_kernel(const abea_read_desc* __restrict__ descs,
      * in 4 VGPRs (one uint4 per lane); the 128 bits of the lane pair the path is in are held in SGPRs,
      * so a step is pure SALU bit picking; v_readlane only when the path changes lane pair or group.
      * Each step emits a 2-bit code; 16 codes -> one dword, 64 dwords -> one coalesced store. */
+#ifdef ABEA_NO_ASM
     int e = best_e, k = K - 1, llk = best_llk;
     int n = 0, gap = 0, max_gap = 0, last_k = k;
     uint32_t cwd = 0, cv = 0;
@@ -475,6 +477,23 @@ void abea_align_kernel(const abea_read_desc* __restrict__ descs,
             cw = nxg;
         }
     }
+#else
+    /* hand-written scalar walk (tools/gen_fill_asm.py: gen_walk), same semantics as the loop above */
+    int n, max_gap, last_k;
+    uint32_t cwd, cv;
+    {
+        uint32_t o_sh2, o_nfl;
+        const uint4* u_trace = (const uint4*)uni_p(trace);
+        uint32_t* u_codes = (uint32_t*)uni_p(codes);
+        asm volatile(ABEA_WALK_ASM
+            : [last_k] "=&s"(last_k), [o_cwd] "=&s"(cwd), [o_sh2] "=&s"(o_sh2), [o_nfl] "=&s"(o_nfl),
+              [o_maxgap] "=&s"(max_gap), [o_cv] "=&v"(cv)
+            : [k0] "s"(uni(K - 1)), [e0] "s"(uni(best_e)), [llk0] "s"(uni(best_llk)),
+              [trace] "s"(u_trace), [codes] "s"(u_codes), [lane] "v"(lane)
+            : ABEA_WALK_CLOBBERS);
+        n = (int)(o_nfl * 16u + o_sh2 / 2u);
+    }
+#endif
     if ((n & 15) != 0 && lane == ((n >> 4) & 63)) cv = cwd;
     if ((n & 1023) != 0 && lane <= (((n - 1) >> 4) & 63)) codes[(size_t)(n >> 10) * 64 + lane] = cv;
     __syncthreads();                                     /* this wave's code words -> all its lanes */

@@ -351,3 +351,118 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+# =====================================================================================================
+# Traceback walk (align.c:452-499) on the scalar unit: one inline-asm statement, ~40 SALU per step.
+# Fixed SGPRs s76..s99, VGPRs v64..v75 (the fill statement's range; the two statements never overlap).
+# =====================================================================================================
+def gen_walk():
+    o = []
+    e = o.append
+    K, E, BI, LLK, G, GAP, MAXGAP, CWD, SH2, NFL, LP, DK = (f"s{i}" for i in range(76, 88))
+    TLO, THI, MV, T64 = "s[88:89]", "s[90:91]", "s[92:93]", "s[94:95]"
+    T64LO = "s94"
+    T, U, X, Y = "s96", "s97", "s98", "s99"
+    CW = [f"v{i}" for i in range(64, 68)]      # current 32-band trace group: one uint4 per lane
+    NXG = [f"v{i}" for i in range(68, 72)]     # prefetched group below
+    CV, VT, L16, L4 = "v72", "v73", "v74", "v75"
+    # ---- entry
+    e(f"s_mov_b32 {K}, %[k0]"); e(f"s_mov_b32 {E}, %[e0]"); e(f"s_mov_b32 {LLK}, %[llk0]")
+    e(f"s_add_u32 {T}, {K}, {E}"); e(f"s_add_u32 {T}, {T}, 2")           # b = e + k + 2
+    e(f"s_lshr_b32 {G}, {T}, 5"); e(f"s_and_b32 {BI}, {T}, 31")
+    for r in (GAP, MAXGAP, CWD, SH2, NFL, DK):
+        e(f"s_mov_b32 {r}, 0")
+    e(f"v_mov_b32 {CV}, 0")
+    e(f"v_lshlrev_b32 {L16}, 4, %[lane]"); e(f"v_lshlrev_b32 {L4}, 2, %[lane]")
+    e(f"s_lshl_b32 {T}, {G}, 10")
+    e(f"global_load_dwordx4 v[64:67], {L16}, %[trace]")                    # placeholder, patched below with soffset add
+    o.pop()
+    # 64-bit base + (g << 10): trace groups are 1 KiB
+    e(f"s_mov_b64 {T64}, %[trace]"); e(f"s_add_u32 s94, s94, {T}"); e("s_addc_u32 s95, s95, 0")
+    e(f"global_load_dwordx4 v[64:67], {L16}, {T64}")
+    e("group_top_%=:")
+    e(f"s_max_i32 {T}, {G}, 1"); e(f"s_sub_u32 {T}, {T}, 1"); e(f"s_lshl_b32 {T}, {T}, 10")
+    e(f"s_mov_b64 {T64}, %[trace]"); e(f"s_add_u32 s94, s94, {T}"); e("s_addc_u32 s95, s95, 0")
+    e(f"global_load_dwordx4 v[68:71], {L16}, {T64}")                       # prefetch the group below
+    e("s_waitcnt vmcnt(1)")                                                 # the current group has landed
+    e(f"v_readlane_b32 s92, {CW[0]}, 50")                                  # band moves of this group ...
+    e(f"v_readlane_b32 s93, {CW[1]}, 50")                                  # ... and of the group below
+    e(f"s_mov_b32 {LP}, -1")
+    e("step_%=:")
+    e(f"s_sub_u32 {T}, {K}, {LLK}")                                         # band offset of (e,k)
+    e(f"s_lshr_b32 {U}, {T}, 1")
+    e(f"s_cmp_eq_u32 {U}, {LP}")
+    e("s_cbranch_scc0 reload_lp_%=")
+    e("step_cont_%=:")
+    e(f"s_and_b32 {T}, {T}, 1"); e(f"s_lshl_b32 {T}, {T}, 1"); e(f"s_lshl2_add_u32 {T}, {BI}, {T}")   # bit position
+    e(f"s_bitcmp1_b32 {T}, 6")
+    e(f"s_cselect_b64 {T64}, {THI}, {TLO}")
+    e(f"s_lshr_b64 {T64}, {T64}, {T}")
+    e(f"s_and_b32 {U}, {T64LO}, 3")                                        # from code: 0 D, 1 U, 2 L
+    e(f"s_sub_u32 {T}, 31, {BI}")
+    e(f"s_lshr_b64 {T64}, {MV}, {T}")
+    e(f"s_and_b32 {T}, {T64LO}, 3")                                        # bit0 = move(b), bit1 = move(b-1)
+    e(f"s_lshl_b32 {X}, {U}, {SH2}"); e(f"s_or_b32 {CWD}, {CWD}, {X}"); e(f"s_add_u32 {SH2}, {SH2}, 2")
+    e(f"s_bitcmp1_b32 {SH2}, 5")
+    e("s_cbranch_scc1 flush_%=")
+    e("flush_ret_%=:")
+    e(f"s_and_b32 {DK}, {U}, 1"); e(f"s_xor_b32 {DK}, {DK}, 1")            # D,L step the k-mer
+    e(f"s_lshr_b32 {X}, {U}, 1")                                           # isL
+    e(f"s_xor_b32 {Y}, {X}, 1")                                            # de: D,U step the event
+    e(f"s_add_u32 {GAP}, {GAP}, 1"); e(f"s_cmp_eq_u32 {X}, 0"); e(f"s_cselect_b32 {GAP}, 0, {GAP}")
+    e(f"s_max_i32 {MAXGAP}, {MAXGAP}, {GAP}")
+    e(f"s_and_b32 {U}, {DK}, {Y}")                                         # isD
+    e(f"s_lshr_b32 {X}, {T}, 1"); e(f"s_and_b32 {X}, {X}, {U}")            # move(b-1) counts only on a diagonal step
+    e(f"s_and_b32 {T}, {T}, 1"); e(f"s_add_u32 {T}, {T}, {X}")
+    e(f"s_sub_u32 {LLK}, {LLK}, {T}")
+    e(f"s_sub_u32 {K}, {K}, {DK}"); e("s_cbranch_scc1 done_%=")            # borrow: ran off k-mer 0
+    e(f"s_sub_u32 {E}, {E}, {Y}"); e("s_cbranch_scc1 done_%=")             # borrow: ran off event 0
+    e(f"s_add_u32 {T}, {DK}, {Y}")
+    e(f"s_sub_u32 {BI}, {BI}, {T}")
+    e("s_cbranch_scc0 step_%=")                                            # no borrow: still in this 32-band group
+    e(f"s_add_u32 {BI}, {BI}, 32"); e(f"s_sub_u32 {G}, {G}, 1")
+    e("s_waitcnt vmcnt(0)")
+    for a, b in zip(CW, NXG):
+        e(f"v_mov_b32 {a}, {b}")
+    e("s_branch group_top_%=")
+    # ---- out of line
+    e("reload_lp_%=:")
+    e(f"s_mov_b32 {LP}, {U}")
+    e(f"v_readlane_b32 s88, {CW[0]}, {U}"); e(f"v_readlane_b32 s89, {CW[1]}, {U}")
+    e(f"v_readlane_b32 s90, {CW[2]}, {U}"); e(f"v_readlane_b32 s91, {CW[3]}, {U}")
+    e("s_branch step_cont_%=")
+    e("flush_%=:")                                                          # 16 codes complete: dword nfl -> lane nfl & 63
+    e(f"s_and_b32 {X}, {NFL}, 63")
+    e(f"v_cmp_eq_u32 vcc, {X}, %[lane]")
+    e(f"v_mov_b32 {VT}, {CWD}")
+    e(f"s_mov_b32 {CWD}, 0"); e(f"s_mov_b32 {SH2}, 0")
+    e(f"v_cndmask_b32 {CV}, {CV}, {VT}, vcc")
+    e(f"s_add_u32 {NFL}, {NFL}, 1")
+    e(f"s_and_b32 {X}, {NFL}, 63")
+    e("s_cbranch_scc1 flush_ret_%=")
+    e(f"s_sub_u32 {X}, {NFL}, 64"); e(f"s_lshl_b32 {X}, {X}, 2")
+    e(f"v_add_u32 {VT}, {X}, {L4}")
+    e("s_nop 1")
+    e(f"global_store_dword {VT}, {CV}, %[codes]")
+    e("s_branch flush_ret_%=")
+    e("done_%=:")
+    e("s_waitcnt vmcnt(0)")
+    e(f"s_add_u32 %[last_k], {K}, {DK}")
+    e(f"s_mov_b32 %[o_cwd], {CWD}"); e(f"s_mov_b32 %[o_sh2], {SH2}"); e(f"s_mov_b32 %[o_nfl], {NFL}")
+    e(f"s_mov_b32 %[o_maxgap], {MAXGAP}")
+    e(f"v_mov_b32 %[o_cv], {CV}")
+    text = "\n".join(f'    "{ln}\\n\\t"' for ln in o)
+    clob = ", ".join([f'"s{i}"' for i in range(76, 100)] + [f'"v{i}"' for i in range(64, 76)])
+    inc = f"""/* GENERATED by tools/gen_fill_asm.py — do not edit. Scalar-unit traceback walk. */
+#define ABEA_WALK_ASM \\
+{text.replace(chr(10), " " + chr(92) + chr(10))}
+#define ABEA_WALK_CLOBBERS {clob}, "vcc", "scc", "memory"
+"""
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "f5c_amd", "csrc", "abea_walk.inc")
+    open(path, "w").write(inc)
+    print(f"wrote {path}: {len(o)} asm lines")
+
+
+if __name__ == "__main__":
+    gen_walk()
