@@ -17,7 +17,7 @@
 #include <hip/hip_runtime.h>
 #include <type_traits>
 #include "abea_device.h"
-#include "abea_fill_interior.inc"
+#include "abea_fill.inc"
 #include "abea_walk.inc"
 
 #define NINF (-__builtin_inff())
@@ -365,44 +365,56 @@ void abea_align_kernel(const abea_read_desc* __restrict__ descs,
         /* bands for which every one of the 100 cells is inside the matrix and neither the trim column
          * nor the last k-mer column can be in band, whatever the moves: one of ll_e / ll_k grows per band */
         int run = min(min(E - 2 - ll_e, K - 102 - ll_k), nb_pad - b);
-        if (ll_k >= 0 && ll_e >= 99 && run > 0) {
 #ifdef ABEA_NO_ASM
+        if (ll_k >= 0 && ll_e >= 99 && run > 0) {
             for (; run > 0; --run) step(std::false_type{});
 #else
-            /* hand-scheduled interior loop (tools/gen_fill_asm.py): same semantics as step(false) x run */
+        if (ll_k >= 0 && ll_e >= 99) {
+            /* hand-scheduled loops (tools/gen_fill_asm.py): same semantics as step(false) x run for the interior
+             * stretch; once the band touches the bottom/right edge of the matrix (run <= 0) the border variant
+             * (validity masks + online end-point scan) runs to the last band */
             uint32_t toff = (uint32_t)lane * 16u + (uint32_t)(b >> 5) * 1024u;
-            uint32_t t0, t1; uint64_t cm0a, cm0b, cm1a, cm1b;
+            uint32_t t0, t1, t2, t3, t4; uint64_t cm0a, cm0b, cm1a, cm1b, cv0, cv1;
             const uint32_t kring_a = (uint32_t)(uintptr_t)k_ring, ering_a = (uint32_t)(uintptr_t)e_ring;
             /* "s" operands must be provably wave-uniform */
             int s_ll_e = uni(ll_e), s_ll_k = uni(ll_k);
             int s_b = uni(b);
-            const int s_b_end = uni(b + run);
+            const bool interior = run > 0;
+            const int s_b_end = interior ? uni(b + run) : uni(nb_pad);
             uint32_t s_k_addr = (uint32_t)uni((int)(kring_a + ((uint32_t)k_next & 127u) * 16u));
             uint32_t s_e_addr = (uint32_t)uni((int)(ering_a + ((uint32_t)e_next & 127u) * 4u));
             if ((kring_a & 4095u) != 0u || (ering_a & 1023u) != 0u) __builtin_trap();   /* ring wrap uses s_bitset0 */
+            const int Km1 = K - 1, Em1 = E - 1;
+            const uint64_t hi_mask = 0xFFFC000000000000ull, m50 = 1ull << ABEA_MOVE_LANE;
             uint32_t s_mvacc = (uint32_t)uni((int)mvacc), s_mvprev = (uint32_t)uni((int)mvprev);
-            const double u_step = uni_d(lp_step), u_stay = uni_d(lp_stay), u_skip = uni_d(lp_skip);
+            const double u_step = uni_d(lp_step), u_stay = uni_d(lp_stay), u_skip = uni_d(lp_skip), u_trim = uni_d(lp_trim);
             const float* u_evm = (const float*)uni_p(evm);
             const abea_kpar_t* u_kpar = (const abea_kpar_t*)uni_p(kpar);
             uint4* u_trace = (uint4*)uni_p(trace);
-            const int Km1 = K - 1, Em1 = E - 1;
-            const uint64_t hi_mask = 0xFFFC000000000000ull, m50 = 1ull << ABEA_MOVE_LANE;
-            asm volatile(ABEA_FILL_INTERIOR_ASM
-                : [Pf0] "+v"(Pf0), [Pf1] "+v"(Pf1), [x0] "+v"(x0), [x1] "+v"(x1),
-                  [g0] "+v"(g0), [c0] "+v"(c0), [g1] "+v"(g1), [c1] "+v"(c1),
-                  [nkg] "+v"(nkg), [nkc] "+v"(nkc), [nx] "+v"(nx), [e_pend] "+v"(e_pend),
-                  [kpg] "+v"(kpg), [kpc] "+v"(kpc), [a1] "+v"(a1), [a2] "+v"(a2), [a3] "+v"(a3),
-                  [acc] "+v"(acc), [toff] "+v"(toff),
-                  [i0] "+v"(i0), [i1] "+v"(i1), [nki] "+v"(nki), [kpi] "+v"(kpi),
-                  [L0] "+v"(L0), [L1] "+v"(L1), [U0] "+v"(U0), [U1] "+v"(U1),
-                  [ll_e] "+s"(s_ll_e), [ll_k] "+s"(s_ll_k), [e_addr] "+s"(s_e_addr), [k_addr] "+s"(s_k_addr),
-                  [mvacc] "+s"(s_mvacc), [mvprev] "+s"(s_mvprev), [b] "+s"(s_b),
-                  [t0] "=&s"(t0), [t1] "=&s"(t1), [cm0a] "=&s"(cm0a), [cm0b] "=&s"(cm0b),
+            uint32_t s_best = (uint32_t)uni((int)__float_as_uint(best));
+            int s_best_e = uni(best_e), s_best_llk = uni(best_llk);
+#define ABEA_FILL_OUTS \
+                  [Pf0] "+v"(Pf0), [Pf1] "+v"(Pf1), [x0] "+v"(x0), [x1] "+v"(x1), \
+                  [g0] "+v"(g0), [c0] "+v"(c0), [g1] "+v"(g1), [c1] "+v"(c1), \
+                  [nkg] "+v"(nkg), [nkc] "+v"(nkc), [nx] "+v"(nx), [e_pend] "+v"(e_pend), \
+                  [kpg] "+v"(kpg), [kpc] "+v"(kpc), [a1] "+v"(a1), [a2] "+v"(a2), [a3] "+v"(a3), \
+                  [acc] "+v"(acc), [toff] "+v"(toff), \
+                  [i0] "+v"(i0), [i1] "+v"(i1), [nki] "+v"(nki), [kpi] "+v"(kpi), \
+                  [L0] "+v"(L0), [L1] "+v"(L1), [U0] "+v"(U0), [U1] "+v"(U1), \
+                  [ll_e] "+s"(s_ll_e), [ll_k] "+s"(s_ll_k), [e_addr] "+s"(s_e_addr), [k_addr] "+s"(s_k_addr), \
+                  [mvacc] "+s"(s_mvacc), [mvprev] "+s"(s_mvprev), [b] "+s"(s_b), \
+                  [t0] "=&s"(t0), [t1] "=&s"(t1), [cm0a] "=&s"(cm0a), [cm0b] "=&s"(cm0b), \
                   [cm1a] "=&s"(cm1a), [cm1b] "=&s"(cm1b)
-                : [lane] "v"(lane), [lp_step] "s"(u_step), [lp_stay] "s"(u_stay), [lp_skip] "s"(u_skip),
-                  [Km1] "s"(uni(Km1)), [Em1] "s"(uni(Em1)), [kring] "s"(kring_a), [ering] "s"(ering_a), [b_end] "s"(s_b_end),
-                  [hi_mask] "s"(hi_mask), [m50] "s"(m50), [evm] "s"(u_evm), [kpar] "s"(u_kpar), [trace] "s"(u_trace)
-                : ABEA_FILL_INTERIOR_CLOBBERS);
+#define ABEA_FILL_INS \
+                  [lane] "v"(lane), [lp_step] "s"(u_step), [lp_stay] "s"(u_stay), [lp_skip] "s"(u_skip), \
+                  [Km1] "s"(uni(Km1)), [Em1] "s"(uni(Em1)), [kring] "s"(kring_a), [ering] "s"(ering_a), \
+                  [b_end] "s"(s_b_end), [m50] "s"(m50), [evm] "s"(u_evm), [kpar] "s"(u_kpar), [trace] "s"(u_trace)
+            asm volatile(ABEA_FILL_ASM
+                : ABEA_FILL_OUTS, [t2] "=&s"(t2), [t3] "=&s"(t3), [t4] "=&s"(t4), [cv0] "=&s"(cv0), [cv1] "=&s"(cv1),
+                  [best] "+s"(s_best), [best_e] "+s"(s_best_e), [best_llk] "+s"(s_best_llk)
+                : ABEA_FILL_INS, [hi_mask] "s"(hi_mask), [lp_trim] "s"(u_trim), [mode] "s"(uni(interior ? 0 : 1))
+                : ABEA_FILL_CLOBBERS);
+            best = __uint_as_float(s_best); best_e = s_best_e; best_llk = s_best_llk;
             ll_e = s_ll_e; ll_k = s_ll_k; e_next = ll_e + 1; k_next = ll_k + 128; b = s_b; run = 0;
             mvacc = s_mvacc; mvprev = s_mvprev;
             P0 = (double)Pf0; P1 = (double)Pf1;

@@ -42,7 +42,9 @@ Q = 106            # store quad v[106:109] aliases the LPD temps (free at the en
 TMP = 118          # 32-bit address temp
 TOFF = 119         # trace store offset (lane*16 + group*1024)
 F = [111, 113]     # from codes: high halves of the TD pairs (free once sd is rounded)
-VEND = 120         # one past the last fixed VGPR
+O0, O1 = 120, 121   # band offsets owned by the lane (border variant only)
+VEND = 122         # one past the last fixed VGPR
+BORDER = False     # generator mode: True adds validity masks + the online end-point scan
 # extra per-cell 32-bit temps reuse the low halves of f64 temps where noted
 
 out = []
@@ -104,7 +106,8 @@ def cell_ops(j, D, U, L):
         f"v_cmp_ge_f32 {cm1}, {v(su)}, {v(sd)}",
         f"v_cmp_eq_f32 {cm2}, {v(sl)}, {v(F[j])}",
         # >= 2 wait states before the masks are read: the mf write and a nop-equivalent come first
-        f"v_cndmask_b32 {v(mf)}, {v(F[j])}, {v(NINF)}, %[hi_mask]",  # lanes >= 50 pinned to -inf
+        (f"v_cndmask_b32 {v(mf)}, {v(NINF)}, {v(F[j])}, %[cv{j}]" if BORDER else       # out-of-matrix cells -> -inf
+         f"v_cndmask_b32 {v(mf)}, {v(F[j])}, {v(NINF)}, %[hi_mask]"),                   # lanes >= 50 pinned to -inf
         "s_nop 0",
         f"v_cndmask_b32 {v(F[j])}, 0, 1, {cm1}",
         f"v_cndmask_b32 {v(F[j])}, {v(F[j])}, 2, {cm2}",
@@ -200,16 +203,67 @@ def body(p, ml, m):
     # exact doubles of the previous band's scores (c0 issued above)
     emit(f"v_cvt_f64_f32 {vp(T['c1'])}, {v(MF1)}")
     emit(f"v_cvt_f64_f32 {vp(T['cs'])}, {v(sh)}")
+    if BORDER:
+        # in-matrix offsets [min_off, max_off) (align.c:337-346 with ll_k >= 0, ll_e >= 99)
+        emit("s_sub_u32 %[t2], %[ll_e], %[Em1]")
+        emit("s_max_i32 %[t2], %[t2], 0")                   # min_off
+        emit("s_sub_u32 %[t3], %[Km1], %[ll_k]")
+        emit("s_add_u32 %[t3], %[t3], 1")
+        emit("s_min_i32 %[t3], %[t3], 100")                 # max_off
+        emit("s_sub_u32 %[t3], %[t3], %[t2]")
+        emit("s_max_i32 %[t3], %[t3], 0")                   # width
+        emit(f"v_subrev_u32 {v(F[0])}, %[t2], {v(O0)}")
+        emit(f"v_subrev_u32 {v(F[1])}, %[t2], {v(O1)}")
+        emit(f"v_cmp_gt_u32 %[cv0], %[t3], {v(F[0])}")
+        emit(f"v_cmp_gt_u32 %[cv1], %[t3], {v(F[1])}")
     ops0 = cell_ops(0, D[0], U[0], L[0]); ops1 = cell_ops(1, D[1], U[1], L[1])
     # split off the two trailing from-code selects of each cell: they go after the next band's decision
     # reads have been issued (hides the v_readlane / v_cmp -> SALU latency)
     tail0, tail1 = ops0[-2:], ops1[-2:]
     for ins in interleave(ops0[:-3], ops1[:-3]):         # drops the s_nop as well
         emit(ins)
-    emit(f"v_readlane_b32 %[t0], {v(MF0)}, 0")          # mf0 was written 2 instructions ago
-    emit(tail0[0]); emit(tail1[0])
-    emit(f"v_cmp_lt_f32 vcc, %[t0], {v(MF1)}")          # t0 written 3 instructions ago
-    emit(tail0[1]); emit(tail1[1])
+    if BORDER:
+        emit("s_nop 0")
+        emit(tail0[0]); emit(tail1[0]); emit(tail0[1]); emit(tail1[1])
+        emit(f"v_cndmask_b32 {v(F[0])}, 0, {v(F[0])}, %[cv0]")     # trace stays 0 outside the matrix (align.c:257)
+        emit(f"v_cndmask_b32 {v(F[1])}, 0, {v(F[1])}, %[cv1]")
+        # ---- online end-point scan (align.c:424-445): cell of the last k-mer, if in band and in range
+        es = f"es_{tag}_%="
+        emit("s_sub_u32 %[t2], %[Km1], %[ll_k]")            # offset of k-mer K-1
+        emit("s_cmp_lt_u32 %[t2], 100")
+        emit(f"s_cbranch_scc0 {es}")
+        emit("s_sub_u32 %[t3], %[ll_e], %[t2]")             # its event
+        emit("s_cmp_le_u32 %[t3], %[Em1]")
+        emit(f"s_cbranch_scc0 {es}")
+        emit("s_lshr_b32 %[t1], %[t2], 1")
+        emit(f"v_readlane_b32 %[t0], {v(MF0)}, %[t1]")
+        emit(f"v_readlane_b32 %[t4], {v(MF1)}, %[t1]")
+        emit("s_bitcmp1_b32 %[t2], 0")
+        emit("s_cselect_b32 %[t0], %[t4], %[t0]")
+        emit("s_sub_u32 %[t4], %[Em1], %[t3]")
+        emit("s_add_u32 %[t4], %[t4], 1")                   # E - e
+        emit(f"v_cvt_f64_u32 {vp(LPD[0])}, %[t4]")
+        emit(f"v_cvt_f64_f32 {vp(LPD[1])}, %[t0]")
+        emit(f"v_mul_f64 {vp(LPD[0])}, {vp(LPD[0])}, %[lp_trim]")
+        emit(f"v_add_f64 {vp(LPD[0])}, {vp(LPD[1])}, {vp(LPD[0])}")
+        emit(f"v_cvt_f32_f64 {v(TMP)}, {vp(LPD[0])}")
+        emit(f"v_mov_b32 {v(LPD[1])}, %[best]")
+        emit("s_nop 0")
+        emit(f"v_cmp_gt_f32 vcc, {v(TMP)}, {v(LPD[1])}")    # strict >: keeps the first maximum (align.c:440)
+        emit("s_and_b64 %[cm0a], vcc, exec")
+        emit(f"s_cbranch_scc0 {es}")
+        emit(f"v_readfirstlane_b32 %[best], {v(TMP)}")
+        emit("s_mov_b32 %[best_e], %[t3]")
+        emit("s_mov_b32 %[best_llk], %[ll_k]")
+        emit(f"{es}:")
+        emit(f"v_readlane_b32 %[t0], {v(MF0)}, 0")
+        emit("s_nop 1")
+        emit(f"v_cmp_lt_f32 vcc, %[t0], {v(MF1)}")
+    else:
+        emit(f"v_readlane_b32 %[t0], {v(MF0)}, 0")          # mf0 was written 2 instructions ago
+        emit(tail0[0]); emit(tail1[0])
+        emit(f"v_cmp_lt_f32 vcc, %[t0], {v(MF1)}")          # t0 written 3 instructions ago
+        emit(tail0[1]); emit(tail1[1])
     # trace nibble: newest band in the top nibble
     emit(f"v_lshl_or_b32 {v(F[0])}, {v(F[1])}, 2, {v(F[0])}")
     emit("s_add_u32 %[b], %[b], 1")
@@ -297,21 +351,11 @@ def exit_stub(p, ml):
     emit("s_branch done_%=")
 
 
-def main():
-    # ---- entry: operands -> fixed registers
-    ent = [
-        (MF0, "Pf0"), (MF1, "Pf1"), (X0, "x0"), (X1, "x1"), (G0, "g0"), (C0, "c0"), (G1, "g1"), (C1, "c1"),
-        (NK, "nkg"), (NK + 1, "nkc"), (NX, "nx"), (EPEND, "e_pend"), (KPEND, "kpg"), (KPEND + 1, "kpc"),
-        (A0, "a1"), (A1, "a2"), (A2, "a3"), (ACC, "acc"), (TOFF, "toff"), (LANE, "lane"),
-    ]
-    for reg, name in ent:
-        emit(f"v_mov_b32 {v(reg)}, %[{name}]")
-    for reg, name in [(I0, "i0"), (I1, "i1"), (NK + 2, "nki"), (KPEND + 2, "kpi"),
-                      (TR[1]['c0'], "L0"), (TR[1]['c1'], "L1"), (TR[1]['cs'], "U1")]:
-        emit(f"v_mov_b64 {vp(reg)}, %[{name}]")
-    emit(f"v_mov_b32 {v(NINF)}, 0xff800000")
-    emit(f"v_mov_b32 {v(SHR)}, 0xff800000")
-    emit(f"v_mov_b32 {v(SHD)}, 0xff800000")
+def variant_code(border):
+    """Decision + 8 bodies + exit stubs of one variant, labels suffixed so both fit in one statement."""
+    global BORDER
+    BORDER = border
+    del out[:]
     emit("s_nop 1")
     emit(f"v_readlane_b32 %[t0], {v(MF0)}, 0")
     emit("s_nop 1")
@@ -325,28 +369,48 @@ def main():
     for p in (0, 1):
         for ml in "RD":
             exit_stub(p, ml)
-    # ---- exit: fixed registers -> operands
-    emit("done_%=:")
-    emit("s_waitcnt vmcnt(0) lgkmcnt(0)")
+    sfx = "B" if border else "I"
+    return [ln.replace("done_%=", "DONE").replace("_%=", f"_{sfx}%=").replace("DONE", "done_%=") for ln in out]
+
+
+def main():
+    # ---- entry: operands -> fixed registers (common to both variants)
+    ent = [
+        (MF0, "Pf0"), (MF1, "Pf1"), (X0, "x0"), (X1, "x1"), (G0, "g0"), (C0, "c0"), (G1, "g1"), (C1, "c1"),
+        (NK, "nkg"), (NK + 1, "nkc"), (NX, "nx"), (EPEND, "e_pend"), (KPEND, "kpg"), (KPEND + 1, "kpc"),
+        (A0, "a1"), (A1, "a2"), (A2, "a3"), (ACC, "acc"), (TOFF, "toff"), (LANE, "lane"),
+    ]
+    head = []
+    for reg, name in ent:
+        head.append(f"v_mov_b32 {v(reg)}, %[{name}]")
+    for reg, name in [(I0, "i0"), (I1, "i1"), (NK + 2, "nki"), (KPEND + 2, "kpi"),
+                      (TR[1]['c0'], "L0"), (TR[1]['c1'], "L1"), (TR[1]['cs'], "U1")]:
+        head.append(f"v_mov_b64 {vp(reg)}, %[{name}]")
+    head += [f"v_mov_b32 {v(NINF)}, 0xff800000", f"v_mov_b32 {v(SHR)}, 0xff800000", f"v_mov_b32 {v(SHD)}, 0xff800000",
+             f"v_lshlrev_b32 {v(O0)}, 1, {v(LANE)}", f"v_lshl_or_b32 {v(O1)}, {v(LANE)}, 1, 1",
+             "s_cmp_eq_u32 %[mode], 0", "s_cbranch_scc0 border_start_%="]
+    interior = variant_code(False)
+    border = ["border_start_%=:"] + variant_code(True)
+    tail = ["done_%=:", "s_waitcnt vmcnt(0) lgkmcnt(0)"]
     for reg, name in ent:
         if name in ("lane",):
             continue
-        emit(f"v_mov_b32 %[{name}], {v(reg)}")
+        tail.append(f"v_mov_b32 %[{name}], {v(reg)}")
     for reg, name in [(I0, "i0"), (I1, "i1"), (NK + 2, "nki"), (KPEND + 2, "kpi")]:
-        emit(f"v_mov_b64 %[{name}], {vp(reg)}")
-    emit("s_nop 1")
-
-    text = "\n".join(f'    "{ln}\\n\\t"' for ln in out)
+        tail.append(f"v_mov_b64 %[{name}], {vp(reg)}")
+    tail.append("s_nop 1")
+    lines = head + interior + border + tail
+    text = "\n".join(f'    "{ln}\\n\\t"' for ln in lines)
     clob = ", ".join(f'"v{i}"' for i in range(VB, VEND))
-    inc = f"""/* GENERATED by tools/gen_fill_asm.py — do not edit. See that file for the register map and hazards. */
-#define ABEA_FILL_INTERIOR_ASM \\
+    inc = f"""/* GENERATED by tools/gen_fill_asm.py — do not edit. See that file for the register map and hazards.
+ * One statement, two variants selected by %[mode]: 0 = interior (no masks), 1 = border (masks + end-point scan). */
+#define ABEA_FILL_ASM \\
 {text.replace(chr(10), " " + chr(92) + chr(10))}
-#define ABEA_FILL_INTERIOR_CLOBBERS {clob}, "vcc", "scc", "memory"
+#define ABEA_FILL_CLOBBERS {clob}, "vcc", "scc", "memory"
 """
-    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "f5c_amd", "csrc",
-                        "abea_fill_interior.inc")
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "f5c_amd", "csrc", "abea_fill.inc")
     open(path, "w").write(inc)
-    print(f"wrote {path}: {len(out)} asm lines")
+    print(f"wrote {path}: {len(lines)} asm lines")
 
 
 if __name__ == "__main__":

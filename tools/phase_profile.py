@@ -35,3 +35,9 @@ for q in range(10):
     print(f"  t={q*10+5:3d}%: waves filling {nf:5d} walking {nw:5d} expanding {ne:5d}")
 i = np.argmax(bands)
 print(f"longest read: {bands[i]:.0f} bands fill {fill[i]*tick*1e3:.2f} ms ({fill[i]/bands[i]*10:.0f} ns/band) walk {walk[i]*tick*1e3:.2f} ms ({walk[i]/steps[i]*10:.0f} ns/step) start {(t0[i]-base)*tick*1e3:.2f} end {(end[i]-base)*tick*1e3:.2f}")
+order = np.argsort(-(end))[:12]
+idx_ok = np.nonzero(ok)[0]
+print("last finishing reads: (bands, fill ms, ns/band, walk ms, start ms, end ms, qc_pass, flagged_bad)")
+for j in order:
+    r = idx_ok[j]
+    print(f"  {bands[j]:.0f} {fill[j]*tick*1e3:.2f} {fill[j]/bands[j]*10:.0f} {walk[j]*tick*1e3:.2f} {(t0[j]-base)*tick*1e3:.2f} {(end[j]-base)*tick*1e3:.2f} {int(n_pairs[r]>0)} {int(b['bad'][r])}")
