@@ -369,18 +369,22 @@ void abea_align_kernel(const abea_read_desc* __restrict__ descs,
         if (ll_k >= 0 && ll_e >= 99 && run > 0) {
             for (; run > 0; --run) step(std::false_type{});
 #else
-        if (ll_k >= 0 && ll_e >= 99) {
-            /* hand-scheduled loops (tools/gen_fill_asm.py): same semantics as step(false) x run for the interior
-             * stretch; once the band touches the bottom/right edge of the matrix (run <= 0) the border variant
-             * (validity masks + online end-point scan) runs to the last band */
+        {
+            /* hand-scheduled loops (tools/gen_fill_asm.py).  Interior variant: same semantics as step(false) x run
+             * while every cell is provably in range.  Border variant (validity masks, trim column, online end-point
+             * scan = step(true)): the first ~100 bands until ll_k >= 0 and ll_e >= 99, and everything after the
+             * band has touched the bottom/right edge of the matrix (never interior again: ll_e, ll_k only grow) */
             uint32_t toff = (uint32_t)lane * 16u + (uint32_t)(b >> 5) * 1024u;
             uint32_t t0, t1, t2, t3, t4; uint64_t cm0a, cm0b, cm1a, cm1b, cv0, cv1;
             const uint32_t kring_a = (uint32_t)(uintptr_t)k_ring, ering_a = (uint32_t)(uintptr_t)e_ring;
             /* "s" operands must be provably wave-uniform */
             int s_ll_e = uni(ll_e), s_ll_k = uni(ll_k);
             int s_b = uni(b);
-            const bool interior = run > 0;
-            const int s_b_end = interior ? uni(b + run) : uni(nb_pad);
+            const bool interior = (ll_k >= 0) && (ll_e >= 99) && (run > 0);
+            const bool past_edge = (E - 2 - ll_e <= 0) || (K - 102 - ll_k <= 0);
+            const int s_b_end = interior ? uni(b + run)
+                              : past_edge ? uni(nb_pad)
+                              : uni(min(nb_pad, b + max(max(-ll_k, 99 - ll_e), 256)));   /* chunk: re-check for the interior variant later */
             uint32_t s_k_addr = (uint32_t)uni((int)(kring_a + ((uint32_t)k_next & 127u) * 16u));
             uint32_t s_e_addr = (uint32_t)uni((int)(ering_a + ((uint32_t)e_next & 127u) * 4u));
             if ((kring_a & 4095u) != 0u || (ering_a & 1023u) != 0u) __builtin_trap();   /* ring wrap uses s_bitset0 */
@@ -419,9 +423,12 @@ void abea_align_kernel(const abea_read_desc* __restrict__ descs,
             mvacc = s_mvacc; mvprev = s_mvprev;
             P0 = (double)Pf0; P1 = (double)Pf1;
 #endif
-        } else {
+        }
+#ifdef ABEA_NO_ASM
+        else {
             step(std::true_type{});
         }
+#endif
     }
     }
     __syncthreads();            /* this wave's trace stores are complete before it reads them back */

@@ -204,12 +204,16 @@ def body(p, ml, m):
     emit(f"v_cvt_f64_f32 {vp(T['c1'])}, {v(MF1)}")
     emit(f"v_cvt_f64_f32 {vp(T['cs'])}, {v(sh)}")
     if BORDER:
-        # in-matrix offsets [min_off, max_off) (align.c:337-346 with ll_k >= 0, ll_e >= 99)
+        # in-matrix offsets [min_off, max_off) (align.c:337-346)
         emit("s_sub_u32 %[t2], %[ll_e], %[Em1]")
-        emit("s_max_i32 %[t2], %[t2], 0")                   # min_off
+        emit("s_sub_u32 %[t3], 0, %[ll_k]")
+        emit("s_max_i32 %[t2], %[t2], %[t3]")
+        emit("s_max_i32 %[t2], %[t2], 0")                   # min_off = max(-ll_k, ll_e-(E-1), 0)
         emit("s_sub_u32 %[t3], %[Km1], %[ll_k]")
         emit("s_add_u32 %[t3], %[t3], 1")
-        emit("s_min_i32 %[t3], %[t3], 100")                 # max_off
+        emit("s_add_u32 %[t4], %[ll_e], 1")
+        emit("s_min_i32 %[t3], %[t3], %[t4]")
+        emit("s_min_i32 %[t3], %[t3], 100")                 # max_off = min(K-ll_k, ll_e+1, 100)
         emit("s_sub_u32 %[t3], %[t3], %[t2]")
         emit("s_max_i32 %[t3], %[t3], 0")                   # width
         emit(f"v_subrev_u32 {v(F[0])}, %[t2], {v(O0)}")
@@ -227,6 +231,25 @@ def body(p, ml, m):
         emit(tail0[0]); emit(tail1[0]); emit(tail0[1]); emit(tail1[1])
         emit(f"v_cndmask_b32 {v(F[0])}, 0, {v(F[0])}, %[cv0]")     # trace stays 0 outside the matrix (align.c:257)
         emit(f"v_cndmask_b32 {v(F[1])}, 0, {v(F[1])}, %[cv1]")
+        # ---- trim column, k-mer -1 (align.c:324-333): score lp_trim*(event+1), FROM_U
+        nt = f"notrim_{tag}_%="
+        emit("s_not_b32 %[t2], %[ll_k]")                    # offset of k-mer -1 = -1 - ll_k
+        emit("s_cmp_lt_u32 %[t2], 100")
+        emit(f"s_cbranch_scc0 {nt}")
+        emit("s_sub_u32 %[t3], %[ll_e], %[t2]")             # its event
+        emit("s_cmp_le_u32 %[t3], %[Em1]")
+        emit(f"s_cbranch_scc0 {nt}")
+        emit("s_add_u32 %[t3], %[t3], 1")
+        emit(f"v_cvt_f64_i32 {vp(LPD[0])}, %[t3]")
+        emit(f"v_cmp_eq_u32 %[cm0a], %[t2], {v(O0)}")
+        emit(f"v_cmp_eq_u32 %[cm0b], %[t2], {v(O1)}")
+        emit(f"v_mul_f64 {vp(LPD[0])}, {vp(LPD[0])}, %[lp_trim]")
+        emit(f"v_cvt_f32_f64 {v(TMP)}, {vp(LPD[0])}")
+        emit(f"v_cndmask_b32 {v(MF0)}, {v(MF0)}, {v(TMP)}, %[cm0a]")
+        emit(f"v_cndmask_b32 {v(MF1)}, {v(MF1)}, {v(TMP)}, %[cm0b]")
+        emit(f"v_cndmask_b32 {v(F[0])}, {v(F[0])}, 1, %[cm0a]")
+        emit(f"v_cndmask_b32 {v(F[1])}, {v(F[1])}, 1, %[cm0b]")
+        emit(f"{nt}:")
         # ---- online end-point scan (align.c:424-445): cell of the last k-mer, if in band and in range
         es = f"es_{tag}_%="
         emit("s_sub_u32 %[t2], %[Km1], %[ll_k]")            # offset of k-mer K-1
