@@ -32,6 +32,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline sample duration")
     ap.add_argument("--arena-gib", type=float, default=0.0, help="cap the scratch arena (0 = 90%% of free HBM)")
+    ap.add_argument("--batch-cache", default="", help="np.savez cache of the generated batch (avoids the forked "
+                    "generator pool, e.g. under rocprofv3)")
     args = ap.parse_args()
 
     import numpy as np
@@ -58,12 +60,19 @@ def main():
     n_reads = args.reads or cfg["n_reads"]
     t0 = time.time()
     workers = max(1, min(32, (os.cpu_count() or 1) // max(1, world)))
-    if args.scaling == "weak":
+    cache = f"{args.batch_cache}.{args.config}.{n_reads}.r{rank}.npz" if args.batch_cache else ""
+    if cache and os.path.exists(cache):
+        z = np.load(cache)
+        batch = {k_: z[k_] for k_ in z.files}
+        batch["pair_cap"] = int(batch["pair_cap"])
+    elif args.scaling == "weak":
         batch = synth.make_batch(n_reads, model, k, seed=cfg["seed"] + 1000 * rank, law=cfg["law"], workers=workers)
     else:
         full = synth.make_batch(n_reads, model, k, seed=cfg["seed"], law=cfg["law"], workers=workers)
         batch, _ = synth.shard_batch(full, rank, world)
         del full
+    if cache and not os.path.exists(cache):
+        np.savez(cache, **batch)
     t_gen = time.time() - t0
 
     d = abea.AbeaContext.upload(batch)            # inputs resident in HBM before the arena is sized
