@@ -392,3 +392,111 @@ int32_t orc_scaling_single(const orc_pair_t* pairs, int32_t n_pairs, const char*
     if (*events_per_base > 5.0) { *read_stat_flag |= 0x004; }                         /* FAILED_QUALITY_CHK */
     return n_align;
 }
+
+
+/* ---- N2: event detection, restated from events.c (scrappie-derived t-statistic peak picker).
+ * The reference is compiled as C++ (Makefile:6-8), so fabs()/sqrt() on float arguments are the float
+ * overloads; written as fabsf/sqrtf here. */
+#include <float.h>
+
+void orc_raw_to_pa(float* raw, size_t nsample, float offset, float range, float digitisation) {
+    float raw_unit = range / digitisation;                          /* f5c.c:693 */
+    for (size_t j = 0; j < nsample; j++) raw[j] = (raw[j] + offset) * raw_unit;
+}
+
+/* events.c:324-369 */
+static float* ev_tstat(const double* sum, const double* sumsq, size_t n, size_t w) {
+    float* t = (float*)calloc(n, sizeof(float));
+    const float eta = FLT_MIN;
+    const float wf = (float)w;
+    if (n < 2 * w || w < 2) return t;
+    for (size_t i = 0; i < w; ++i) { t[i] = 0; t[n - i - 1] = 0; }
+    for (size_t i = w; i <= n - w; ++i) {
+        double sum1 = sum[i], sumsq1 = sumsq[i];
+        if (i > w) { sum1 -= sum[i - w]; sumsq1 -= sumsq[i - w]; }
+        float sum2 = (float)(sum[i + w] - sum[i]);
+        float sumsq2 = (float)(sumsq[i + w] - sumsq[i]);
+        float mean1 = sum1 / wf;
+        float mean2 = sum2 / wf;
+        float combined_var = sumsq1 / wf - mean1 * mean1 + sumsq2 / wf - mean2 * mean2;
+        combined_var = fmaxf(combined_var, eta);
+        const float delta_mean = mean2 - mean1;
+        t[i] = fabsf(delta_mean) / sqrtf(combined_var / wf);
+    }
+    return t;
+}
+
+typedef struct {
+    int def_peak_pos; float def_peak_val; const float* signal; size_t signal_length; float threshold;
+    size_t window_length; size_t masked_to; int peak_pos; float peak_value; int valid_peak;
+} ev_detector;
+
+size_t orc_getevents(size_t nsample, const float* raw, orc_event_t* out) {
+    const size_t n = nsample;
+    if (n == 0) return 0;
+    /* events.c:303-313: prefix sums; the square is a float product */
+    double* sums = (double*)calloc(n + 1, sizeof(double));
+    double* sumsqs = (double*)calloc(n + 1, sizeof(double));
+    for (size_t i = 0; i < n; ++i) {
+        sums[i + 1] = sums[i] + raw[i];
+        sumsqs[i + 1] = sumsqs[i] + raw[i] * raw[i];
+    }
+    float* t1 = ev_tstat(sums, sumsqs, n, 3);                         /* events.c:52-56 DNA defaults */
+    float* t2 = ev_tstat(sums, sumsqs, n, 6);
+    ev_detector d[2] = {
+        { -1, FLT_MAX, t1, n, 1.4f, 3, 0, -1, FLT_MAX, 0 },
+        { -1, FLT_MAX, t2, n, 9.0f, 6, 0, -1, FLT_MAX, 0 } };
+    const float peak_height = 0.2f;
+    size_t* peaks = (size_t*)calloc(n, sizeof(size_t));
+    size_t peak_count = 0;
+    for (size_t i = 0; i < n; i++) {                                  /* events.c:380-452 */
+        for (unsigned k = 0; k < 2; k++) {
+            ev_detector* det = &d[k];
+            if (det->masked_to >= i) continue;
+            float cur = det->signal[i];
+            if (det->peak_pos == det->def_peak_pos) {
+                if (cur < det->peak_value) {
+                    det->peak_value = cur;
+                } else if (cur - det->peak_value > peak_height) {
+                    det->peak_value = cur;
+                    det->peak_pos = (int)i;
+                }
+            } else {
+                if (cur > det->peak_value) { det->peak_value = cur; det->peak_pos = (int)i; }
+                if (k == 0) {
+                    if (det->peak_value > det->threshold) {
+                        d[1].masked_to = det->peak_pos + det->window_length;
+                        d[1].peak_pos = d[1].def_peak_pos;
+                        d[1].peak_value = d[1].def_peak_val;
+                        d[1].valid_peak = 0;
+                    }
+                }
+                if (det->peak_value - cur > peak_height && det->peak_value > det->threshold) det->valid_peak = 1;
+                if (det->valid_peak && (i - det->peak_pos) > det->window_length / 2) {
+                    peaks[peak_count++] = det->peak_pos;
+                    det->peak_pos = det->def_peak_pos;
+                    det->peak_value = cur;
+                    det->valid_peak = 0;
+                }
+            }
+        }
+    }
+    /* events.c:466-513: events between consecutive peaks */
+    size_t ne = 1;
+    for (size_t i = 0; i < n; ++i) if (peaks[i] > 0 && peaks[i] < n) ne++;
+    for (size_t ev = 0; ev < ne; ++ev) {
+        size_t start = (ev == 0) ? 0 : peaks[ev - 1];
+        size_t end = (ev == ne - 1) ? n : peaks[ev];
+        if (ne == 1) { start = 0; end = n; }                          /* no peak: the reference reads peaks[-1] */
+        orc_event_t e; memset(&e, 0, sizeof e);
+        e.start = (uint64_t)start;
+        e.length = (float)(end - start);
+        e.mean = (float)(sums[end] - sums[start]) / e.length;
+        const float deltasqr = (sumsqs[end] - sumsqs[start]);
+        const float var = deltasqr / e.length - e.mean * e.mean;
+        e.stdv = sqrtf(fmaxf(var, 0.0f));
+        out[ev] = e;
+    }
+    free(peaks); free(t1); free(t2); free(sums); free(sumsqs);
+    return ne;
+}

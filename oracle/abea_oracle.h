@@ -59,6 +59,13 @@ void orc_align_batch(int32_t n_reads, const char* reads, const int64_t* read_ptr
                      orc_pair_t* pairs, const int64_t* pair_ptr, int32_t* n_pairs, orc_diag_t* diags,
                      int32_t n_threads);
 
+/* Event detection: raw pA samples -> event table.  getevents (events.c:562-582), i.e.
+ * detect_events on the whole signal (the trim result there is discarded), DNA parameters
+ * (events.c:52-56).  Returns the number of events written (<= nsample); out must hold nsample entries. */
+size_t orc_getevents(size_t nsample, const float* raw_pa, orc_event_t* out);
+/* ADC -> pA conversion of event_single (f5c.c:692-696), in place on a float copy of the int16 samples */
+void orc_raw_to_pa(float* raw, size_t nsample, float offset, float range, float digitisation);
+
 /* glibc allocator tuning for the multi-threaded CPU baseline (see abea_oracle.c) */
 void orc_malloc_tuning(int on);
 

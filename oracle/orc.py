@@ -97,6 +97,20 @@ def align_batch(batch, model, k, n_threads=1, want_diag=True):
     return pairs, n_pairs, diags
 
 
+def getevents(raw_adc, offset, rng, digitisation):
+    """int16 ADC samples + channel scaling -> (event table, pA signal) as event_single does (f5c.c:682-710)."""
+    L = lib()
+    L.orc_getevents.restype = C.c_size_t
+    L.orc_getevents.argtypes = [C.c_size_t, C.c_void_p, C.c_void_p]
+    L.orc_raw_to_pa.restype = None
+    L.orc_raw_to_pa.argtypes = [C.c_void_p, C.c_size_t, C.c_float, C.c_float, C.c_float]
+    pa = np.ascontiguousarray(raw_adc, dtype=np.float32).copy()
+    L.orc_raw_to_pa(_p(pa), len(pa), np.float32(offset), np.float32(rng), np.float32(digitisation))
+    ev = np.zeros(len(pa), dtype=EVENT_DT)
+    n = L.orc_getevents(len(pa), _p(pa), _p(ev))
+    return ev[:n].copy(), pa
+
+
 def malloc_tuning(on: bool):
     lib().orc_malloc_tuning(1 if on else 0)
 
