@@ -39,7 +39,10 @@ class _DevBatch(C.Structure):
     _fields_ = [("n_reads", C.c_int32), ("read_ptr", C.c_void_p), ("read_len", C.c_void_p),
                 ("event_ptr", C.c_void_p), ("n_events", C.c_void_p), ("pair_ptr", C.c_void_p),
                 ("scalings", C.c_void_p), ("reads", C.c_void_p), ("events", C.c_void_p),
-                ("pairs", C.c_void_p), ("n_pairs", C.c_void_p), ("diag", C.c_void_p)]
+                ("pairs", C.c_void_p), ("n_pairs", C.c_void_p), ("diag", C.c_void_p),
+                ("kmer_ptr", C.c_void_p), ("base_to_event_map", C.c_void_p), ("scalings_io", C.c_void_p),
+                ("events_per_base", C.c_void_p), ("read_stat_flag", C.c_void_p), ("n_event_alignment", C.c_void_p),
+                ("min_num_events_to_rescale", C.c_int32), ("reserved", C.c_int32)]
 
 
 class Stats(C.Structure):
@@ -193,14 +196,38 @@ class AbeaContext:
         d["diag"] = torch.zeros(max(1, n) * DIAG_DT.itemsize, dtype=torch.uint8, device=dev)
         return d
 
-    def align_db_device(self, dbatch, want_diag=True):
-        """Run the hot path on a batch already resident in HBM (what bench.py times). Synchronous."""
+    def align_db_device(self, dbatch, want_diag=True, scaling=False):
+        """Run the hot path on a batch already resident in HBM (what bench.py times). Synchronous.
+        scaling=True also runs scaling_single (postalign + recalibrate_model, row N1) on the device."""
+        import torch
+        sc = [None] * 6 + [0, 0]
+        if scaling:
+            n = dbatch["n_reads"]
+            K = (dbatch["read_len"].astype(np.int64) - self.kmer_size + 1).clip(min=0)
+            dbatch["kmer_ptr"] = np.concatenate([[0], np.cumsum(K)[:-1]]).astype(np.int64) if n else np.zeros(0, np.int64)
+            dev = dbatch["pairs"].device
+            dbatch["b2e"] = torch.full((max(1, int(K.sum())) * 2,), -1, dtype=torch.int32, device=dev)
+            dbatch["scalings_io"] = torch.from_numpy(dbatch["scalings"].copy().view(np.uint8)).to(dev)
+            dbatch["events_per_base"] = torch.zeros(max(1, n), dtype=torch.float64, device=dev)
+            dbatch["read_stat_flag"] = torch.zeros(max(1, n), dtype=torch.int32, device=dev)
+            dbatch["n_event_alignment"] = torch.zeros(max(1, n), dtype=torch.int32, device=dev)
+            sc = [_p(dbatch["kmer_ptr"]), dbatch["b2e"].data_ptr(), dbatch["scalings_io"].data_ptr(),
+                  dbatch["events_per_base"].data_ptr(), dbatch["read_stat_flag"].data_ptr(),
+                  dbatch["n_event_alignment"].data_ptr(), 0, 0]
         db = _DevBatch(dbatch["n_reads"], _p(dbatch["read_ptr"]), _p(dbatch["read_len"]),
                        _p(dbatch["event_ptr"]), _p(dbatch["n_events"]), _p(dbatch["pair_ptr"]),
                        _p(dbatch["scalings"]),
                        dbatch["reads"].data_ptr(), dbatch["events"].data_ptr(), dbatch["pairs"].data_ptr(),
-                       dbatch["n_pairs"].data_ptr(), dbatch["diag"].data_ptr() if want_diag else None)
+                       dbatch["n_pairs"].data_ptr(), dbatch["diag"].data_ptr() if want_diag else None, *sc)
         self._chk(self._lib.abea_align_batch_device(self._h, C.byref(db)), "abea_align_batch_device")
+
+    @staticmethod
+    def download_scaling(dbatch):
+        """(base_to_event_map int32[ΣK,2], scalings SCAL_DT[n], events_per_base f64[n], flags i32[n], n_align i32[n])"""
+        n = dbatch["n_reads"]
+        return (dbatch["b2e"].cpu().numpy().reshape(-1, 2), dbatch["scalings_io"].cpu().numpy().view(SCAL_DT)[:n],
+                dbatch["events_per_base"].cpu().numpy()[:n], dbatch["read_stat_flag"].cpu().numpy()[:n],
+                dbatch["n_event_alignment"].cpu().numpy()[:n])
 
     @staticmethod
     def download(dbatch):

@@ -23,6 +23,7 @@ static_assert(sizeof(abea_event_t) == 24, "event_t layout (f5c.h:129)");
 static_assert(sizeof(abea_model_t) == 12, "model_t layout (f5c.h:147)");
 static_assert(sizeof(abea_scalings_t) == 16, "scalings_t layout (f5c.h:158)");
 static_assert(sizeof(abea_pair_t) == 8, "AlignedPair layout (f5c.h:181)");
+static_assert(sizeof(abea_index_pair_t) == 8, "index_pair_t layout (f5c.h:187)");
 static_assert(sizeof(abea_read_diag) == 40, "abea_read_diag layout");
 static_assert(sizeof(abea_kpar_t) == 16, "kpar layout");
 static_assert(sizeof(abea_fill_out) == 16, "fill_out layout");
@@ -32,6 +33,9 @@ extern "C" {
 __global__ void abea_selftest_kernel(int* out);
 __global__ void abea_pre_kernel(const abea_read_desc*, const char*, const abea_event_t*, const abea_model_t*, int,
                                 abea_kpar_t*, float*);
+__global__ void abea_scaling_kernel(const abea_read_desc*, const char*, const abea_model_t*, int, const float*,
+                                    const abea_pair_t*, const int32_t*, abea_index_pair_t*, abea_scalings_t*, double*,
+                                    int32_t*, int32_t*, int);
 __global__ void abea_align_kernel(const abea_read_desc*, const float*, const abea_kpar_t*, uint4*, uint32_t*,
                                   abea_pair_t*, int32_t*, abea_read_diag*);
 }
@@ -217,6 +221,9 @@ extern "C" int abea_align_batch_device(abea_ctx* c, const abea_device_batch* B) 
     if (!B->read_ptr || !B->read_len || !B->event_ptr || !B->n_events || !B->pair_ptr || !B->scalings ||
         !B->reads || !B->events || !B->pairs || !B->n_pairs)
         return fail(ABEA_EINVAL, "abea_align_batch_device: null array");
+    if (B->base_to_event_map && (!B->kmer_ptr || !B->scalings_io || !B->events_per_base || !B->read_stat_flag ||
+                                 !B->n_event_alignment))
+        return fail(ABEA_EINVAL, "abea_align_batch_device: scaling outputs requested but some are null");
     HIP_TRY(hipSetDevice(c->device));      /* the caller's thread changes per batch (f5c.cu:692-694) */
 
     /* ---- guards + ordering ---- */
@@ -271,6 +278,7 @@ extern "C" int abea_align_batch_device(abea_ctx* c, const abea_device_batch* B) 
             memset(&d, 0, sizeof d);
             d.out_idx = r.idx;
             d.read_off = B->read_ptr[r.idx]; d.event_off = B->event_ptr[r.idx]; d.pair_off = B->pair_ptr[r.idx];
+            d.kmer_off = B->kmer_ptr ? B->kmer_ptr[r.idx] : 0;
             d.read_len = r.L; d.n_events = r.E; d.n_kmers = r.K;
             if (!r.run) { d.n_groups = 0; continue; }
             d.n_groups = (int32_t)((r.n_bands + ABEA_GROUP - 1) / ABEA_GROUP);
@@ -314,11 +322,20 @@ extern "C" int abea_align_batch_device(abea_ctx* c, const abea_device_batch* B) 
         hipLaunchKernelGGL(abea_align_kernel, dim3((unsigned)m), dim3(64), 0, c->stream,
                            d_desc, d_evm, d_kpar, d_trace, d_codes, B->pairs, B->n_pairs, B->diag);
         HIP_TRY(hipEventRecord(c->ev[2], c->stream));
+        if (B->base_to_event_map) {                          /* row N1: scaling_single on the device */
+            hipLaunchKernelGGL(abea_scaling_kernel, dim3((unsigned)m), dim3(64), 0, c->stream,
+                               d_desc, B->reads, c->d_model, (int)c->k, d_evm, B->pairs, B->n_pairs,
+                               B->base_to_event_map, B->scalings_io, B->events_per_base, B->read_stat_flag,
+                               B->n_event_alignment,
+                               B->min_num_events_to_rescale > 0 ? B->min_num_events_to_rescale : 200);
+        }
+        HIP_TRY(hipEventRecord(c->ev[3], c->stream));
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(c->stream));            /* h_desc and the arena are reused by the next sub-batch */
         float ms = 0;
         HIP_TRY(hipEventElapsedTime(&ms, c->ev[0], c->ev[1])); st.pre_ms += ms;
         HIP_TRY(hipEventElapsedTime(&ms, c->ev[1], c->ev[2])); st.fill_ms += ms;   /* fused fill + traceback */
+        HIP_TRY(hipEventElapsedTime(&ms, c->ev[2], c->ev[3])); st.trace_ms += ms;  /* optional scaling kernel */
         st.n_sub_batches += 1; st.fill_launches += 1;
         pos = end;
     }

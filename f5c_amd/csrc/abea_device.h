@@ -26,6 +26,8 @@ typedef struct __attribute__((aligned(16))) {
     int64_t evm_off;      /* floats into the event-mean scratch */
     int64_t trace_off;    /* uint4  into the trace scratch (n_groups * 64 uint4) */
     int64_t code_off;     /* uint32 into the traceback-code scratch */
+    int64_t kmer_off;     /* abea_index_pair_t into base_to_event_map (optional scaling outputs) */
+    int64_t pad64;
     int32_t read_len, n_events, n_kmers, n_groups;
     float   scale, shift;
     int32_t out_idx;      /* index of the read in the caller's n_pairs[] / diag[] */

@@ -580,3 +580,142 @@ void abea_align_kernel(const abea_read_desc* __restrict__ descs,
         }
     }
 }
+
+
+/* ================================================================ scaling_single on the device (row N1)
+ * postalign (align.c:561-661) + recalibrate_model (align.c:666-773) + the QC flags of scaling_single
+ * (f5c.c:736-807), one wavefront per read, run after abea_align_kernel while pairs/evm are still resident.
+ *   base_to_event_map: every k-mer owns one contiguous run of pairs; its first pair repeats the previous
+ *     event iff it was reached by a skip (FROM_L), all later pairs of the run are new events.
+ *   'M' states = first event of each k-mer that has events and whose rank differs from the previous such
+ *     k-mer; the five normal-equation sums and the variance sum are accumulated in k order, in fp64, by a
+ *     uniform LDS loop (adding +0.0 for non-'M' k-mers), so they round exactly as the reference's loop. */
+extern "C" __global__ __launch_bounds__(64)
+void abea_scaling_kernel(const abea_read_desc* __restrict__ descs, const char* __restrict__ reads,
+                         const abea_model_t* __restrict__ model, int kmer_size,
+                         const float* __restrict__ evm_all, const abea_pair_t* __restrict__ pairs_all,
+                         const int32_t* __restrict__ n_pairs, abea_index_pair_t* __restrict__ b2e_all,
+                         abea_scalings_t* __restrict__ sc_io, double* __restrict__ epb_out,
+                         int32_t* __restrict__ flag_io, int32_t* __restrict__ nalign_out, int min_rescale) {
+    __shared__ double acc_s[5][64];
+    const abea_read_desc* d = descs + blockIdx.x;
+    const int lane = threadIdx.x;
+    const int out_idx = d->out_idx;
+    const int n = n_pairs[out_idx];
+    if (d->n_groups == 0 || n <= 0) {                    /* f5c.c:786-794: could not align */
+        if (lane == 0) { flag_io[out_idx] |= ABEA_FAILED_ALIGNMENT; epb_out[out_idx] = 0.0; nalign_out[out_idx] = 0; }
+        return;
+    }
+    const int K = d->n_kmers;
+    const abea_pair_t* __restrict__ pairs = pairs_all + d->pair_off;
+    abea_index_pair_t* map = b2e_all + d->kmer_off;
+    const float* __restrict__ evm = evm_all + d->evm_off;
+    const char* __restrict__ seq = reads + d->read_off;
+
+    /* ---- base_to_event_map (align.c:571-596) ---- */
+    for (int i = lane; i < n; i += 64) {
+        const abea_pair_t p = pairs[i];
+        abea_pair_t pm, pn; pm.ref_pos = pm.read_pos = -1; pn = pm;
+        if (i > 0) pm = pairs[i - 1];
+        if (i < n - 1) pn = pairs[i + 1];
+        const bool run_start = (i == 0) || (pm.ref_pos != p.ref_pos);
+        const bool run_end = (i == n - 1) || (pn.ref_pos != p.ref_pos);
+        const bool is_new = (i == 0) || (p.read_pos != pm.read_pos);
+        if (run_start) map[p.ref_pos].start = is_new ? p.read_pos : (!run_end ? pn.read_pos : -1);
+        if (run_end) map[p.ref_pos].stop = (!run_start || is_new) ? p.read_pos : -1;
+    }
+    const double events_per_base = (double)(pairs[n - 1].read_pos - pairs[0].read_pos) / K;   /* align.c:602 */
+    __syncthreads();
+
+    /* ---- recalibrate_model: normal equations over the 'M' states (align.c:677-723) ---- */
+    double A00 = 0, A01 = 0, A11 = 0, b0 = 0, b1 = 0;
+    int n_M = 0, n_align = 0, carry_rank = -1;
+    for (int k0 = 0; k0 < K; k0 += 64) {
+        const int k = k0 + lane;
+        abea_index_pair_t m; m.start = -1; m.stop = -1;
+        int rank = 0;
+        if (k < K) {
+            m = map[k];
+            for (int j = 0; j < kmer_size; ++j) rank = (rank << 2) | (int)base_code(seq[k + j]);
+        }
+        const bool valid = m.start != -1;
+        const unsigned long long vm = __ballot(valid);
+        const unsigned long long lower = vm & ((1ull << lane) - 1ull);
+        const int src = lower ? 63 - __clzll(lower) : 0;
+        const int prev_rank = lower ? __shfl(rank, src, 64) : carry_rank;
+        const bool isM = valid && (rank != prev_rank);
+        double t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
+        if (isM) {
+            const abea_model_t mo = model[rank];
+            const double e = evm[m.start], mu = mo.level_mean, sd = mo.level_stdv;
+            const double inv_var = 1. / (sd * sd);
+            t0 = inv_var; t1 = mu * inv_var; t2 = mu * mu * inv_var; t3 = e * inv_var; t4 = mu * e * inv_var;
+        }
+        acc_s[0][lane] = t0; acc_s[1][lane] = t1; acc_s[2][lane] = t2; acc_s[3][lane] = t3; acc_s[4][lane] = t4;
+        n_M += __popcll(__ballot(isM));
+        n_align += valid ? (m.stop - m.start + 1) : 0;
+        __syncthreads();
+        #pragma unroll 4
+        for (int l = 0; l < 64; ++l) {                   /* uniform, k order */
+            A00 += acc_s[0][l]; A01 += acc_s[1][l]; A11 += acc_s[2][l]; b0 += acc_s[3][l]; b1 += acc_s[4][l];
+        }
+        __syncthreads();
+        if (vm) carry_rank = __shfl(rank, 63 - __clzll(vm), 64);
+    }
+    for (int off = 32; off > 0; off >>= 1) n_align += __shfl_xor(n_align, off, 64);
+
+    bool calibrated = false;
+    double shift = 0, scale = 0, var = 0;
+    if (n_M >= min_rescale) {
+        const double A10 = A01;
+        const double div = A00 * A11 - A01 * A10;
+        shift = -(A01 * b1 - A11 * b0) / div;
+        scale = (A00 * b1 - A10 * b0) / div;
+        carry_rank = -1;
+        for (int k0 = 0; k0 < K; k0 += 64) {             /* align.c:738-753 */
+            const int k = k0 + lane;
+            abea_index_pair_t m; m.start = -1; m.stop = -1;
+            int rank = 0;
+            if (k < K) {
+                m = map[k];
+                for (int j = 0; j < kmer_size; ++j) rank = (rank << 2) | (int)base_code(seq[k + j]);
+            }
+            const bool valid = m.start != -1;
+            const unsigned long long vm = __ballot(valid);
+            const unsigned long long lower = vm & ((1ull << lane) - 1ull);
+            const int src = lower ? 63 - __clzll(lower) : 0;
+            const int prev_rank = lower ? __shfl(rank, src, 64) : carry_rank;
+            double t = 0;
+            if (valid && rank != prev_rank) {
+                const abea_model_t mo = model[rank];
+                const double e = evm[m.start], mu = mo.level_mean, sd = mo.level_stdv;
+                const double yi = (e - shift - scale * mu);
+                t = yi * yi / (sd * sd);
+            }
+            acc_s[0][lane] = t;
+            __syncthreads();
+            #pragma unroll 8
+            for (int l = 0; l < 64; ++l) var += acc_s[0][l];
+            __syncthreads();
+            if (vm) carry_rank = __shfl(rank, 63 - __clzll(vm), 64);
+        }
+        var /= n_M;
+        var = sqrt(var);
+        calibrated = true;
+    }
+    if (lane == 0) {
+        epb_out[out_idx] = events_per_base;
+        nalign_out[out_idx] = n_align;
+        int flag = 0;
+        float fvar = sc_io[out_idx].var;
+        if (calibrated) {
+            abea_scalings_t o = sc_io[out_idx];
+            o.shift = (float)shift; o.scale = (float)scale; o.var = (float)var;
+            sc_io[out_idx] = o;
+            fvar = o.var;
+        }
+        if (!calibrated || fvar > 2.5) flag |= ABEA_FAILED_CALIBRATION;       /* f5c.c:776-782 */
+        else if (events_per_base > 5.0) flag |= ABEA_FAILED_QUALITY_CHK;      /* f5c.c:799-805 */
+        flag_io[out_idx] |= flag;
+    }
+}

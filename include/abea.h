@@ -33,6 +33,7 @@ typedef struct { uint64_t start; float length; float mean; float stdv; } abea_ev
 typedef struct { float level_mean; float level_stdv; float level_log_stdv; } abea_model_t;       /* model_t     src/f5c.h:147-155 */
 typedef struct { float scale; float shift; float var; float log_var; } abea_scalings_t;          /* scalings_t  src/f5c.h:158-172 */
 typedef struct { int32_t ref_pos; int32_t read_pos; } abea_pair_t;                               /* AlignedPair src/f5c.h:181-184 */
+typedef struct { int32_t start; int32_t stop; } abea_index_pair_t;                               /* index_pair_t src/f5c.h:187-190 */
 
 /* Per-read quantities align() computes but f5c does not return (src/align.c:415-445,526-535);
  * optional output used by the parity tests for the "scores within 1e-4" check. */
@@ -102,14 +103,30 @@ typedef struct {
     abea_pair_t* pairs;          /* out                                                  */
     int32_t* n_pairs;            /* out [n_reads]                                        */
     abea_read_diag* diag;        /* out [n_reads], optional (NULL)                       */
+    /* ---- optional: scaling_single() on the device (src/f5c.c:736-807 = postalign + recalibrate_model,
+     *      src/align.c:561-773), run right after the alignment while the pairs are still in HBM.
+     *      All NULL = skipped.  Row N1 of SURVEY §8f. ---- */
+    const int64_t* kmer_ptr;               /* HOST: offset of read i in base_to_event_map (read_len-k+1 entries each) */
+    abea_index_pair_t* base_to_event_map;  /* DEVICE out: db->base_to_event_map[i][k] */
+    abea_scalings_t* scalings_io;          /* DEVICE in/out [n_reads]: estimated scalings in, recalibrated
+                                              shift/scale/var out when calibrated (log_var is left to the host) */
+    double* events_per_base;               /* DEVICE out [n_reads]: db->events_per_base[i] */
+    int32_t* read_stat_flag;               /* DEVICE in/out [n_reads]: FAILED_* bits OR-ed in (src/f5c.h:66-68) */
+    int32_t* n_event_alignment;            /* DEVICE out [n_reads]: db->n_event_alignment[i] */
+    int32_t  min_num_events_to_rescale;    /* opt.min_num_events_to_rescale (src/f5c.c:1185: 200); 0 -> 200 */
+    int32_t  reserved;
 } abea_device_batch;
+#define ABEA_FAILED_CALIBRATION 0x001      /* src/f5c.h:66 */
+#define ABEA_FAILED_ALIGNMENT   0x002      /* src/f5c.h:67 */
+#define ABEA_FAILED_QUALITY_CHK 0x004      /* src/f5c.h:68 */
 
 /* Same computation with inputs/outputs already in HBM (what bench.py times). Synchronous. */
 int abea_align_batch_device(abea_ctx* ctx, const abea_device_batch* batch);
 
 /* ---- timing / accounting of the last batch (core_t timing fields, src/f5c.h:457-466) ---- */
 typedef struct {
-    double pre_ms, fill_ms, trace_ms;     /* HIP-event kernel times on the library's stream, summed over sub-batches */
+    double pre_ms, fill_ms, trace_ms;     /* HIP-event kernel times on the library's stream, summed over sub-batches
+                                             (fill = fused fill+traceback kernel, trace = optional scaling kernel) */
     double h2d_ms, d2h_ms, host_ms;       /* host batch only */
     double total_ms;                      /* wall time of the call */
     int64_t n_reads_gpu, n_reads_skipped, n_sub_batches;

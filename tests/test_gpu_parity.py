@@ -203,3 +203,38 @@ def test_cpp_caller_through_f5c_shim(orc, r9, tmp_path):
         exp = [tuple(int(v) for v in p) for p in o_pairs[s:s + o_n[i]]]
         assert got == exp, f"read {i}"
     assert (o_n > 0).sum() >= 12
+
+
+def test_scaling_single_on_device(ctx, orc, r9):
+    """Row N1: postalign + recalibrate_model + QC flags on the device vs the oracle restatement
+    (itself pinned to recalib_scalings.exp): base_to_event_map, flags and counts bit-exact, recalibrated
+    shift/scale/var equal as floats, events_per_base equal as doubles."""
+    from f5c_amd import synth
+    k, model = r9
+    batch = synth.make_batch(48, model, k, seed=81, law="gamma8k", bad_frac=0.1)
+    # two short reads: too few 'M' events to recalibrate (< 200) -> FAILED_CALIBRATION
+    d = ctx.upload(batch)
+    ctx.align_db_device(d, scaling=True)
+    pairs, n_pairs, _ = ctx.download(d)
+    b2e, sc, epb, flags, nalign = ctx.download_scaling(d)
+    n_cal = 0
+    for i in range(len(n_pairs)):
+        s, L = int(batch["read_ptr"][i]), int(batch["read_len"][i])
+        es, E = int(batch["event_ptr"][i]), int(batch["n_events"][i])
+        ps = int(batch["pair_ptr"][i])
+        seq = batch["reads"][s:s + L].tobytes()
+        r = orc.scaling_single(pairs[ps:ps + n_pairs[i]], seq, batch["events"][es:es + E], model, k,
+                               batch["scalings"]["scale"][i], batch["scalings"]["shift"][i])
+        assert flags[i] == r["flag"], (i, flags[i], r["flag"])
+        assert nalign[i] == r["n_alignment"]
+        assert epb[i] == r["events_per_base"]
+        if n_pairs[i] > 0:
+            K = L - k + 1
+            ko = int(d["kmer_ptr"][i])
+            assert (b2e[ko:ko + K, 0] == r["base_to_event_map"]["start"]).all()
+            assert (b2e[ko:ko + K, 1] == r["base_to_event_map"]["stop"]).all()
+            if not (r["flag"] & 1) or r["scalings"]["var"] != 0:
+                assert sc["shift"][i] == r["scalings"]["shift"] and sc["scale"][i] == r["scalings"]["scale"]
+                assert sc["var"][i] == r["scalings"]["var"]
+                n_cal += 1
+    assert n_cal >= 35 and (flags == 2).sum() >= 2
