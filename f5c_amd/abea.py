@@ -69,6 +69,13 @@ def load_library():
         if not os.path.exists(LIB_PATH):
             raise AbeaError(f"{LIB_PATH} not built; run `python -c 'import __graft_entry__ as g; g.build()'` "
                             "(there is no CPU fallback)")
+        # torch bundles its own libamdhip64 (same SONAME as /opt/rocm's): let it load first so that both this
+        # library and torch share ONE HIP runtime in the process (the other order leaves torch without a device)
+        try:
+            import torch
+            torch.cuda.is_available()
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         L.abea_init.restype = C.c_int
         L.abea_init.argtypes = [C.POINTER(C.c_void_p), C.POINTER(_Cfg)]

@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <numeric>
+#include <thread>
 #include <vector>
 #include "abea_device.h"
 
@@ -348,6 +349,20 @@ extern "C" int abea_align_batch_device(abea_ctx* c, const abea_device_batch* B) 
     return ABEA_OK;
 }
 
+/* run fn(i) for i in [0,n) on up to `threads` host threads, contiguous blocks (reads are independent) */
+template <class F> static void parallel_for(int32_t n, int threads, F fn) {
+    threads = std::max(1, std::min(threads, n / 64 + 1));
+    if (threads == 1) { for (int32_t i = 0; i < n; ++i) fn(i); return; }
+    std::vector<std::thread> pool;
+    const int32_t step = (n + threads - 1) / threads;
+    for (int t = 0; t < threads; ++t) {
+        const int32_t lo = t * step, hi = std::min(n, lo + step);
+        if (lo >= hi) break;
+        pool.emplace_back([=]() { for (int32_t i = lo; i < hi; ++i) fn(i); });
+    }
+    for (auto& th : pool) th.join();
+}
+
 /* ------------------------------------------------------------------ host batch (db_t view) */
 extern "C" int abea_align_batch_host(abea_ctx* c, const abea_host_batch* H) {
     if (!c || !H) return fail(ABEA_EINVAL, "null argument");
@@ -384,12 +399,13 @@ extern "C" int abea_align_batch_host(abea_ctx* c, const abea_host_batch* H) {
     if ((rc = ensure_dev((void**)&c->d_npairs, &c->d_npairs_cap, (size_t)n * sizeof(int32_t)))) return rc;
     if ((rc = ensure_dev((void**)&c->d_diag, &c->d_diag_cap, (size_t)n * sizeof(abea_read_diag)))) return rc;
 
-    for (int32_t i = 0; i < n; ++i) {
+    const int host_threads = (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    parallel_for(n, host_threads, [&](int32_t i) {         /* the reference flattens on one thread (f5c.cu:744-802) */
         const size_t L = (size_t)read_len[(size_t)i], E = (size_t)n_events[(size_t)i];
         if (L) memcpy(c->h_reads + read_ptr[(size_t)i], H->read[i], L);
         c->h_reads[read_ptr[(size_t)i] + (int64_t)L] = '\0';
         if (E) memcpy(c->h_events + event_ptr[(size_t)i], H->events[i], E * sizeof(abea_event_t));
-    }
+    });
     const double t1 = now_ms();
     HIP_TRY(hipMemcpyAsync(c->d_reads, c->h_reads, sum_read, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(c->d_events, c->h_events, sum_ev * sizeof(abea_event_t), hipMemcpyHostToDevice, c->stream));
@@ -416,13 +432,13 @@ extern "C" int abea_align_batch_host(abea_ctx* c, const abea_host_batch* H) {
     HIP_TRY(hipStreamSynchronize(c->stream));
     const double t4 = now_ms();
     /* un-flatten into the caller-owned per-read buffers (f5c.cu:1003-1030; pairs already ascending) */
-    for (int32_t i = 0; i < n; ++i) {
+    parallel_for(n, host_threads, [&](int32_t i) {
         const int32_t np = c->h_npairs[i];
         H->n_pairs[i] = np;
         if (np > 0) memcpy(H->pairs[i], c->h_pairs + pair_ptr[(size_t)i], (size_t)np * sizeof(abea_pair_t));
         if (H->diag) H->diag[i] = c->h_diag[i];
-        st.sum_pairs += np;
-    }
+    });
+    for (int32_t i = 0; i < n; ++i) st.sum_pairs += c->h_npairs[i];
     const double t5 = now_ms();
     st.h2d_ms = t2 - t1; st.d2h_ms = t4 - t3; st.host_ms = (t1 - t0) + (t5 - t4);
     st.total_ms = t5 - t0;
