@@ -45,12 +45,6 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         assert world == 1 and args.gpus == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
-    torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # nccl == RCCL on ROCm
-
     cfg = synth.CONFIGS[args.config]
     k = cfg["k"]
     if k == 6:
@@ -74,6 +68,13 @@ def main():
     if cache and not os.path.exists(cache):
         np.savez(cache, **batch)
     t_gen = time.time() - t0
+
+    # GPU / RCCL initialisation only after the forked generator pool is done
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # nccl == RCCL on ROCm
 
     d = abea.AbeaContext.upload(batch)            # inputs resident in HBM before the arena is sized
     ctx = abea.AbeaContext(model, k, device_id=local_rank, verbosity=0,
