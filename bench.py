@@ -32,6 +32,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline sample duration")
     ap.add_argument("--arena-gib", type=float, default=0.0, help="cap the scratch arena (0 = 90%% of free HBM)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to exercise the N>1 path on one GPU)")
+    ap.add_argument("--one-device", action="store_true", help="testing aid: every rank uses cuda:0 (needs --backend gloo)")
     ap.add_argument("--batch-cache", default="", help="np.savez cache of the generated batch (avoids the forked "
                     "generator pool, e.g. under rocprofv3)")
     args = ap.parse_args()
@@ -70,11 +73,16 @@ def main():
     t_gen = time.time() - t0
 
     # GPU / RCCL initialisation only after the forked generator pool is done
+    if args.one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # nccl == RCCL on ROCm
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # nccl == RCCL on ROCm
+        else:
+            dist.init_process_group("gloo")
 
     d = abea.AbeaContext.upload(batch)            # inputs resident in HBM before the arena is sized
     ctx = abea.AbeaContext(model, k, device_id=local_rank, verbosity=0,
@@ -111,7 +119,8 @@ def main():
     a_min = int(st["bytes_min"]) + 8 * sum_pairs
     stats_vec = torch.tensor([elapsed, float(sum_events), fill_ms, pre_ms, trace_ms, float(launches),
                               float(a_ref), float(a_min), float(len(batch["read_len"])),
-                              float((n_pairs > 0).sum())], dtype=torch.float64, device="cuda")
+                              float((n_pairs > 0).sum())], dtype=torch.float64,
+                             device="cuda" if args.backend == "nccl" else "cpu")
     if dist is not None:
         allv = [torch.zeros_like(stats_vec) for _ in range(world)]
         dist.all_gather(allv, stats_vec)            # the "trivial final gather" over xGMI
