@@ -159,7 +159,8 @@ def main():
                          "algorithmic_bytes_per_launch": int(a_ref_launch),
                          "bytes_per_event_ref": round(a_ref / sum_events, 1),
                          "frac_min_bytes": round(a_min / max(1, st["fill_launches"]) / (fill_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                         "avg_launch_ms": round(fill_avg_ms, 3)},
+                         "avg_launch_ms": round(fill_avg_ms, 3),
+                         "limiter": valu_issue(args.config, sum_events, fill_avg_ms)},
             "gen_s": round(t_gen, 1),
         }
         if world == 1 and not args.no_cpu_baseline:
@@ -177,6 +178,18 @@ def pmc_traffic(config, sum_events):
     try:
         t = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))[config]
         return int(t["hbm_bytes_per_event"] * sum_events)
+    except Exception:
+        return None
+
+
+def valu_issue(config, sum_events, launch_ms):
+    """What actually bounds the kernel: VALU issue.  wave64 VALU instructions per launch (rocprofv3 SQ_INSTS_VALU of
+    the same command, profiles/pmc_traffic.json) x measured issue cost per instruction per SIMD / (1024 SIMDs x time)."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))[config]
+        busy_ms = t["valu_wave_instr_per_event"] * sum_events * t["valu_issue_ns_per_instr"] * 1e-6 / 1024.0
+        return {"unit": "valu-issue", "frac": round(busy_ms / launch_ms, 3),
+                "valu_wave_instr_per_launch": int(t["valu_wave_instr_per_event"] * sum_events)}
     except Exception:
         return None
 
