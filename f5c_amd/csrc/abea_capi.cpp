@@ -27,7 +27,6 @@ static_assert(sizeof(abea_pair_t) == 8, "AlignedPair layout (f5c.h:181)");
 static_assert(sizeof(abea_index_pair_t) == 8, "index_pair_t layout (f5c.h:187)");
 static_assert(sizeof(abea_read_diag) == 40, "abea_read_diag layout");
 static_assert(sizeof(abea_kpar_t) == 16, "kpar layout");
-static_assert(sizeof(abea_fill_out) == 16, "fill_out layout");
 static_assert(sizeof(abea_read_desc) % 16 == 0, "desc alignment");
 
 extern "C" {
@@ -189,7 +188,7 @@ static size_t scratch_bytes(const plan_read& r) {
     const size_t n_groups = (size_t)(r.n_bands + ABEA_GROUP - 1) / ABEA_GROUP;
     return align_up((size_t)r.K * sizeof(abea_kpar_t), 16) + align_up((size_t)r.E * 4 + 256, 16) +
            align_up(((size_t)(r.E + r.K) / 16 + 2) * 4, 16) + n_groups * 64 * sizeof(uint4) +
-           sizeof(abea_fill_out) + sizeof(abea_read_desc);
+           sizeof(abea_read_desc);
 }
 
 static int ensure_pinned(void** p, size_t* cap, size_t need) {
@@ -260,7 +259,7 @@ extern "C" int abea_align_batch_device(abea_ctx* c, const abea_device_batch* B) 
         size_t end = pos, bytes = 4096;
         while (end < seq.size()) {
             const plan_read& r = reads[(size_t)seq[end]];
-            size_t need = r.run ? scratch_bytes(r) : (sizeof(abea_read_desc) + sizeof(abea_fill_out));
+            size_t need = r.run ? scratch_bytes(r) : sizeof(abea_read_desc);
             if (bytes + need + 65536 > c->arena_bytes) break;
             bytes += need; ++end;
         }
@@ -271,7 +270,7 @@ extern "C" int abea_align_batch_device(abea_ctx* c, const abea_device_batch* B) 
         int rc = ensure_pinned((void**)&c->h_desc, &c->h_desc_cap, m * sizeof(abea_read_desc));
         if (rc) return rc;
 
-        /* ---- arena layout: [desc][fout][kpar][evm][codes][trace] ---- */
+        /* ---- arena layout: [desc][kpar][evm][codes][trace] ---- */
         size_t n_kpar = 0, n_evm = 0, n_code = 0, n_trace = 0;
         for (size_t j = 0; j < m; ++j) {
             const plan_read& r = reads[(size_t)seq[pos + j]];
@@ -307,7 +306,6 @@ extern "C" int abea_align_batch_device(abea_ctx* c, const abea_device_batch* B) 
         }
         uint8_t* p = c->arena;
         abea_read_desc* d_desc = (abea_read_desc*)p;        p += align_up(m * sizeof(abea_read_desc), 256);
-        abea_fill_out* d_fout = (abea_fill_out*)p;          p += align_up(m * sizeof(abea_fill_out), 256);
         abea_kpar_t* d_kpar = (abea_kpar_t*)p;              p += align_up(n_kpar * sizeof(abea_kpar_t), 256);
         float* d_evm = (float*)p;                           p += align_up(n_evm * 4 + 512, 256);
         uint32_t* d_codes = (uint32_t*)p;                   p += align_up(n_code * 4, 256);

@@ -35,7 +35,4 @@ typedef struct __attribute__((aligned(16))) {
     double  lp_skip, lp_stay, lp_step, lp_trim;   /* align.c:212-216 */
 } abea_read_desc;
 
-/* What the fill kernel hands to the traceback kernel. */
-typedef struct { float best_score; int32_t best_event; int32_t best_llk; int32_t pad; } abea_fill_out;
-
 #endif

@@ -254,7 +254,7 @@ void abea_align_kernel(const abea_read_desc* __restrict__ descs,
     uint32_t mvacc = 0, mvprev = 0;                     /* band-move bits of this group / the group below */
     int b = 2;
 
-    auto step = [&](auto border_tag) {
+    [[maybe_unused]] auto step = [&](auto border_tag) {   /* reference semantics of one band; the shipped path is the asm below */
         constexpr bool BORDER = decltype(border_tag)::value;
         /* ---- Suzuki-Kasahara move (align.c:304-322): right = ll < ur, alternate when both are -inf ---- */
         const float s_ll = readlane_f(Pf0, 0);
