@@ -14,7 +14,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ABEA_LIB_PATH", os.path.join(_HERE, "libabea_hip.so"))   # override only for kernel A/B experiments
 
 EXPORTS = ["abea_init", "abea_free", "abea_last_error", "abea_align_batch_host",
-           "abea_align_batch_device", "abea_get_stats", "abea_device_info", "abea_selftest"]
+           "abea_align_batch_device", "abea_detect_events_device", "abea_get_stats", "abea_device_info",
+           "abea_selftest"]
 SHIM_EXPORTS = ["abea_f5c_init", "abea_f5c_align", "abea_f5c_free"]      # include/abea_f5c_shim.h
 
 
@@ -45,9 +46,16 @@ class _DevBatch(C.Structure):
                 ("min_num_events_to_rescale", C.c_int32), ("reserved", C.c_int32)]
 
 
+class _SigBatch(C.Structure):
+    _fields_ = [("n_reads", C.c_int32), ("sig_ptr", C.c_void_p), ("n_samples", C.c_void_p), ("scaling", C.c_void_p),
+                ("event_ptr", C.c_void_p), ("event_cap", C.c_void_p), ("read_ptr", C.c_void_p), ("read_len", C.c_void_p),
+                ("signal", C.c_void_p), ("reads", C.c_void_p), ("events", C.c_void_p), ("n_events", C.c_void_p),
+                ("scalings", C.c_void_p)]
+
+
 class Stats(C.Structure):
     _fields_ = [("pre_ms", C.c_double), ("fill_ms", C.c_double), ("trace_ms", C.c_double),
-                ("h2d_ms", C.c_double), ("d2h_ms", C.c_double), ("host_ms", C.c_double),
+                ("h2d_ms", C.c_double), ("d2h_ms", C.c_double), ("host_ms", C.c_double), ("event_ms", C.c_double),
                 ("total_ms", C.c_double),
                 ("n_reads_gpu", C.c_int64), ("n_reads_skipped", C.c_int64), ("n_sub_batches", C.c_int64),
                 ("sum_events", C.c_int64), ("sum_bands", C.c_int64), ("sum_pairs", C.c_int64),
@@ -86,6 +94,8 @@ def load_library():
         L.abea_align_batch_host.argtypes = [C.c_void_p, C.POINTER(_HostBatch)]
         L.abea_align_batch_device.restype = C.c_int
         L.abea_align_batch_device.argtypes = [C.c_void_p, C.POINTER(_DevBatch)]
+        L.abea_detect_events_device.restype = C.c_int
+        L.abea_detect_events_device.argtypes = [C.c_void_p, C.POINTER(_SigBatch)]
         L.abea_get_stats.restype = C.c_int
         L.abea_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
         L.abea_device_info.restype = C.c_int
@@ -227,6 +237,41 @@ class AbeaContext:
                        dbatch["reads"].data_ptr(), dbatch["events"].data_ptr(), dbatch["pairs"].data_ptr(),
                        dbatch["n_pairs"].data_ptr(), dbatch["diag"].data_ptr() if want_diag else None, *sc)
         self._chk(self._lib.abea_align_batch_device(self._h, C.byref(db)), "abea_align_batch_device")
+
+    def detect_events_device(self, signals, scaling, seqs=None, cap_div=4):
+        """Row N2: raw ADC signals -> event tables (+ method-of-moments scalings when `seqs` is given) on the
+        device. signals: list of int16 arrays; scaling: float32 [n,3] (offset, range, digitisation).
+        Returns (list of EVENT_DT arrays, n_events int32[n], scalings SCAL_DT[n] or None)."""
+        import torch
+        dev = torch.device("cuda", torch.cuda.current_device())
+        n = len(signals)
+        ns = np.array([len(s) for s in signals], dtype=np.int32)
+        sig_ptr = np.concatenate([[0], np.cumsum(ns.astype(np.int64))[:-1]]).astype(np.int64)
+        cap = (ns // cap_div + 16).astype(np.int32)
+        ev_ptr = np.concatenate([[0], np.cumsum(cap.astype(np.int64))[:-1]]).astype(np.int64)
+        d_sig = torch.from_numpy(np.concatenate(signals).astype(np.int16)).to(dev)
+        d_ev = torch.zeros(int(cap.sum()) * EVENT_DT.itemsize, dtype=torch.uint8, device=dev)
+        d_ne = torch.zeros(n, dtype=torch.int32, device=dev)
+        sc = np.ascontiguousarray(scaling, dtype=np.float32).reshape(n, 3)
+        d_reads = d_scal = None
+        rp = rl = None
+        if seqs is not None:
+            rl = np.array([len(s) for s in seqs], dtype=np.int32)
+            rp = np.concatenate([[0], np.cumsum(rl.astype(np.int64) + 1)[:-1]]).astype(np.int64)
+            flat = np.zeros(int((rl.astype(np.int64) + 1).sum()), dtype=np.uint8)
+            for i, s in enumerate(seqs):
+                flat[rp[i]:rp[i] + rl[i]] = np.frombuffer(s, dtype=np.uint8)
+            d_reads = torch.from_numpy(flat).to(dev)
+            d_scal = torch.zeros(n * SCAL_DT.itemsize, dtype=torch.uint8, device=dev)
+        sb = _SigBatch(n, _p(sig_ptr), _p(ns), _p(sc), _p(ev_ptr), _p(cap), _p(rp) if rp is not None else None,
+                       _p(rl) if rl is not None else None, d_sig.data_ptr(),
+                       d_reads.data_ptr() if d_reads is not None else None, d_ev.data_ptr(), d_ne.data_ptr(),
+                       d_scal.data_ptr() if d_scal is not None else None)
+        self._chk(self._lib.abea_detect_events_device(self._h, C.byref(sb)), "abea_detect_events_device")
+        ne = d_ne.cpu().numpy()
+        allev = d_ev.cpu().numpy().view(EVENT_DT)
+        evs = [allev[ev_ptr[i]:ev_ptr[i] + min(ne[i], cap[i])] for i in range(n)]
+        return evs, ne, (d_scal.cpu().numpy().view(SCAL_DT) if d_scal is not None else None)
 
     @staticmethod
     def download_scaling(dbatch):

@@ -36,6 +36,9 @@ __global__ void abea_pre_kernel(const abea_read_desc*, const char*, const abea_e
 __global__ void abea_scaling_kernel(const abea_read_desc*, const char*, const abea_model_t*, int, const float*,
                                     const abea_pair_t*, const int32_t*, abea_index_pair_t*, abea_scalings_t*, double*,
                                     int32_t*, int32_t*, int);
+__global__ void abea_event_kernel(int, const int32_t*, const int16_t*, const int64_t*, const int32_t*, const float*,
+                                  abea_event_t*, const int64_t*, const int32_t*, int32_t*, const char*, const int64_t*,
+                                  const int32_t*, const abea_model_t*, int, abea_scalings_t*);
 __global__ void abea_align_kernel(const abea_read_desc*, const float*, const abea_kpar_t*, uint4*, uint32_t*,
                                   abea_pair_t*, int32_t*, abea_read_diag*);
 }
@@ -344,6 +347,51 @@ extern "C" int abea_align_batch_device(abea_ctx* c, const abea_device_batch* B) 
         fprintf(stderr, "[abea] %lld reads on GPU, %lld skipped, %lld sub-batch(es): pre %.3f ms fill %.3f ms post %.3f ms\n",
                 (long long)st.n_reads_gpu, (long long)st.n_reads_skipped, (long long)st.n_sub_batches,
                 st.pre_ms, st.fill_ms, st.trace_ms);
+    return ABEA_OK;
+}
+
+/* ------------------------------------------------------------------ raw signal -> events (row N2) */
+extern "C" int abea_detect_events_device(abea_ctx* c, const abea_signal_batch* B) {
+    if (!c || !B) return fail(ABEA_EINVAL, "null argument");
+    const int32_t n = B->n_reads;
+    if (n < 0) return fail(ABEA_EINVAL, "n_reads < 0");
+    if (n == 0) return ABEA_OK;
+    if (!B->sig_ptr || !B->n_samples || !B->scaling || !B->event_ptr || !B->event_cap || !B->signal || !B->events ||
+        !B->n_events)
+        return fail(ABEA_EINVAL, "abea_detect_events_device: null array");
+    if (B->scalings && (!B->reads || !B->read_ptr || !B->read_len))
+        return fail(ABEA_EINVAL, "abea_detect_events_device: scalings need the read sequences");
+    HIP_TRY(hipSetDevice(c->device));
+    /* lane-per-read kernel: order reads by length so that the 64 reads of a wavefront finish together */
+    std::vector<int32_t> order((size_t)n);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return B->n_samples[a] > B->n_samples[b]; });
+    /* index arrays go through the arena: [order][sig_ptr][n_samples][scaling][event_ptr][event_cap][read_ptr][read_len] */
+    const size_t N = (size_t)n;
+    const size_t bytes = N * (4 + 8 + 4 + 12 + 8 + 4 + 8 + 4) + 1024;
+    if (bytes > c->arena_bytes) return fail(ABEA_ENOMEM, "arena too small for %d index records", n);
+    int rc = ensure_pinned((void**)&c->h_desc, &c->h_desc_cap, bytes);
+    if (rc) return rc;
+    uint8_t* h = (uint8_t*)c->h_desc; uint8_t* d = c->arena;
+    size_t o = 0;
+    auto put = [&](const void* src, size_t sz) { size_t at = o; if (src) memcpy(h + o, src, sz); else memset(h + o, 0, sz);
+                                                 o = align_up(o + sz, 16); return at; };
+    const size_t o_order = put(order.data(), N * 4), o_sig = put(B->sig_ptr, N * 8), o_ns = put(B->n_samples, N * 4);
+    const size_t o_sc = put(B->scaling, N * 12), o_ep = put(B->event_ptr, N * 8), o_ec = put(B->event_cap, N * 4);
+    const size_t o_rp = put(B->read_ptr, N * 8), o_rl = put(B->read_len, N * 4);
+    HIP_TRY(hipMemcpyAsync(d, h, o, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipEventRecord(c->ev[0], c->stream));
+    hipLaunchKernelGGL(abea_event_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, c->stream,
+                       n, (const int32_t*)(d + o_order), B->signal, (const int64_t*)(d + o_sig), (const int32_t*)(d + o_ns),
+                       (const float*)(d + o_sc), B->events, (const int64_t*)(d + o_ep), (const int32_t*)(d + o_ec),
+                       B->n_events, B->reads, (const int64_t*)(d + o_rp), (const int32_t*)(d + o_rl), c->d_model,
+                       (int)c->k, B->scalings);
+    HIP_TRY(hipEventRecord(c->ev[1], c->stream));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
+    c->stats.event_ms = ms;
     return ABEA_OK;
 }
 

@@ -719,3 +719,160 @@ void abea_scaling_kernel(const abea_read_desc* __restrict__ descs, const char* _
         flag_io[out_idx] |= flag;
     }
 }
+
+
+/* ================================================================ event detection on the device (row N2)
+ * event_single's front half (f5c.c:682-712): ADC -> pA, getevents() (events.c:562-582 = detect_events on the
+ * whole signal; the trim result there is discarded) and estimate_scalings_using_mom (align.c:58-106).
+ * Everything in it is order-dependent floating point (sequential fp64 prefix sums, a two-detector peak-picking
+ * automaton), so it is restated as ONE streaming pass per read with O(1) state, executed lane-per-read in the
+ * reference's exact operation order; nothing is re-associated, so events come out bit-identical.
+ *   - prefix sums S, Q are carried in registers; the last 16 are kept in an LDS ring laid out [slot][lane]
+ *     (conflict-free) because the windowed t-statistics at position p need S[p-6], S[p-3], S[p], S[p+3], S[p+6];
+ *   - both detectors run at position p = i-5 (the delay of the 6-wide window);
+ *   - an event is emitted the moment a detector fires, from the prefix sums saved when its peak was set. */
+struct abea_evdet {
+    float peak_value; int peak_pos; long long masked_to; bool valid; double s_pk, q_pk;
+};
+
+static __device__ __forceinline__ float abea_tstat(double s_lo, double s_mid, double s_hi, double q_lo, double q_mid,
+                                                   double q_hi, float wf) {
+    /* events.c:343-366 */
+    const double sum1 = s_mid - s_lo, sumsq1 = q_mid - q_lo;
+    const float sum2 = (float)(s_hi - s_mid);
+    const float sumsq2 = (float)(q_hi - q_mid);
+    const float mean1 = (float)(sum1 / (double)wf);
+    const float mean2 = sum2 / wf;
+    float combined_var = (float)(((sumsq1 / (double)wf - (double)(mean1 * mean1)) + (double)(sumsq2 / wf)) -
+                                 (double)(mean2 * mean2));
+    combined_var = fmaxf(combined_var, 1.17549435e-38f);            /* FLT_MIN */
+    const float delta_mean = mean2 - mean1;
+    return fabsf(delta_mean) / sqrtf(combined_var / wf);
+}
+
+extern "C" __global__ __launch_bounds__(64)
+void abea_event_kernel(int n_reads, const int32_t* __restrict__ order,
+                       const int16_t* __restrict__ signal, const int64_t* __restrict__ sig_ptr,
+                       const int32_t* __restrict__ n_samples, const float* __restrict__ scaling /* [n][3] offset,range,digitisation */,
+                       abea_event_t* __restrict__ events, const int64_t* __restrict__ event_ptr,
+                       const int32_t* __restrict__ event_cap, int32_t* __restrict__ n_events,
+                       const char* __restrict__ reads, const int64_t* __restrict__ read_ptr,
+                       const int32_t* __restrict__ read_len, const abea_model_t* __restrict__ model, int kmer_size,
+                       abea_scalings_t* __restrict__ scalings) {
+    __shared__ double ring[2][16][64];                   /* [S|Q][slot][lane] */
+    const int lane = threadIdx.x;
+    const int slot = blockIdx.x * 64 + lane;
+    if (slot >= n_reads) return;
+    const int r = order[slot];
+    const int n = n_samples[r];
+    const int16_t* __restrict__ sig = signal + sig_ptr[r];
+    abea_event_t* __restrict__ ev = events + event_ptr[r];
+    const int cap = event_cap[r];
+    const float offset = scaling[3 * r], range = scaling[3 * r + 1], digitisation = scaling[3 * r + 2];
+    const float raw_unit = range / digitisation;                    /* f5c.c:693 */
+    if (n <= 0) { n_events[r] = 0; return; }
+
+    abea_evdet det[2];
+    for (int k = 0; k < 2; ++k) {
+        det[k].peak_value = 3.402823466e+38f; det[k].peak_pos = -1; det[k].masked_to = 0; det[k].valid = false;
+        det[k].s_pk = 0; det[k].q_pk = 0;
+    }
+    const float thr[2] = {1.4f, 9.0f};                               /* events.c:52-56, DNA */
+    const int win[2] = {3, 6};
+    const float peak_height = 0.2f;
+    const bool t1_on = !(n < 6), t2_on = !(n < 12);                  /* d_length < 2*w -> all zeros */
+
+    double S = 0.0, Q = 0.0;                                         /* S[i], Q[i]: sums up to but excluding i */
+    ring[0][0][lane] = 0.0; ring[1][0][lane] = 0.0;                  /* S[0] = Q[0] = 0 */
+    unsigned long long last_pos = 0; double s_last = 0.0, q_last = 0.0;
+    int n_ev = 0;
+    double ev_sum = 0.0;                                             /* align.c:68-71, event order */
+
+    auto emit_event = [&](unsigned long long end, double s_end, double q_end) {   /* events.c:466-486 */
+        const float length = (float)(end - last_pos);
+        const float mean = (float)(s_end - s_last) / length;
+        const float deltasqr = (float)(q_end - q_last);
+        const float var = deltasqr / length - mean * mean;
+        if (n_ev < cap) {
+            abea_event_t e; e.start = last_pos; e.length = length; e.mean = mean; e.stdv = sqrtf(fmaxf(var, 0.0f));
+            ev[n_ev] = e;
+        }
+        ev_sum += mean;
+        ++n_ev;
+        last_pos = end; s_last = s_end; q_last = q_end;
+    };
+
+    auto detect_at = [&](int p) {                                    /* events.c:380-452 at position p */
+        const double s_mid = ring[0][p & 15][lane], q_mid = ring[1][p & 15][lane];
+        float ts[2] = {0.f, 0.f};
+        if (t1_on && p >= 3 && p <= n - 3)
+            ts[0] = abea_tstat(ring[0][(p - 3) & 15][lane], s_mid, ring[0][(p + 3) & 15][lane],
+                               ring[1][(p - 3) & 15][lane], q_mid, ring[1][(p + 3) & 15][lane], 3.0f);
+        if (t2_on && p >= 6 && p <= n - 6)
+            ts[1] = abea_tstat(ring[0][(p - 6) & 15][lane], s_mid, ring[0][(p + 6) & 15][lane],
+                               ring[1][(p - 6) & 15][lane], q_mid, ring[1][(p + 6) & 15][lane], 6.0f);
+        #pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            abea_evdet& d = det[k];
+            if (d.masked_to >= (long long)p) continue;
+            const float cur = ts[k];
+            if (d.peak_pos == -1) {
+                if (cur < d.peak_value) {
+                    d.peak_value = cur;
+                } else if (cur - d.peak_value > peak_height) {
+                    d.peak_value = cur; d.peak_pos = p; d.s_pk = s_mid; d.q_pk = q_mid;
+                }
+            } else {
+                if (cur > d.peak_value) { d.peak_value = cur; d.peak_pos = p; d.s_pk = s_mid; d.q_pk = q_mid; }
+                if (k == 0) {
+                    if (d.peak_value > thr[0]) {
+                        det[1].masked_to = (long long)d.peak_pos + win[0];
+                        det[1].peak_pos = -1; det[1].peak_value = 3.402823466e+38f; det[1].valid = false;
+                    }
+                }
+                if (d.peak_value - cur > peak_height && d.peak_value > thr[k]) d.valid = true;
+                if (d.valid && (unsigned long long)(p - d.peak_pos) > (unsigned long long)(win[k] / 2)) {
+                    emit_event((unsigned long long)d.peak_pos, d.s_pk, d.q_pk);
+                    d.peak_pos = -1; d.peak_value = cur; d.valid = false;
+                }
+            }
+        }
+    };
+
+    for (int i = 0; i < n; ++i) {
+        const float x = ((float)sig[i] + offset) * raw_unit;         /* f5c.c:694-696 */
+        S = S + (double)x;                                           /* events.c:309-312; the square is a float product */
+        Q = Q + (double)(x * x);
+        ring[0][(i + 1) & 15][lane] = S; ring[1][(i + 1) & 15][lane] = Q;
+        const int p = i - 5;                                         /* S[p+6] just became available */
+        if (p >= 0) detect_at(p);
+    }
+    for (int p = max(n - 5, 0); p < n; ++p) detect_at(p);            /* tail: the 6-wide statistic is 0 there */
+    emit_event((unsigned long long)n, S, Q);                         /* last event ends at nsample (events.c:509-511) */
+    n_events[r] = n_ev;
+
+    /* ---- estimate_scalings_using_mom (align.c:58-106) ---- */
+    if (scalings) {
+        const int L = read_len[r];
+        const int K = L - kmer_size + 1;
+        const char* __restrict__ seq = reads + read_ptr[r];
+        double km_sum = 0.0, km_sq = 0.0;
+        for (int i = 0; i < K; ++i) {
+            uint32_t rank = 0;
+            for (int j = 0; j < kmer_size; ++j) rank = (rank << 2) | base_code(seq[i + j]);
+            const double l = model[rank].level_mean;
+            km_sum += l;
+            km_sq += l * l;
+        }
+        const int ne = min(n_ev, cap);
+        const double shift = ev_sum / n_ev - km_sum / K;
+        double ev_sq = 0.0;
+        for (int i = 0; i < ne; ++i) {
+            const double m = (double)ev[i].mean;
+            ev_sq += (m - shift) * (m - shift);
+        }
+        const double scale = (ev_sq / n_ev) / (km_sq / K);
+        abea_scalings_t o; o.shift = (float)shift; o.scale = (float)scale; o.var = 1.0f; o.log_var = 0.0f;
+        scalings[r] = o;
+    }
+}

@@ -221,3 +221,19 @@ def take_reads(batch, idx):
         "pair_ptr": np.concatenate([[0], np.cumsum(cap)[:-1]]).astype(np.int64) if n else np.zeros(0, np.int64),
         "pair_cap": int(cap.sum()), "bad": batch["bad"][idx].copy(),
     }
+
+
+def make_signals(batch, seed=0, offset=10.0, rng_pa=1467.61, digitisation=8192.0):
+    """Raw int16 ADC signals for the reads of a batch: each event contributes `length` samples drawn around its
+    mean (so event detection has something real to find). Returns (list of int16 arrays, float32 [n,3] scaling)."""
+    r = np.random.default_rng([seed, 0x516])
+    raw_unit = np.float32(rng_pa) / np.float32(digitisation)
+    sigs = []
+    for i in range(len(batch["read_len"])):
+        s, E = int(batch["event_ptr"][i]), int(batch["n_events"][i])
+        ev = batch["events"][s:s + E]
+        ln = ev["length"].astype(np.int64)
+        pa = np.repeat(ev["mean"].astype(np.float64), ln) + r.normal(0.0, 1.2, int(ln.sum()))
+        sigs.append(np.clip(np.rint(pa / raw_unit - offset), -32768, 32767).astype(np.int16))
+    sc = np.tile(np.array([offset, rng_pa, digitisation], dtype=np.float32), (len(sigs), 1))
+    return sigs, sc

@@ -123,11 +123,33 @@ typedef struct {
 /* Same computation with inputs/outputs already in HBM (what bench.py times). Synchronous. */
 int abea_align_batch_device(abea_ctx* ctx, const abea_device_batch* batch);
 
+/* ---- raw-signal batch: the front half of event_single() on the device (src/f5c.c:682-712; row N2) ----
+ * ADC samples -> pA -> getevents() (src/events.c:562-582) -> estimate_scalings_using_mom() (src/align.c:58-106).
+ * Index / scaling arrays are HOST pointers, bulk arrays DEVICE pointers.  Events of read i are written at
+ * events[event_ptr[i] ...] up to event_cap[i] entries; n_events[i] is the true count (> cap means truncated). */
+typedef struct {
+    int32_t n_reads;
+    const int64_t* sig_ptr;        /* HOST: offset of read i in `signal` (samples) */
+    const int32_t* n_samples;      /* HOST: db->sig[i]->nsample */
+    const float*   scaling;        /* HOST [n_reads][3]: offset, range, digitisation (signal_t, src/f5c.h:276-286) */
+    const int64_t* event_ptr;      /* HOST */
+    const int32_t* event_cap;      /* HOST */
+    const int64_t* read_ptr;       /* HOST: offset of read i in `reads` (for the scalings); may be NULL with scalings */
+    const int32_t* read_len;       /* HOST */
+    const int16_t* signal;         /* DEVICE: raw ADC samples */
+    const char*    reads;          /* DEVICE: flattened sequences (NULL = no scalings) */
+    abea_event_t*  events;         /* DEVICE out */
+    int32_t*       n_events;       /* DEVICE out [n_reads] */
+    abea_scalings_t* scalings;     /* DEVICE out [n_reads] (scale, shift, var = 1), optional */
+} abea_signal_batch;
+int abea_detect_events_device(abea_ctx* ctx, const abea_signal_batch* batch);
+
 /* ---- timing / accounting of the last batch (core_t timing fields, src/f5c.h:457-466) ---- */
 typedef struct {
     double pre_ms, fill_ms, trace_ms;     /* HIP-event kernel times on the library's stream, summed over sub-batches
                                              (fill = fused fill+traceback kernel, trace = optional scaling kernel) */
     double h2d_ms, d2h_ms, host_ms;       /* host batch only */
+    double event_ms;                      /* abea_detect_events_device: kernel time of the last call */
     double total_ms;                      /* wall time of the call */
     int64_t n_reads_gpu, n_reads_skipped, n_sub_batches;
     int64_t sum_events, sum_bands, sum_pairs;

@@ -70,3 +70,58 @@ def test_gpu_bit_exact_on_real_signal_reads(ctx, orc, r9):
         s = int(batch["pair_ptr"][i])
         assert (pairs[s:s + o_n[i]] == o_pairs[s:s + o_n[i]]).all()
     assert np.allclose(diag["sum_emission"], o_diag["sum_emission"], rtol=0, atol=1e-4)
+
+
+@pytest.mark.gpu
+def test_gpu_event_detection_bit_exact(ctx, orc, r9):
+    """Row N2: raw ADC signal -> events + method-of-moments scalings on the device, bit-exact against the oracle's
+    event detection (itself pinned to est_scalings.exp / adaptive.exp), on real reads and synthetic signals."""
+    from f5c_amd import synth
+    k, model = r9
+    reads = list(_reads())
+    sigs = [r["sig"] for r in reads]
+    scal = np.array([[r["offset"], r["range"], r["digitisation"]] for r in reads], dtype=np.float32)
+    seqs = [r["seq"] for r in reads]
+    b = synth.make_batch(40, model, k, seed=91, law=1500, bad_frac=0.0)
+    s_sigs, s_scal = synth.make_signals(b, seed=3)
+    for i in range(40):
+        s, L = int(b["read_ptr"][i]), int(b["read_len"][i])
+        seqs.append(b["reads"][s:s + L].tobytes())
+    sigs += s_sigs
+    scal = np.concatenate([scal, s_scal])
+    evs, ne, sc = ctx.detect_events_device(sigs, scal, seqs=seqs)
+    for i, sig in enumerate(sigs):
+        o_ev, _ = orc.getevents(sig, scal[i, 0], scal[i, 1], scal[i, 2])
+        assert ne[i] == len(o_ev), (i, ne[i], len(o_ev))
+        for f in ("start", "length", "mean", "stdv"):
+            assert (evs[i][f] == o_ev[f]).all(), (i, f)
+        scale, shift = orc.estimate_scalings(seqs[i], model, k, o_ev)
+        assert sc["scale"][i] == np.float32(scale) and sc["shift"][i] == np.float32(shift)
+    # the printed est_scalings.exp lines of the real reads come out of the device path too
+    for i, r in enumerate(reads):
+        assert "%.2f %.2f" % (sc["shift"][i], sc["scale"][i]) == r["est"]
+    assert 5 < np.mean([len(s) / max(1, n) for s, n in zip(sigs, ne)]) < 15     # ~10 samples per event
+
+
+@pytest.mark.gpu
+def test_gpu_raw_signal_to_recalibrated_scalings(ctx, orc, r9):
+    """Whole device chain on real reads: raw signal -> events -> scalings -> ABEA -> scaling_single; the printed
+    recalib_scalings.exp / adaptive.exp values of the reference come out of the GPU."""
+    from f5c_amd import synth
+    k, model = r9
+    reads = list(_reads())
+    evs, ne, sc = ctx.detect_events_device([r["sig"] for r in reads],
+                                           np.array([[r["offset"], r["range"], r["digitisation"]] for r in reads]),
+                                           seqs=[r["seq"] for r in reads])
+    batch = synth.batch_from_reads([r["seq"] for r in reads], [e.copy() for e in evs],
+                                   [(sc["scale"][i], sc["shift"][i]) for i in range(len(reads))])
+    d = ctx.upload(batch)
+    ctx.align_db_device(d, scaling=True)
+    _, n_pairs, diag = ctx.download(d)
+    _, rsc, _, flags, _ = ctx.download_scaling(d)
+    for i, r in enumerate(reads):
+        gsum, gn = r["ada"].split()
+        assert n_pairs[i] == int(gn)
+        assert abs(diag["sum_emission"][i] - float(gsum)) <= 1e-6 * abs(float(gsum)) + 1e-6
+        assert "%.2f %.2f %.2f" % (rsc["shift"][i], rsc["scale"][i], rsc["var"][i]) == r["rec"]
+        assert flags[i] == 0
