@@ -839,14 +839,32 @@ void abea_event_kernel(int n_reads, const int32_t* __restrict__ order,
         }
     };
 
-    for (int i = 0; i < n; ++i) {
-        const float x = ((float)sig[i] + offset) * raw_unit;         /* f5c.c:694-696 */
+    auto sample = [&](int i, int raw) {
+        const float x = ((float)raw + offset) * raw_unit;            /* f5c.c:694-696 */
         S = S + (double)x;                                           /* events.c:309-312; the square is a float product */
         Q = Q + (double)(x * x);
         ring[0][(i + 1) & 15][lane] = S; ring[1][(i + 1) & 15][lane] = Q;
         const int p = i - 5;                                         /* S[p+6] just became available */
         if (p >= 0) detect_at(p);
+    };
+    /* samples are fetched 8 at a time (16 B per lane), the next chunk one iteration ahead: a per-sample load
+     * would put a full memory latency on every step of this sequential loop */
+    int i = 0;
+    const int head = min(n, (int)(((16u - ((uintptr_t)sig & 15u)) & 15u) >> 1));
+    for (; i < head; ++i) sample(i, sig[i]);
+    if (i + 8 <= n) {
+        uint4 nxt = *reinterpret_cast<const uint4*>(sig + i);
+        while (i + 8 <= n) {
+            const uint4 cur = nxt;
+            if (i + 16 <= n) nxt = *reinterpret_cast<const uint4*>(sig + i + 8);
+            sample(i + 0, (int)(short)(cur.x & 0xffffu)); sample(i + 1, (int)(short)(cur.x >> 16));
+            sample(i + 2, (int)(short)(cur.y & 0xffffu)); sample(i + 3, (int)(short)(cur.y >> 16));
+            sample(i + 4, (int)(short)(cur.z & 0xffffu)); sample(i + 5, (int)(short)(cur.z >> 16));
+            sample(i + 6, (int)(short)(cur.w & 0xffffu)); sample(i + 7, (int)(short)(cur.w >> 16));
+            i += 8;
+        }
     }
+    for (; i < n; ++i) sample(i, sig[i]);
     for (int p = max(n - 5, 0); p < n; ++p) detect_at(p);            /* tail: the 6-wide statistic is 0 there */
     emit_event((unsigned long long)n, S, Q);                         /* last event ends at nsample (events.c:509-511) */
     n_events[r] = n_ev;

@@ -1,0 +1,24 @@
+#!/usr/bin/env python3
+"""Throughput of the device event-detection kernel (row N2) next to the oracle's CPU getevents."""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from f5c_amd import abea, synth, load_model_f32
+from oracle import orc
+k, model = load_model_f32("tests/golden/r9.4_450bps.6mer.f32")
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
+b = synth.make_batch(n, model, k, seed=20250002, law="gamma8k", workers=16)
+sigs, sc = synth.make_signals(b, seed=1)
+seqs = [b["reads"][int(b["read_ptr"][i]):int(b["read_ptr"][i]) + int(b["read_len"][i])].tobytes() for i in range(n)]
+ns = sum(len(s) for s in sigs)
+ctx = abea.AbeaContext(model, k, max_arena_bytes=8 << 30)
+for rep in range(2):
+    evs, ne, scal = ctx.detect_events_device(sigs, sc, seqs=seqs)
+    ms = ctx.stats()["event_ms"]
+    print(f"device: {n} reads, {ns/1e6:.1f} Msamples, {int(ne.sum())/1e6:.2f} Mevents: kernel {ms:.2f} ms = {ns/ms/1e3:.1f} Msamples/s, {ne.sum()/ms/1e3:.1f} Mevents/s")
+t0 = time.perf_counter()
+m = 0
+for i in range(0, n, max(1, n // 16)):
+    orc.getevents(sigs[i], *sc[i]); m += len(sigs[i])
+t = time.perf_counter() - t0
+print(f"oracle getevents, 1 thread: {m/t/1e6:.1f} Msamples/s")
