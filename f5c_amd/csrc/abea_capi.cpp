@@ -36,9 +36,18 @@ __global__ void abea_pre_kernel(const abea_read_desc*, const char*, const abea_e
 __global__ void abea_scaling_kernel(const abea_read_desc*, const char*, const abea_model_t*, int, const float*,
                                     const abea_pair_t*, const int32_t*, abea_index_pair_t*, abea_scalings_t*, double*,
                                     int32_t*, int32_t*, int);
-__global__ void abea_event_kernel(int, const int32_t*, const int16_t*, const int64_t*, const int32_t*, const float*,
-                                  abea_event_t*, const int64_t*, const int32_t*, int32_t*, const char*, const int64_t*,
-                                  const int32_t*, const abea_model_t*, int, abea_scalings_t*);
+__global__ void abea_ev_sums_kernel(int, const int32_t*, const int16_t*, const int64_t*, const int32_t*, const float*,
+                                    const int64_t*, double*, double*);
+__global__ void abea_ev_tstat_kernel(int, const int32_t*, const int32_t*, const int64_t*, const int32_t*, const double*,
+                                     const double*, float*, float*);
+__global__ void abea_ev_detect_kernel(int, const int32_t*, const int32_t*, const int64_t*, const float*, const float*,
+                                      const int64_t*, const int32_t*, int32_t*, int32_t*);
+__global__ void abea_ev_create_kernel(int, const int32_t*, const int32_t*, const int64_t*, const double*, const double*,
+                                      const int64_t*, const int32_t*, const int32_t*, const int32_t*, const int32_t*,
+                                      abea_event_t*, const int64_t*, float*);
+__global__ void abea_ev_scalings_kernel(int, const int32_t*, const int64_t*, const float*, const int32_t*,
+                                        const int32_t*, const char*, const int64_t*, const int32_t*,
+                                        const abea_model_t*, int, abea_scalings_t*);
 __global__ void abea_align_kernel(const abea_read_desc*, const float*, const abea_kpar_t*, uint4*, uint32_t*,
                                   abea_pair_t*, int32_t*, abea_read_diag*);
 }
@@ -362,36 +371,84 @@ extern "C" int abea_detect_events_device(abea_ctx* c, const abea_signal_batch* B
     if (B->scalings && (!B->reads || !B->read_ptr || !B->read_len))
         return fail(ABEA_EINVAL, "abea_detect_events_device: scalings need the read sequences");
     HIP_TRY(hipSetDevice(c->device));
-    /* lane-per-read kernel: order reads by length so that the 64 reads of a wavefront finish together */
+    /* lane-per-read passes: order reads by length so that the 64 reads of a wavefront finish together */
     std::vector<int32_t> order((size_t)n);
     std::iota(order.begin(), order.end(), 0);
     std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return B->n_samples[a] > B->n_samples[b]; });
-    /* index arrays go through the arena: [order][sig_ptr][n_samples][scaling][event_ptr][event_cap][read_ptr][read_len] */
     const size_t N = (size_t)n;
-    const size_t bytes = N * (4 + 8 + 4 + 12 + 8 + 4 + 8 + 4) + 1024;
-    if (bytes > c->arena_bytes) return fail(ABEA_ENOMEM, "arena too small for %d index records", n);
-    int rc = ensure_pinned((void**)&c->h_desc, &c->h_desc_cap, bytes);
-    if (rc) return rc;
-    uint8_t* h = (uint8_t*)c->h_desc; uint8_t* d = c->arena;
-    size_t o = 0;
-    auto put = [&](const void* src, size_t sz) { size_t at = o; if (src) memcpy(h + o, src, sz); else memset(h + o, 0, sz);
-                                                 o = align_up(o + sz, 16); return at; };
-    const size_t o_order = put(order.data(), N * 4), o_sig = put(B->sig_ptr, N * 8), o_ns = put(B->n_samples, N * 4);
-    const size_t o_sc = put(B->scaling, N * 12), o_ep = put(B->event_ptr, N * 8), o_ec = put(B->event_cap, N * 4);
-    const size_t o_rp = put(B->read_ptr, N * 8), o_rl = put(B->read_len, N * 4);
-    HIP_TRY(hipMemcpyAsync(d, h, o, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipEventRecord(c->ev[0], c->stream));
-    hipLaunchKernelGGL(abea_event_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, c->stream,
-                       n, (const int32_t*)(d + o_order), B->signal, (const int64_t*)(d + o_sig), (const int32_t*)(d + o_ns),
-                       (const float*)(d + o_sc), B->events, (const int64_t*)(d + o_ep), (const int32_t*)(d + o_ec),
-                       B->n_events, B->reads, (const int64_t*)(d + o_rp), (const int32_t*)(d + o_rl), c->d_model,
-                       (int)c->k, B->scalings);
-    HIP_TRY(hipEventRecord(c->ev[1], c->stream));
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    float ms = 0;
-    HIP_TRY(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
-    c->stats.event_ms = ms;
+    const int n_waves_all = (n + 63) / 64;
+    c->stats.event_ms = 0;
+    int w0 = 0;
+    while (w0 < n_waves_all) {
+        /* ---- carve waves whose interleaved scratch fits the arena: per sample S,Q fp64 + two float t-statistics
+         *      (24 B), per event slot a peak position + a mean (8 B) ---- */
+        const size_t idx_bytes = N * (4 + 8 + 4 + 12 + 8 + 4 + 8 + 4) + (size_t)n_waves_all * 24 + 4096;
+        if (idx_bytes + (1u << 20) > c->arena_bytes) return fail(ABEA_ENOMEM, "arena too small for %d index records", n);
+        const size_t budget = c->arena_bytes - idx_bytes - 4096;
+        std::vector<int64_t> wave_base, peak_base; std::vector<int32_t> wave_len, wave_cap;
+        size_t entries = 0, pentries = 0;
+        int w1 = w0;
+        while (w1 < n_waves_all) {
+            const int32_t len = B->n_samples[order[(size_t)w1 * 64]] + 1;      /* longest read of the wave, +1 for S[n] */
+            int32_t cap = 1;
+            for (int q = w1 * 64; q < std::min(n, (w1 + 1) * 64); ++q) cap = std::max(cap, B->event_cap[order[(size_t)q]]);
+            const size_t need = (size_t)std::max(len, 1) * 64, pneed = (size_t)cap * 64;
+            if ((entries + need) * 24 + (pentries + pneed) * 8 > budget) break;
+            wave_base.push_back((int64_t)entries); wave_len.push_back(len);
+            peak_base.push_back((int64_t)pentries); wave_cap.push_back(cap);
+            entries += need; pentries += pneed; ++w1;
+        }
+        if (w1 == w0) return fail(ABEA_ENOMEM, "a read of %d samples does not fit the %zu-byte arena",
+                                  B->n_samples[order[(size_t)w0 * 64]], c->arena_bytes);
+        const int nw = w1 - w0;
+        const int r0 = w0 * 64, nr = std::min(n - r0, nw * 64);
+        int rc = ensure_pinned((void**)&c->h_desc, &c->h_desc_cap, idx_bytes);
+        if (rc) return rc;
+        uint8_t* h = (uint8_t*)c->h_desc; uint8_t* d = c->arena;
+        size_t o = 0;
+        auto put = [&](const void* src, size_t sz) { size_t at = o; if (src) memcpy(h + o, src, sz); else memset(h + o, 0, sz);
+                                                     o = align_up(o + sz, 16); return at; };
+        const size_t o_order = put(order.data() + r0, (size_t)nr * 4), o_sig = put(B->sig_ptr, N * 8);
+        const size_t o_ns = put(B->n_samples, N * 4), o_sc = put(B->scaling, N * 12), o_ep = put(B->event_ptr, N * 8);
+        const size_t o_ec = put(B->event_cap, N * 4), o_rp = put(B->read_ptr, N * 8), o_rl = put(B->read_len, N * 4);
+        const size_t o_wb = put(wave_base.data(), (size_t)nw * 8), o_wl = put(wave_len.data(), (size_t)nw * 4);
+        const size_t o_pb = put(peak_base.data(), (size_t)nw * 8), o_wc = put(wave_cap.data(), (size_t)nw * 4);
+        double* dS = (double*)(d + align_up(o, 256));
+        double* dQ = dS + entries;
+        float* dT1 = (float*)(dQ + entries);
+        float* dT2 = dT1 + entries;
+        int32_t* dPk = (int32_t*)(dT2 + entries);
+        float* dMean = (float*)(dPk + pentries);
+        HIP_TRY(hipMemcpyAsync(d, h, o, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipEventRecord(c->ev[0], c->stream));
+        hipLaunchKernelGGL(abea_ev_sums_kernel, dim3((unsigned)nw), dim3(64), 0, c->stream,
+                           nr, (const int32_t*)(d + o_order), B->signal, (const int64_t*)(d + o_sig),
+                           (const int32_t*)(d + o_ns), (const float*)(d + o_sc), (const int64_t*)(d + o_wb), dS, dQ);
+        const unsigned tiles = (unsigned)std::min<int64_t>(1024, (wave_len[0] + 3) / 4);
+        hipLaunchKernelGGL(abea_ev_tstat_kernel, dim3(tiles, (unsigned)nw), dim3(256), 0, c->stream,
+                           nr, (const int32_t*)(d + o_order), (const int32_t*)(d + o_ns), (const int64_t*)(d + o_wb),
+                           (const int32_t*)(d + o_wl), dS, dQ, dT1, dT2);
+        hipLaunchKernelGGL(abea_ev_detect_kernel, dim3((unsigned)nw), dim3(64), 0, c->stream,
+                           nr, (const int32_t*)(d + o_order), (const int32_t*)(d + o_ns), (const int64_t*)(d + o_wb),
+                           dT1, dT2, (const int64_t*)(d + o_pb), (const int32_t*)(d + o_ec), dPk, B->n_events);
+        const unsigned etiles = (unsigned)std::min<int64_t>(256, (wave_cap[0] + 3) / 4);
+        hipLaunchKernelGGL(abea_ev_create_kernel, dim3(etiles, (unsigned)nw), dim3(256), 0, c->stream,
+                           nr, (const int32_t*)(d + o_order), (const int32_t*)(d + o_ns), (const int64_t*)(d + o_wb),
+                           dS, dQ, (const int64_t*)(d + o_pb), (const int32_t*)(d + o_wc), dPk, B->n_events,
+                           (const int32_t*)(d + o_ec), B->events, (const int64_t*)(d + o_ep), dMean);
+        if (B->scalings)
+            hipLaunchKernelGGL(abea_ev_scalings_kernel, dim3((unsigned)nw), dim3(64), 0, c->stream,
+                               nr, (const int32_t*)(d + o_order), (const int64_t*)(d + o_pb), dMean, B->n_events,
+                               (const int32_t*)(d + o_ec), B->reads, (const int64_t*)(d + o_rp),
+                               (const int32_t*)(d + o_rl), c->d_model, (int)c->k, B->scalings);
+        HIP_TRY(hipEventRecord(c->ev[1], c->stream));
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
+        c->stats.event_ms += ms;
+        w0 = w1;
+    }
     return ABEA_OK;
 }
 

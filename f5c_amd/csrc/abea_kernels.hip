@@ -724,15 +724,20 @@ void abea_scaling_kernel(const abea_read_desc* __restrict__ descs, const char* _
 /* ================================================================ event detection on the device (row N2)
  * event_single's front half (f5c.c:682-712): ADC -> pA, getevents() (events.c:562-582 = detect_events on the
  * whole signal; the trim result there is discarded) and estimate_scalings_using_mom (align.c:58-106).
- * Everything in it is order-dependent floating point (sequential fp64 prefix sums, a two-detector peak-picking
- * automaton), so it is restated as ONE streaming pass per read with O(1) state, executed lane-per-read in the
- * reference's exact operation order; nothing is re-associated, so events come out bit-identical.
- *   - prefix sums S, Q are carried in registers; the last 16 are kept in an LDS ring laid out [slot][lane]
- *     (conflict-free) because the windowed t-statistics at position p need S[p-6], S[p-3], S[p], S[p+3], S[p+6];
- *   - both detectors run at position p = i-5 (the delay of the 6-wide window);
- *   - an event is emitted the moment a detector fires, from the prefix sums saved when its peak was set. */
+ * Everything in it is order-dependent floating point, so nothing is re-associated; the work is split so that only
+ * what is inherently sequential runs sequentially:
+ *   pass 1  abea_ev_sums_kernel    lane-per-read: x = (adc+offset)*raw_unit, S[i+1] = S[i] + x, Q[i+1] = Q[i] + x*x
+ *                                  (fp64, sample order; events.c:303-313)                      ~12 instr / sample
+ *   pass 2  abea_ev_tstat_kernel   fully parallel over samples: the two windowed t-statistics (events.c:324-369)
+ *   pass 3  abea_ev_detect_kernel  lane-per-read: the two-detector peak-picking automaton (events.c:380-452); its only
+ *                                  output is the list of peak positions
+ *   pass 4  abea_ev_create_kernel  fully parallel over events: event_t from the prefix sums at consecutive peaks
+ *                                  (events.c:466-513)
+ *   pass 5  abea_ev_scalings_kernel lane-per-read: method-of-moments scalings (align.c:58-106)
+ * Scratch is interleaved per wavefront: sample i of the read in lane l of wave w lives at wave_base[w] + i*64 + l,
+ * so the lane-per-read passes load/store 64 consecutive elements per instruction and pass 2 is a flat stream. */
 struct abea_evdet {
-    float peak_value; int peak_pos; long long masked_to; bool valid; double s_pk, q_pk;
+    float peak_value; int peak_pos; long long masked_to; bool valid;
 };
 
 static __device__ __forceinline__ float abea_tstat(double s_lo, double s_mid, double s_hi, double q_lo, double q_mid,
@@ -751,104 +756,28 @@ static __device__ __forceinline__ float abea_tstat(double s_lo, double s_mid, do
 }
 
 extern "C" __global__ __launch_bounds__(64)
-void abea_event_kernel(int n_reads, const int32_t* __restrict__ order,
-                       const int16_t* __restrict__ signal, const int64_t* __restrict__ sig_ptr,
-                       const int32_t* __restrict__ n_samples, const float* __restrict__ scaling /* [n][3] offset,range,digitisation */,
-                       abea_event_t* __restrict__ events, const int64_t* __restrict__ event_ptr,
-                       const int32_t* __restrict__ event_cap, int32_t* __restrict__ n_events,
-                       const char* __restrict__ reads, const int64_t* __restrict__ read_ptr,
-                       const int32_t* __restrict__ read_len, const abea_model_t* __restrict__ model, int kmer_size,
-                       abea_scalings_t* __restrict__ scalings) {
-    __shared__ double ring[2][16][64];                   /* [S|Q][slot][lane] */
+void abea_ev_sums_kernel(int n_reads, const int32_t* __restrict__ order, const int16_t* __restrict__ signal,
+                         const int64_t* __restrict__ sig_ptr, const int32_t* __restrict__ n_samples,
+                         const float* __restrict__ scaling, const int64_t* __restrict__ wave_base,
+                         double* __restrict__ S_all, double* __restrict__ Q_all) {
     const int lane = threadIdx.x;
     const int slot = blockIdx.x * 64 + lane;
     if (slot >= n_reads) return;
     const int r = order[slot];
     const int n = n_samples[r];
     const int16_t* __restrict__ sig = signal + sig_ptr[r];
-    abea_event_t* __restrict__ ev = events + event_ptr[r];
-    const int cap = event_cap[r];
     const float offset = scaling[3 * r], range = scaling[3 * r + 1], digitisation = scaling[3 * r + 2];
     const float raw_unit = range / digitisation;                    /* f5c.c:693 */
-    if (n <= 0) { n_events[r] = 0; return; }
-
-    abea_evdet det[2];
-    for (int k = 0; k < 2; ++k) {
-        det[k].peak_value = 3.402823466e+38f; det[k].peak_pos = -1; det[k].masked_to = 0; det[k].valid = false;
-        det[k].s_pk = 0; det[k].q_pk = 0;
-    }
-    const float thr[2] = {1.4f, 9.0f};                               /* events.c:52-56, DNA */
-    const int win[2] = {3, 6};
-    const float peak_height = 0.2f;
-    const bool t1_on = !(n < 6), t2_on = !(n < 12);                  /* d_length < 2*w -> all zeros */
-
-    double S = 0.0, Q = 0.0;                                         /* S[i], Q[i]: sums up to but excluding i */
-    ring[0][0][lane] = 0.0; ring[1][0][lane] = 0.0;                  /* S[0] = Q[0] = 0 */
-    unsigned long long last_pos = 0; double s_last = 0.0, q_last = 0.0;
-    int n_ev = 0;
-    double ev_sum = 0.0;                                             /* align.c:68-71, event order */
-
-    auto emit_event = [&](unsigned long long end, double s_end, double q_end) {   /* events.c:466-486 */
-        const float length = (float)(end - last_pos);
-        const float mean = (float)(s_end - s_last) / length;
-        const float deltasqr = (float)(q_end - q_last);
-        const float var = deltasqr / length - mean * mean;
-        if (n_ev < cap) {
-            abea_event_t e; e.start = last_pos; e.length = length; e.mean = mean; e.stdv = sqrtf(fmaxf(var, 0.0f));
-            ev[n_ev] = e;
-        }
-        ev_sum += mean;
-        ++n_ev;
-        last_pos = end; s_last = s_end; q_last = q_end;
-    };
-
-    auto detect_at = [&](int p) {                                    /* events.c:380-452 at position p */
-        const double s_mid = ring[0][p & 15][lane], q_mid = ring[1][p & 15][lane];
-        float ts[2] = {0.f, 0.f};
-        if (t1_on && p >= 3 && p <= n - 3)
-            ts[0] = abea_tstat(ring[0][(p - 3) & 15][lane], s_mid, ring[0][(p + 3) & 15][lane],
-                               ring[1][(p - 3) & 15][lane], q_mid, ring[1][(p + 3) & 15][lane], 3.0f);
-        if (t2_on && p >= 6 && p <= n - 6)
-            ts[1] = abea_tstat(ring[0][(p - 6) & 15][lane], s_mid, ring[0][(p + 6) & 15][lane],
-                               ring[1][(p - 6) & 15][lane], q_mid, ring[1][(p + 6) & 15][lane], 6.0f);
-        #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            abea_evdet& d = det[k];
-            if (d.masked_to >= (long long)p) continue;
-            const float cur = ts[k];
-            if (d.peak_pos == -1) {
-                if (cur < d.peak_value) {
-                    d.peak_value = cur;
-                } else if (cur - d.peak_value > peak_height) {
-                    d.peak_value = cur; d.peak_pos = p; d.s_pk = s_mid; d.q_pk = q_mid;
-                }
-            } else {
-                if (cur > d.peak_value) { d.peak_value = cur; d.peak_pos = p; d.s_pk = s_mid; d.q_pk = q_mid; }
-                if (k == 0) {
-                    if (d.peak_value > thr[0]) {
-                        det[1].masked_to = (long long)d.peak_pos + win[0];
-                        det[1].peak_pos = -1; det[1].peak_value = 3.402823466e+38f; det[1].valid = false;
-                    }
-                }
-                if (d.peak_value - cur > peak_height && d.peak_value > thr[k]) d.valid = true;
-                if (d.valid && (unsigned long long)(p - d.peak_pos) > (unsigned long long)(win[k] / 2)) {
-                    emit_event((unsigned long long)d.peak_pos, d.s_pk, d.q_pk);
-                    d.peak_pos = -1; d.peak_value = cur; d.valid = false;
-                }
-            }
-        }
-    };
-
+    double* __restrict__ Sw = S_all + wave_base[blockIdx.x] + lane;
+    double* __restrict__ Qw = Q_all + wave_base[blockIdx.x] + lane;
+    double S = 0.0, Q = 0.0;
+    Sw[0] = 0.0; Qw[0] = 0.0;                                       /* S[0] = Q[0] = 0 */
     auto sample = [&](int i, int raw) {
         const float x = ((float)raw + offset) * raw_unit;            /* f5c.c:694-696 */
         S = S + (double)x;                                           /* events.c:309-312; the square is a float product */
         Q = Q + (double)(x * x);
-        ring[0][(i + 1) & 15][lane] = S; ring[1][(i + 1) & 15][lane] = Q;
-        const int p = i - 5;                                         /* S[p+6] just became available */
-        if (p >= 0) detect_at(p);
+        Sw[(size_t)(i + 1) * 64] = S; Qw[(size_t)(i + 1) * 64] = Q;
     };
-    /* samples are fetched 8 at a time (16 B per lane), the next chunk one iteration ahead: a per-sample load
-     * would put a full memory latency on every step of this sequential loop */
     int i = 0;
     const int head = min(n, (int)(((16u - ((uintptr_t)sig & 15u)) & 15u) >> 1));
     for (; i < head; ++i) sample(i, sig[i]);
@@ -865,32 +794,198 @@ void abea_event_kernel(int n_reads, const int32_t* __restrict__ order,
         }
     }
     for (; i < n; ++i) sample(i, sig[i]);
-    for (int p = max(n - 5, 0); p < n; ++p) detect_at(p);            /* tail: the 6-wide statistic is 0 there */
-    emit_event((unsigned long long)n, S, Q);                         /* last event ends at nsample (events.c:509-511) */
-    n_events[r] = n_ev;
+}
 
-    /* ---- estimate_scalings_using_mom (align.c:58-106) ---- */
-    if (scalings) {
-        const int L = read_len[r];
-        const int K = L - kmer_size + 1;
-        const char* __restrict__ seq = reads + read_ptr[r];
-        double km_sum = 0.0, km_sq = 0.0;
-        for (int i = 0; i < K; ++i) {
-            uint32_t rank = 0;
-            for (int j = 0; j < kmer_size; ++j) rank = (rank << 2) | base_code(seq[i + j]);
-            const double l = model[rank].level_mean;
-            km_sum += l;
-            km_sq += l * l;
+extern "C" __global__ __launch_bounds__(256)
+void abea_ev_tstat_kernel(int n_reads, const int32_t* __restrict__ order, const int32_t* __restrict__ n_samples,
+                          const int64_t* __restrict__ wave_base, const int32_t* __restrict__ wave_len,
+                          const double* __restrict__ S_all, const double* __restrict__ Q_all,
+                          float* __restrict__ t1_all, float* __restrict__ t2_all) {
+    /* grid.y = wave, grid.x tiles the positions of that wave; a 256-thread block covers 4 positions x 64 lanes */
+    const int w = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int slot = w * 64 + lane;
+    const int n = slot < n_reads ? n_samples[order[slot]] : 0;
+    const int64_t base = wave_base[w];
+    const int len = wave_len[w];
+    for (int p = blockIdx.x * 4 + (threadIdx.x >> 6); p < len; p += gridDim.x * 4) {
+        float a = 0.f, b = 0.f;
+        if (p < n) {
+            const double* Sp = S_all + base + (int64_t)p * 64 + lane;
+            const double* Qp = Q_all + base + (int64_t)p * 64 + lane;
+            const double s_mid = Sp[0], q_mid = Qp[0];
+            if (n >= 6 && p >= 3 && p <= n - 3)
+                a = abea_tstat(Sp[-3 * 64], s_mid, Sp[3 * 64], Qp[-3 * 64], q_mid, Qp[3 * 64], 3.0f);
+            if (n >= 12 && p >= 6 && p <= n - 6)
+                b = abea_tstat(Sp[-6 * 64], s_mid, Sp[6 * 64], Qp[-6 * 64], q_mid, Qp[6 * 64], 6.0f);
         }
-        const int ne = min(n_ev, cap);
-        const double shift = ev_sum / n_ev - km_sum / K;
-        double ev_sq = 0.0;
-        for (int i = 0; i < ne; ++i) {
-            const double m = (double)ev[i].mean;
-            ev_sq += (m - shift) * (m - shift);
-        }
-        const double scale = (ev_sq / n_ev) / (km_sq / K);
-        abea_scalings_t o; o.shift = (float)shift; o.scale = (float)scale; o.var = 1.0f; o.log_var = 0.0f;
-        scalings[r] = o;
+        t1_all[base + (int64_t)p * 64 + lane] = a;
+        t2_all[base + (int64_t)p * 64 + lane] = b;
     }
+}
+
+extern "C" __global__ __launch_bounds__(64)
+void abea_ev_detect_kernel(int n_reads, const int32_t* __restrict__ order, const int32_t* __restrict__ n_samples,
+                           const int64_t* __restrict__ wave_base, const float* __restrict__ t1_all,
+                           const float* __restrict__ t2_all, const int64_t* __restrict__ peak_base,
+                           const int32_t* __restrict__ event_cap, int32_t* __restrict__ peaks_all,
+                           int32_t* __restrict__ n_events) {
+    const int lane = threadIdx.x;
+    const int slot = blockIdx.x * 64 + lane;
+    if (slot >= n_reads) return;
+    const int r = order[slot];
+    const int n = n_samples[r];
+    const int cap = event_cap[r];
+    if (n <= 0) { n_events[r] = 0; return; }
+    const int64_t base = wave_base[blockIdx.x] + lane;
+    const float* __restrict__ t1 = t1_all + base;
+    const float* __restrict__ t2 = t2_all + base;
+    int32_t* __restrict__ pk = peaks_all + peak_base[blockIdx.x] + lane;
+
+    abea_evdet det[2];
+    for (int k = 0; k < 2; ++k) {
+        det[k].peak_value = 3.402823466e+38f; det[k].peak_pos = -1; det[k].masked_to = 0; det[k].valid = false;
+    }
+    const float thr[2] = {1.4f, 9.0f};                               /* events.c:52-56, DNA */
+    const int win[2] = {3, 6};
+    const float peak_height = 0.2f;
+    int n_pk = 0;
+
+    auto detect_at = [&](int p, float ts0, float ts1) {              /* events.c:380-452 at position p */
+        const float ts[2] = {ts0, ts1};
+        #pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            abea_evdet& d = det[k];
+            if (d.masked_to >= (long long)p) continue;
+            const float cur = ts[k];
+            if (d.peak_pos == -1) {
+                if (cur < d.peak_value) {
+                    d.peak_value = cur;
+                } else if (cur - d.peak_value > peak_height) {
+                    d.peak_value = cur; d.peak_pos = p;
+                }
+            } else {
+                if (cur > d.peak_value) { d.peak_value = cur; d.peak_pos = p; }
+                if (k == 0) {
+                    if (d.peak_value > thr[0]) {
+                        det[1].masked_to = (long long)d.peak_pos + win[0];
+                        det[1].peak_pos = -1; det[1].peak_value = 3.402823466e+38f; det[1].valid = false;
+                    }
+                }
+                if (d.peak_value - cur > peak_height && d.peak_value > thr[k]) d.valid = true;
+                if (d.valid && (unsigned long long)(p - d.peak_pos) > (unsigned long long)(win[k] / 2)) {
+                    if (n_pk < cap) pk[(size_t)n_pk * 64] = d.peak_pos;      /* peaks[peak_count++] (events.c:443) */
+                    ++n_pk;
+                    d.peak_pos = -1; d.peak_value = cur; d.valid = false;
+                }
+            }
+        }
+    };
+    /* the automaton is a serial chain with no loads of its own: its inputs are fetched 8 positions at a time, two
+     * blocks ahead, and a fired peak is a 4-byte store */
+    const int last = max(n - 1, 0);
+    float a1[8], a2[8], b1[8], b2[8];
+    #pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        a1[j] = t1[(size_t)min(j, last) * 64]; a2[j] = t2[(size_t)min(j, last) * 64];
+        b1[j] = t1[(size_t)min(8 + j, last) * 64]; b2[j] = t2[(size_t)min(8 + j, last) * 64];
+    }
+    for (int p0 = 0; p0 < n; p0 += 8) {
+        float c1[8], c2[8];
+        #pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            c1[j] = t1[(size_t)min(p0 + 16 + j, last) * 64]; c2[j] = t2[(size_t)min(p0 + 16 + j, last) * 64];
+        }
+        #pragma unroll
+        for (int j = 0; j < 8; ++j) if (p0 + j < n) detect_at(p0 + j, a1[j], a2[j]);
+        #pragma unroll
+        for (int j = 0; j < 8; ++j) { a1[j] = b1[j]; a2[j] = b2[j]; b1[j] = c1[j]; b2[j] = c2[j]; }
+    }
+    n_events[r] = n_pk + 1;                                          /* events.c:491-497: one more event than peaks */
+}
+
+/* pass 4: events from consecutive peaks (events.c:466-513), fully parallel: one thread per (read, event) */
+extern "C" __global__ __launch_bounds__(256)
+void abea_ev_create_kernel(int n_reads, const int32_t* __restrict__ order, const int32_t* __restrict__ n_samples,
+                           const int64_t* __restrict__ wave_base, const double* __restrict__ S_all,
+                           const double* __restrict__ Q_all, const int64_t* __restrict__ peak_base,
+                           const int32_t* __restrict__ wave_cap, const int32_t* __restrict__ peaks_all,
+                           const int32_t* __restrict__ n_events, const int32_t* __restrict__ event_cap,
+                           abea_event_t* __restrict__ events, const int64_t* __restrict__ event_ptr,
+                           float* __restrict__ mean_all) {
+    const int w = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int slot = w * 64 + lane;
+    if (slot >= n_reads) return;
+    const int r = order[slot];
+    const int n = n_samples[r];
+    const int ne = min(n_events[r], event_cap[r]);
+    const int64_t base = wave_base[w] + lane;
+    const int32_t* __restrict__ pk = peaks_all + peak_base[w] + lane;
+    abea_event_t* __restrict__ ev = events + event_ptr[r];
+    const int wcap = wave_cap[w];
+    for (int j = blockIdx.x * 4 + (threadIdx.x >> 6); j < wcap; j += gridDim.x * 4) {
+        if (j >= ne || n <= 0) continue;
+        const unsigned long long start = (j == 0) ? 0ull : (unsigned long long)pk[(size_t)(j - 1) * 64];
+        const unsigned long long end = (j == n_events[r] - 1) ? (unsigned long long)n : (unsigned long long)pk[(size_t)j * 64];
+        const double s_end = S_all[base + (int64_t)end * 64], q_end = Q_all[base + (int64_t)end * 64];
+        const double s_st = S_all[base + (int64_t)start * 64], q_st = Q_all[base + (int64_t)start * 64];
+        abea_event_t e;
+        e.start = start;
+        e.length = (float)(end - start);
+        e.mean = (float)(s_end - s_st) / e.length;
+        const float deltasqr = (float)(q_end - q_st);
+        const float var = deltasqr / e.length - e.mean * e.mean;
+        e.stdv = sqrtf(fmaxf(var, 0.0f));
+        ev[j] = e;
+        mean_all[peak_base[w] + (int64_t)j * 64 + lane] = e.mean;
+    }
+}
+
+/* pass 5: estimate_scalings_using_mom (align.c:58-106), lane-per-read, sequential fp64 sums in the reference's order */
+extern "C" __global__ __launch_bounds__(64)
+void abea_ev_scalings_kernel(int n_reads, const int32_t* __restrict__ order, const int64_t* __restrict__ peak_base,
+                             const float* __restrict__ mean_all, const int32_t* __restrict__ n_events,
+                             const int32_t* __restrict__ event_cap, const char* __restrict__ reads,
+                             const int64_t* __restrict__ read_ptr, const int32_t* __restrict__ read_len,
+                             const abea_model_t* __restrict__ model, int kmer_size,
+                             abea_scalings_t* __restrict__ scalings) {
+    const int lane = threadIdx.x;
+    const int slot = blockIdx.x * 64 + lane;
+    if (slot >= n_reads) return;
+    const int r = order[slot];
+    const int n_ev = n_events[r];
+    const int ne = min(n_ev, event_cap[r]);
+    const float* __restrict__ mean = mean_all + peak_base[blockIdx.x] + lane;
+    double ev_sum = 0.0;
+    for (int i0 = 0; i0 < ne; i0 += 8) {
+        float m[8];
+        #pragma unroll
+        for (int j = 0; j < 8; ++j) m[j] = mean[(size_t)min(i0 + j, ne - 1) * 64];
+        #pragma unroll
+        for (int j = 0; j < 8; ++j) if (i0 + j < ne) ev_sum += m[j];
+    }
+    const int L = read_len[r];
+    const int K = L - kmer_size + 1;
+    const char* __restrict__ seq = reads + read_ptr[r];
+    double km_sum = 0.0, km_sq = 0.0;
+    for (int i = 0; i < K; ++i) {
+        uint32_t rank = 0;
+        for (int j = 0; j < kmer_size; ++j) rank = (rank << 2) | base_code(seq[i + j]);
+        const double l = model[rank].level_mean;
+        km_sum += l;
+        km_sq += l * l;
+    }
+    const double shift = ev_sum / n_ev - km_sum / K;
+    double ev_sq = 0.0;
+    for (int i0 = 0; i0 < ne; i0 += 8) {
+        float m[8];
+        #pragma unroll
+        for (int j = 0; j < 8; ++j) m[j] = mean[(size_t)min(i0 + j, ne - 1) * 64];
+        #pragma unroll
+        for (int j = 0; j < 8; ++j) if (i0 + j < ne) ev_sq += ((double)m[j] - shift) * ((double)m[j] - shift);
+    }
+    const double scale = (ev_sq / n_ev) / (km_sq / K);
+    abea_scalings_t o; o.shift = (float)shift; o.scale = (float)scale; o.var = 1.0f; o.log_var = 0.0f;
+    scalings[r] = o;
 }

@@ -5,13 +5,14 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from f5c_amd import abea, synth, load_model_f32
 from oracle import orc
-k, model = load_model_f32("tests/golden/r9.4_450bps.6mer.f32")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+k, model = load_model_f32(os.path.join(ROOT, "tests/golden/r9.4_450bps.6mer.f32"))
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
-b = synth.make_batch(n, model, k, seed=20250002, law="gamma8k", workers=16)
+b = synth.make_batch(n, model, k, seed=20250002, law="gamma8k", workers=int(os.environ.get("ABEA_WORKERS", "16")))
 sigs, sc = synth.make_signals(b, seed=1)
 seqs = [b["reads"][int(b["read_ptr"][i]):int(b["read_ptr"][i]) + int(b["read_len"][i])].tobytes() for i in range(n)]
 ns = sum(len(s) for s in sigs)
-ctx = abea.AbeaContext(model, k, max_arena_bytes=8 << 30)
+ctx = abea.AbeaContext(model, k, mem_frac=0.6)
 for rep in range(2):
     evs, ne, scal = ctx.detect_events_device(sigs, sc, seqs=seqs)
     ms = ctx.stats()["event_ms"]
