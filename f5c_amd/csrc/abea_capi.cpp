@@ -45,9 +45,11 @@ __global__ void abea_ev_detect_kernel(int, const int32_t*, const int32_t*, const
 __global__ void abea_ev_create_kernel(int, const int32_t*, const int32_t*, const int64_t*, const double*, const double*,
                                       const int64_t*, const int32_t*, const int32_t*, const int32_t*, const int32_t*,
                                       abea_event_t*, const int64_t*, float*);
+__global__ void abea_ev_kmer_kernel(int, const int32_t*, const char*, const int64_t*, const int32_t*, const abea_model_t*,
+                                    int, const int64_t*, const int32_t*, float*);
 __global__ void abea_ev_scalings_kernel(int, const int32_t*, const int64_t*, const float*, const int32_t*,
-                                        const int32_t*, const char*, const int64_t*, const int32_t*,
-                                        const abea_model_t*, int, abea_scalings_t*);
+                                        const int32_t*, const int32_t*, const int64_t*, const float*, int,
+                                        abea_scalings_t*);
 __global__ void abea_align_kernel(const abea_read_desc*, const float*, const abea_kpar_t*, uint4*, uint32_t*,
                                   abea_pair_t*, int32_t*, abea_read_diag*);
 }
@@ -382,21 +384,25 @@ extern "C" int abea_detect_events_device(abea_ctx* c, const abea_signal_batch* B
     while (w0 < n_waves_all) {
         /* ---- carve waves whose interleaved scratch fits the arena: per sample S,Q fp64 + two float t-statistics
          *      (24 B), per event slot a peak position + a mean (8 B) ---- */
-        const size_t idx_bytes = N * (4 + 8 + 4 + 12 + 8 + 4 + 8 + 4) + (size_t)n_waves_all * 24 + 4096;
+        const size_t idx_bytes = N * (4 + 8 + 4 + 12 + 8 + 4 + 8 + 4) + (size_t)n_waves_all * 40 + 8192;
         if (idx_bytes + (1u << 20) > c->arena_bytes) return fail(ABEA_ENOMEM, "arena too small for %d index records", n);
         const size_t budget = c->arena_bytes - idx_bytes - 4096;
-        std::vector<int64_t> wave_base, peak_base; std::vector<int32_t> wave_len, wave_cap;
-        size_t entries = 0, pentries = 0;
+        std::vector<int64_t> wave_base, peak_base, kmer_base; std::vector<int32_t> wave_len, wave_cap, wave_k;
+        size_t entries = 0, pentries = 0, kentries = 0;
         int w1 = w0;
         while (w1 < n_waves_all) {
             const int32_t len = B->n_samples[order[(size_t)w1 * 64]] + 1;      /* longest read of the wave, +1 for S[n] */
-            int32_t cap = 1;
-            for (int q = w1 * 64; q < std::min(n, (w1 + 1) * 64); ++q) cap = std::max(cap, B->event_cap[order[(size_t)q]]);
-            const size_t need = (size_t)std::max(len, 1) * 64, pneed = (size_t)cap * 64;
-            if ((entries + need) * 24 + (pentries + pneed) * 8 > budget) break;
+            int32_t cap = 1, wk = 1;
+            for (int q = w1 * 64; q < std::min(n, (w1 + 1) * 64); ++q) {
+                cap = std::max(cap, B->event_cap[order[(size_t)q]]);
+                if (B->scalings) wk = std::max(wk, B->read_len[order[(size_t)q]] - (int32_t)c->k + 1);
+            }
+            const size_t need = (size_t)std::max(len, 1) * 64, pneed = (size_t)cap * 64, kneed = (size_t)wk * 64;
+            if ((entries + need) * 24 + (pentries + pneed) * 8 + (kentries + kneed) * 4 > budget) break;
             wave_base.push_back((int64_t)entries); wave_len.push_back(len);
             peak_base.push_back((int64_t)pentries); wave_cap.push_back(cap);
-            entries += need; pentries += pneed; ++w1;
+            kmer_base.push_back((int64_t)kentries); wave_k.push_back(wk);
+            entries += need; pentries += pneed; kentries += kneed; ++w1;
         }
         if (w1 == w0) return fail(ABEA_ENOMEM, "a read of %d samples does not fit the %zu-byte arena",
                                   B->n_samples[order[(size_t)w0 * 64]], c->arena_bytes);
@@ -413,12 +419,14 @@ extern "C" int abea_detect_events_device(abea_ctx* c, const abea_signal_batch* B
         const size_t o_ec = put(B->event_cap, N * 4), o_rp = put(B->read_ptr, N * 8), o_rl = put(B->read_len, N * 4);
         const size_t o_wb = put(wave_base.data(), (size_t)nw * 8), o_wl = put(wave_len.data(), (size_t)nw * 4);
         const size_t o_pb = put(peak_base.data(), (size_t)nw * 8), o_wc = put(wave_cap.data(), (size_t)nw * 4);
+        const size_t o_kb = put(kmer_base.data(), (size_t)nw * 8), o_wk = put(wave_k.data(), (size_t)nw * 4);
         double* dS = (double*)(d + align_up(o, 256));
         double* dQ = dS + entries;
         float* dT1 = (float*)(dQ + entries);
         float* dT2 = dT1 + entries;
         int32_t* dPk = (int32_t*)(dT2 + entries);
         float* dMean = (float*)(dPk + pentries);
+        float* dKm = dMean + pentries;
         HIP_TRY(hipMemcpyAsync(d, h, o, hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipEventRecord(c->ev[0], c->stream));
         hipLaunchKernelGGL(abea_ev_sums_kernel, dim3((unsigned)nw), dim3(64), 0, c->stream,
@@ -436,11 +444,17 @@ extern "C" int abea_detect_events_device(abea_ctx* c, const abea_signal_batch* B
                            nr, (const int32_t*)(d + o_order), (const int32_t*)(d + o_ns), (const int64_t*)(d + o_wb),
                            dS, dQ, (const int64_t*)(d + o_pb), (const int32_t*)(d + o_wc), dPk, B->n_events,
                            (const int32_t*)(d + o_ec), B->events, (const int64_t*)(d + o_ep), dMean);
-        if (B->scalings)
+        if (B->scalings) {
+            const unsigned ktiles = (unsigned)std::min<int64_t>(256, (*std::max_element(wave_k.begin(), wave_k.end()) + 3) / 4);
+            hipLaunchKernelGGL(abea_ev_kmer_kernel, dim3(ktiles, (unsigned)nw), dim3(256), 0, c->stream,
+                               nr, (const int32_t*)(d + o_order), B->reads, (const int64_t*)(d + o_rp),
+                               (const int32_t*)(d + o_rl), c->d_model, (int)c->k, (const int64_t*)(d + o_kb),
+                               (const int32_t*)(d + o_wk), dKm);
             hipLaunchKernelGGL(abea_ev_scalings_kernel, dim3((unsigned)nw), dim3(64), 0, c->stream,
                                nr, (const int32_t*)(d + o_order), (const int64_t*)(d + o_pb), dMean, B->n_events,
-                               (const int32_t*)(d + o_ec), B->reads, (const int64_t*)(d + o_rp),
-                               (const int32_t*)(d + o_rl), c->d_model, (int)c->k, B->scalings);
+                               (const int32_t*)(d + o_ec), (const int32_t*)(d + o_rl), (const int64_t*)(d + o_kb), dKm,
+                               (int)c->k, B->scalings);
+        }
         HIP_TRY(hipEventRecord(c->ev[1], c->stream));
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(c->stream));

@@ -851,34 +851,41 @@ void abea_ev_detect_kernel(int n_reads, const int32_t* __restrict__ order, const
     const float peak_height = 0.2f;
     int n_pk = 0;
 
-    auto detect_at = [&](int p, float ts0, float ts1) {              /* events.c:380-452 at position p */
+    /* events.c:380-452 at position p, written with selects instead of branches: the 64 reads of a wavefront are in
+     * unrelated automaton states, so branchy code would execute every path anyway */
+    auto detect_at = [&](int p, float ts0, float ts1) {
         const float ts[2] = {ts0, ts1};
         #pragma unroll
         for (int k = 0; k < 2; ++k) {
             abea_evdet& d = det[k];
-            if (d.masked_to >= (long long)p) continue;
             const float cur = ts[k];
-            if (d.peak_pos == -1) {
-                if (cur < d.peak_value) {
-                    d.peak_value = cur;
-                } else if (cur - d.peak_value > peak_height) {
-                    d.peak_value = cur; d.peak_pos = p;
-                }
-            } else {
-                if (cur > d.peak_value) { d.peak_value = cur; d.peak_pos = p; }
-                if (k == 0) {
-                    if (d.peak_value > thr[0]) {
-                        det[1].masked_to = (long long)d.peak_pos + win[0];
-                        det[1].peak_pos = -1; det[1].peak_value = 3.402823466e+38f; det[1].valid = false;
-                    }
-                }
-                if (d.peak_value - cur > peak_height && d.peak_value > thr[k]) d.valid = true;
-                if (d.valid && (unsigned long long)(p - d.peak_pos) > (unsigned long long)(win[k] / 2)) {
-                    if (n_pk < cap) pk[(size_t)n_pk * 64] = d.peak_pos;      /* peaks[peak_count++] (events.c:443) */
-                    ++n_pk;
-                    d.peak_pos = -1; d.peak_value = cur; d.valid = false;
-                }
+            const bool active = d.masked_to < (long long)p;
+            const bool searching = d.peak_pos == -1;
+            /* CASE 1: no maximum recorded yet */
+            const bool lower = cur < d.peak_value;
+            const bool rise = !lower && (cur - d.peak_value > peak_height);
+            /* CASE 2: in a peak */
+            const bool higher = cur > d.peak_value;
+            const float pv_i = higher ? cur : d.peak_value;
+            const int pp_i = higher ? p : d.peak_pos;
+            const bool inpeak = active && !searching;
+            if (k == 0) {                                            /* a short-window peak that will fire masks the long detector */
+                const bool dom = inpeak && (pv_i > thr[0]);
+                det[1].masked_to = dom ? (long long)pp_i + win[0] : det[1].masked_to;
+                det[1].peak_pos = dom ? -1 : det[1].peak_pos;
+                det[1].peak_value = dom ? 3.402823466e+38f : det[1].peak_value;
+                det[1].valid = dom ? false : det[1].valid;
             }
+            const bool valid_i = d.valid || ((pv_i - cur > peak_height) && (pv_i > thr[k]));
+            const bool fire = inpeak && valid_i && ((unsigned)(p - pp_i) > (unsigned)(win[k] / 2));
+            if (fire) {                                              /* peaks[peak_count++] (events.c:443) */
+                if (n_pk < cap) pk[(size_t)n_pk * 64] = pp_i;
+                ++n_pk;
+            }
+            const bool srch = active && searching;
+            d.peak_value = srch ? ((lower || rise) ? cur : d.peak_value) : (inpeak ? (fire ? cur : pv_i) : d.peak_value);
+            d.peak_pos = srch ? (rise ? p : -1) : (inpeak ? (fire ? -1 : pp_i) : d.peak_pos);
+            d.valid = inpeak ? (fire ? false : valid_i) : d.valid;
         }
     };
     /* the automaton is a serial chain with no loads of its own: its inputs are fetched 8 positions at a time, two
@@ -942,14 +949,35 @@ void abea_ev_create_kernel(int n_reads, const int32_t* __restrict__ order, const
     }
 }
 
+/* pass 4b: model level of every k-mer of every read (align.c:75-78), parallel; interleaved like the other scratch */
+extern "C" __global__ __launch_bounds__(256)
+void abea_ev_kmer_kernel(int n_reads, const int32_t* __restrict__ order, const char* __restrict__ reads,
+                         const int64_t* __restrict__ read_ptr, const int32_t* __restrict__ read_len,
+                         const abea_model_t* __restrict__ model, int kmer_size, const int64_t* __restrict__ kmer_base,
+                         const int32_t* __restrict__ wave_k, float* __restrict__ kmean_all) {
+    const int w = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int slot = w * 64 + lane;
+    if (slot >= n_reads) return;
+    const int r = order[slot];
+    const int K = read_len[r] - kmer_size + 1;
+    const char* __restrict__ seq = reads + read_ptr[r];
+    const int wk = wave_k[w];
+    for (int i = blockIdx.x * 4 + (threadIdx.x >> 6); i < wk; i += gridDim.x * 4) {
+        if (i >= K) continue;
+        uint32_t rank = 0;
+        for (int j = 0; j < kmer_size; ++j) rank = (rank << 2) | base_code(seq[i + j]);
+        kmean_all[kmer_base[w] + (int64_t)i * 64 + lane] = model[rank].level_mean;
+    }
+}
+
 /* pass 5: estimate_scalings_using_mom (align.c:58-106), lane-per-read, sequential fp64 sums in the reference's order */
 extern "C" __global__ __launch_bounds__(64)
 void abea_ev_scalings_kernel(int n_reads, const int32_t* __restrict__ order, const int64_t* __restrict__ peak_base,
                              const float* __restrict__ mean_all, const int32_t* __restrict__ n_events,
-                             const int32_t* __restrict__ event_cap, const char* __restrict__ reads,
-                             const int64_t* __restrict__ read_ptr, const int32_t* __restrict__ read_len,
-                             const abea_model_t* __restrict__ model, int kmer_size,
-                             abea_scalings_t* __restrict__ scalings) {
+                             const int32_t* __restrict__ event_cap, const int32_t* __restrict__ read_len,
+                             const int64_t* __restrict__ kmer_base, const float* __restrict__ kmean_all,
+                             int kmer_size, abea_scalings_t* __restrict__ scalings) {
     const int lane = threadIdx.x;
     const int slot = blockIdx.x * 64 + lane;
     if (slot >= n_reads) return;
@@ -965,16 +993,15 @@ void abea_ev_scalings_kernel(int n_reads, const int32_t* __restrict__ order, con
         #pragma unroll
         for (int j = 0; j < 8; ++j) if (i0 + j < ne) ev_sum += m[j];
     }
-    const int L = read_len[r];
-    const int K = L - kmer_size + 1;
-    const char* __restrict__ seq = reads + read_ptr[r];
+    const int K = read_len[r] - kmer_size + 1;
+    const float* __restrict__ km = kmean_all + kmer_base[blockIdx.x] + lane;
     double km_sum = 0.0, km_sq = 0.0;
-    for (int i = 0; i < K; ++i) {
-        uint32_t rank = 0;
-        for (int j = 0; j < kmer_size; ++j) rank = (rank << 2) | base_code(seq[i + j]);
-        const double l = model[rank].level_mean;
-        km_sum += l;
-        km_sq += l * l;
+    for (int i0 = 0; i0 < K; i0 += 8) {
+        float m[8];
+        #pragma unroll
+        for (int j = 0; j < 8; ++j) m[j] = km[(size_t)min(i0 + j, K - 1) * 64];
+        #pragma unroll
+        for (int j = 0; j < 8; ++j) if (i0 + j < K) { const double l = m[j]; km_sum += l; km_sq += l * l; }
     }
     const double shift = ev_sum / n_ev - km_sum / K;
     double ev_sq = 0.0;
