@@ -83,17 +83,23 @@ struct abea_ctx {
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     /* pinned staging for descriptors */
     abea_read_desc* h_desc = nullptr; size_t h_desc_cap = 0;
-    /* host-batch staging (grow on demand) */
-    char* h_reads = nullptr;       size_t h_reads_cap = 0;
-    abea_event_t* h_events = nullptr; size_t h_events_cap = 0;
-    abea_pair_t* h_pairs = nullptr;  size_t h_pairs_cap = 0;
-    int32_t* h_npairs = nullptr;     size_t h_npairs_cap = 0;
-    abea_read_diag* h_diag = nullptr; size_t h_diag_cap = 0;
-    char* d_reads = nullptr;       size_t d_reads_cap = 0;
-    abea_event_t* d_events = nullptr; size_t d_events_cap = 0;
-    abea_pair_t* d_pairs = nullptr;  size_t d_pairs_cap = 0;
-    int32_t* d_npairs = nullptr;     size_t d_npairs_cap = 0;
-    abea_read_diag* d_diag = nullptr; size_t d_diag_cap = 0;
+    /* host-batch pipeline (abea_align_batch_host): chunks of reads rotate through these slots, each with its own
+     * stream, pinned staging block and share of the arena */
+    struct host_slot {
+        hipStream_t stream = nullptr;
+        hipEvent_t k0 = nullptr, k1 = nullptr, done = nullptr;
+        static const int N_PIECES = 4;         /* the copies of a chunk go in pieces so that they overlap the host loops */
+        hipEvent_t piece_done[N_PIECES] = {nullptr, nullptr, nullptr, nullptr};
+        int32_t piece_end[N_PIECES] = {0, 0, 0, 0};                   /* chunk-local read index ends (caller order) */
+        std::vector<int64_t> pair_off;                                /* chunk-local read index -> offset in pairs */
+        uint8_t* pinned = nullptr;  size_t pinned_cap = 0;
+        /* the chunk in flight */
+        bool busy = false;
+        int32_t first = 0, count = 0;
+        size_t o_desc = 0, o_npairs = 0, o_pairs = 0, o_diag = 0;      /* offsets into `pinned` */
+    };
+    static const int N_SLOTS = 3;
+    host_slot slot[N_SLOTS];
     abea_stats stats;
 };
 
@@ -123,6 +129,11 @@ extern "C" int abea_init(abea_ctx** out, const abea_cfg* cfg) {
     c->verbosity = cfg->verbosity;
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     for (auto& e : c->ev) HIP_TRY(hipEventCreate(&e));
+    for (auto& sl : c->slot) {
+        HIP_TRY(hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreate(&sl.k0)); HIP_TRY(hipEventCreate(&sl.k1)); HIP_TRY(hipEventCreate(&sl.done));
+        for (auto& e : sl.piece_done) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
     const size_t n_model = (size_t)1 << (2 * cfg->kmer_size);
     HIP_TRY(hipMalloc(&c->d_model, n_model * sizeof(abea_model_t)));
     HIP_TRY(hipMemcpy(c->d_model, cfg->model, n_model * sizeof(abea_model_t), hipMemcpyHostToDevice));
@@ -148,9 +159,15 @@ extern "C" void abea_free(abea_ctx* c) {
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     hipFree(c->d_model); hipFree(c->arena);
-    hipFree(c->d_reads); hipFree(c->d_events); hipFree(c->d_pairs); hipFree(c->d_npairs); hipFree(c->d_diag);
-    hipHostFree(c->h_desc); hipHostFree(c->h_reads); hipHostFree(c->h_events); hipHostFree(c->h_pairs);
-    hipHostFree(c->h_npairs); hipHostFree(c->h_diag);
+    hipHostFree(c->h_desc);
+    for (auto& sl : c->slot) {
+        if (sl.stream) { hipStreamSynchronize(sl.stream); hipStreamDestroy(sl.stream); }
+        if (sl.k0) hipEventDestroy(sl.k0);
+        if (sl.k1) hipEventDestroy(sl.k1);
+        if (sl.done) hipEventDestroy(sl.done);
+        for (auto& e : sl.piece_done) if (e) hipEventDestroy(e);
+        hipHostFree(sl.pinned);
+    }
     for (auto& e : c->ev) if (e) hipEventDestroy(e);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
@@ -205,6 +222,53 @@ static size_t scratch_bytes(const plan_read& r) {
            sizeof(abea_read_desc);
 }
 
+/* element counts of one launch's scratch arrays */
+struct sub_layout { size_t n_kpar = 0, n_evm = 0, n_code = 0, n_trace = 0; };
+
+/* Descriptor of one read and its place in the launch's scratch; the caller sets read_off/event_off/pair_off/kmer_off. */
+static void plan_desc(abea_read_desc& d, const plan_read& r, int k, const abea_scalings_t& sc, sub_layout& lay,
+                      abea_stats& st) {
+    (void)k;
+    memset(&d, 0, sizeof d);
+    d.out_idx = r.idx;
+    d.read_len = r.L; d.n_events = r.E; d.n_kmers = r.K;
+    if (!r.run) { d.n_groups = 0; return; }
+    d.n_groups = (int32_t)((r.n_bands + ABEA_GROUP - 1) / ABEA_GROUP);
+    d.scale = sc.scale; d.shift = sc.shift;
+    d.kpar_off = (int64_t)lay.n_kpar;   lay.n_kpar += (size_t)r.K;
+    d.evm_off = (int64_t)lay.n_evm;     lay.n_evm += align_up((size_t)r.E + 64, 4);
+    d.code_off = (int64_t)lay.n_code;   lay.n_code += align_up((size_t)(r.E + r.K) / 16 + 2, 4);
+    d.trace_off = (int64_t)lay.n_trace; lay.n_trace += (size_t)d.n_groups * 64;
+    /* align.c:207-216, doubles, glibc */
+    volatile double eps = 1e-10, trim_p = 0.01;
+    double events_per_kmer = (double)(size_t)r.E / (size_t)r.K;
+    double p_stay = 1 - (1 / (events_per_kmer + 1));
+    d.lp_skip = log(eps);
+    d.lp_stay = log(p_stay);
+    d.lp_step = log(1.0 - exp(d.lp_skip) - exp(d.lp_stay));
+    d.lp_trim = log(trim_p);
+    st.sum_events += r.E; st.sum_bands += r.n_bands;
+    /* SURVEY §8d algorithmic bytes; P is added after the run from n_pairs */
+    const uint64_t Bn = (uint64_t)r.n_bands;
+    st.bytes_ref += 24ull * r.E + (uint64_t)(r.L + 1) + 40 + 108ull * Bn + 4;
+    st.bytes_min += 4ull * r.E + (uint64_t)(r.L + 3) / 4 + 40 + 25ull * Bn + (Bn + 7) / 8 + 4;
+    /* this implementation: pre (24E + L + 12K model gather -> 16K + 4E), fill (16K + 4E in, 32 B/band trace out),
+     * post (trace blocks on the path ~ 32 B/band worst case, codes, 16K+4E again, 8P out) */
+    st.bytes_moved += 24ull * r.E + r.L + 12ull * r.K + 2 * (16ull * r.K + 4ull * r.E) + 64ull * Bn +
+                      16ull * r.K + 4ull * r.E;
+}
+
+/* the align_single guard (f5c.c:813-814, E/L < 15.0f in float); reads shorter than k are UB in the reference
+ * (size_t underflow, align.c:191) and rejected here */
+static plan_read make_plan(int32_t idx, int32_t L, int32_t E, uint32_t k) {
+    plan_read r;
+    r.idx = idx; r.L = L; r.E = E;
+    r.K = L - (int32_t)k + 1;
+    r.run = E > 0 && r.K >= 1 && ((float)E / (float)L) < 15.0f;
+    r.n_bands = (int64_t)E + r.K + 2;
+    return r;
+}
+
 static int ensure_pinned(void** p, size_t* cap, size_t need) {
     if (*cap >= need) return ABEA_OK;
     if (*p) hipHostFree(*p);
@@ -246,12 +310,7 @@ extern "C" int abea_align_batch_device(abea_ctx* c, const abea_device_batch* B) 
     std::vector<int32_t> skipped;
     for (int32_t i = 0; i < n; ++i) {
         plan_read& r = reads[(size_t)i];
-        r.idx = i; r.L = B->read_len[i]; r.E = B->n_events[i];
-        r.K = r.L - (int32_t)c->k + 1;
-        /* align_single guard f5c.c:813-814 (E/L < 15.0f in float); reads shorter than k are UB in the
-         * reference (size_t underflow align.c:191) and rejected here */
-        r.run = r.E > 0 && r.K >= 1 && ((float)r.E / (float)r.L) < 15.0f;
-        r.n_bands = (int64_t)r.E + r.K + 2;
+        r = make_plan(i, B->read_len[i], B->n_events[i], c->k);
         if (r.run) order.push_back(i); else skipped.push_back(i);
     }
     std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) {
@@ -263,9 +322,6 @@ extern "C" int abea_align_batch_device(abea_ctx* c, const abea_device_batch* B) 
     std::vector<int32_t> seq; seq.reserve((size_t)n);
     seq.insert(seq.end(), order.begin(), order.end());
     seq.insert(seq.end(), skipped.begin(), skipped.end());
-
-    volatile double eps = 1e-10, trim_p = 0.01;
-    const double lp_skip = log(eps), lp_trim = log(trim_p);        /* align.c:212-216 */
 
     size_t pos = 0;
     while (pos < seq.size()) {
@@ -285,39 +341,15 @@ extern "C" int abea_align_batch_device(abea_ctx* c, const abea_device_batch* B) 
         if (rc) return rc;
 
         /* ---- arena layout: [desc][kpar][evm][codes][trace] ---- */
-        size_t n_kpar = 0, n_evm = 0, n_code = 0, n_trace = 0;
+        sub_layout lay;
         for (size_t j = 0; j < m; ++j) {
             const plan_read& r = reads[(size_t)seq[pos + j]];
             abea_read_desc& d = c->h_desc[j];
-            memset(&d, 0, sizeof d);
-            d.out_idx = r.idx;
+            plan_desc(d, r, (int)c->k, B->scalings[r.idx], lay, st);
             d.read_off = B->read_ptr[r.idx]; d.event_off = B->event_ptr[r.idx]; d.pair_off = B->pair_ptr[r.idx];
             d.kmer_off = B->kmer_ptr ? B->kmer_ptr[r.idx] : 0;
-            d.read_len = r.L; d.n_events = r.E; d.n_kmers = r.K;
-            if (!r.run) { d.n_groups = 0; continue; }
-            d.n_groups = (int32_t)((r.n_bands + ABEA_GROUP - 1) / ABEA_GROUP);
-            d.scale = B->scalings[r.idx].scale; d.shift = B->scalings[r.idx].shift;
-            d.kpar_off = (int64_t)n_kpar;  n_kpar += (size_t)r.K;
-            d.evm_off = (int64_t)n_evm;    n_evm += align_up((size_t)r.E + 64, 4);
-            d.code_off = (int64_t)n_code;  n_code += align_up((size_t)(r.E + r.K) / 16 + 2, 4);
-            d.trace_off = (int64_t)n_trace; n_trace += (size_t)d.n_groups * 64;
-            /* align.c:207-216, doubles, glibc */
-            double events_per_kmer = (double)(size_t)r.E / (size_t)r.K;
-            double p_stay = 1 - (1 / (events_per_kmer + 1));
-            d.lp_skip = lp_skip;
-            d.lp_stay = log(p_stay);
-            d.lp_step = log(1.0 - exp(lp_skip) - exp(d.lp_stay));
-            d.lp_trim = lp_trim;
-            st.sum_events += r.E; st.sum_bands += r.n_bands;
-            /* SURVEY §8d algorithmic bytes; P is added after the run from n_pairs */
-            const uint64_t Bn = (uint64_t)r.n_bands;
-            st.bytes_ref += 24ull * r.E + (uint64_t)(r.L + 1) + 40 + 108ull * Bn + 4;
-            st.bytes_min += 4ull * r.E + (uint64_t)(r.L + 3) / 4 + 40 + 25ull * Bn + (Bn + 7) / 8 + 4;
-            /* this implementation: pre (24E + L + 12K model gather -> 16K + 4E), fill (16K + 4E in, 32 B/band trace out),
-             * post (trace blocks on the path ~ 32 B/band worst case, codes, 16K+4E again, 8P out) */
-            st.bytes_moved += 24ull * r.E + r.L + 12ull * r.K + 2 * (16ull * r.K + 4ull * r.E) + 64ull * Bn +
-                              16ull * r.K + 4ull * r.E;
         }
+        const size_t n_kpar = lay.n_kpar, n_evm = lay.n_evm, n_code = lay.n_code, n_trace = lay.n_trace;
         uint8_t* p = c->arena;
         abea_read_desc* d_desc = (abea_read_desc*)p;        p += align_up(m * sizeof(abea_read_desc), 256);
         abea_kpar_t* d_kpar = (abea_kpar_t*)p;              p += align_up(n_kpar * sizeof(abea_kpar_t), 256);
@@ -481,6 +513,44 @@ template <class F> static void parallel_for(int32_t n, int threads, F fn) {
 }
 
 /* ------------------------------------------------------------------ host batch (db_t view) */
+/* Finish the chunk in flight in `sl`: wait for its D2H, then un-flatten into the caller-owned per-read buffers
+ * (the role of f5c.cu:1003-1030; pairs arrive already ascending). */
+static int host_retire(abea_ctx* c, abea_ctx::host_slot& sl, const abea_host_batch* H, int host_threads, abea_stats& st,
+                       double& host_ms) {
+    if (!sl.busy) return ABEA_OK;
+    const int32_t* npairs = (const int32_t*)(sl.pinned + sl.o_npairs);
+    const abea_pair_t* pairs = (const abea_pair_t*)(sl.pinned + sl.o_pairs);
+    const abea_read_diag* diag = (const abea_read_diag*)(sl.pinned + sl.o_diag);
+    const int32_t first = sl.first;
+    int32_t lo = 0;
+    for (int q = 0; q < abea_ctx::host_slot::N_PIECES; ++q) {           /* piece q un-flattens while piece q+1 is still copying */
+        HIP_TRY(hipEventSynchronize(sl.piece_done[q]));
+        const int32_t hi = sl.piece_end[q];
+        const double t0 = now_ms();
+        parallel_for(hi - lo, host_threads, [&](int32_t t) {
+            const int32_t j = lo + t, i = first + j;
+            const int32_t np = npairs[j];
+            H->n_pairs[i] = np;
+            if (np > 0) memcpy(H->pairs[i], pairs + sl.pair_off[(size_t)j], (size_t)np * sizeof(abea_pair_t));
+            if (H->diag) H->diag[i] = diag[j];
+        });
+        host_ms += now_ms() - t0;
+        lo = hi;
+    }
+    HIP_TRY(hipEventSynchronize(sl.done));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, sl.k0, sl.k1));
+    st.fill_ms += ms;
+    for (int32_t j = 0; j < sl.count; ++j) st.sum_pairs += npairs[j];
+    sl.busy = false;
+    (void)c;
+    return ABEA_OK;
+}
+
+/* Replaces align_cuda (f5c.cu:647-1061).  The batch is cut into chunks of reads; each chunk is flattened into pinned
+ * memory (sequence + event means only: ABEA reads nothing else of event_t, align.c:131), copied, aligned and copied
+ * back on its slot's stream, so that the host copies, both PCIe directions and the kernels of neighbouring chunks
+ * overlap.  Results do not depend on the chunking (reads are independent). */
 extern "C" int abea_align_batch_host(abea_ctx* c, const abea_host_batch* H) {
     if (!c || !H) return fail(ABEA_EINVAL, "null argument");
     const int32_t n = H->n_reads;
@@ -488,77 +558,185 @@ extern "C" int abea_align_batch_host(abea_ctx* c, const abea_host_batch* H) {
     if (n == 0) { memset(&c->stats, 0, sizeof c->stats); return ABEA_OK; }
     if (!H->read || !H->read_len || !H->events || !H->n_events || !H->scalings || !H->pairs || !H->n_pairs)
         return fail(ABEA_EINVAL, "abea_align_batch_host: null array");
-    const double t0 = now_ms();
+    const double t_start = now_ms();
     HIP_TRY(hipSetDevice(c->device));
+    abea_stats st; memset(&st, 0, sizeof st);
+    st.arena_bytes = c->arena_bytes;
+    double host_ms = 0;
 
-    /* ---- flatten (the role of f5c.cu:744-802) ---- */
-    std::vector<int64_t> read_ptr((size_t)n), event_ptr((size_t)n), pair_ptr((size_t)n);
-    std::vector<int32_t> n_events((size_t)n), read_len((size_t)n);
-    size_t sum_read = 0, sum_ev = 0, sum_pair = 0;
+    std::vector<plan_read> reads((size_t)n);
     for (int32_t i = 0; i < n; ++i) {
         const bool good = (!H->n_samples || H->n_samples[i] > 0) && H->read[i] && H->events[i] && H->pairs[i] &&
                           H->read_len[i] > 0 && H->n_events[i] > 0 && H->n_events[i] < (uint64_t)INT32_MAX;
-        read_len[(size_t)i] = good ? H->read_len[i] : 0;       /* bad read (nsample == 0): n_pairs = 0 (f5c.c:826-828) */
-        n_events[(size_t)i] = good ? (int32_t)H->n_events[i] : 0;
-        read_ptr[(size_t)i] = (int64_t)sum_read;  sum_read += (size_t)read_len[(size_t)i] + 1;
-        event_ptr[(size_t)i] = (int64_t)sum_ev;   sum_ev += (size_t)n_events[(size_t)i];
-        pair_ptr[(size_t)i] = (int64_t)sum_pair;  sum_pair += (size_t)n_events[(size_t)i] + (size_t)read_len[(size_t)i];
+        /* bad read (nsample == 0): n_pairs = 0 (f5c.c:826-828) */
+        reads[(size_t)i] = make_plan(i, good ? H->read_len[i] : 0, good ? (int32_t)H->n_events[i] : 0, c->k);
+        if (reads[(size_t)i].run) ++st.n_reads_gpu; else ++st.n_reads_skipped;
     }
-    int rc;
-    if ((rc = ensure_pinned((void**)&c->h_reads, &c->h_reads_cap, sum_read + 16))) return rc;
-    if ((rc = ensure_pinned((void**)&c->h_events, &c->h_events_cap, (sum_ev + 1) * sizeof(abea_event_t)))) return rc;
-    if ((rc = ensure_pinned((void**)&c->h_pairs, &c->h_pairs_cap, (sum_pair + 1) * sizeof(abea_pair_t)))) return rc;
-    if ((rc = ensure_pinned((void**)&c->h_npairs, &c->h_npairs_cap, (size_t)n * sizeof(int32_t)))) return rc;
-    if ((rc = ensure_pinned((void**)&c->h_diag, &c->h_diag_cap, (size_t)n * sizeof(abea_read_diag)))) return rc;
-    if ((rc = ensure_dev((void**)&c->d_reads, &c->d_reads_cap, sum_read + 16))) return rc;
-    if ((rc = ensure_dev((void**)&c->d_events, &c->d_events_cap, (sum_ev + 1) * sizeof(abea_event_t)))) return rc;
-    if ((rc = ensure_dev((void**)&c->d_pairs, &c->d_pairs_cap, (sum_pair + 1) * sizeof(abea_pair_t)))) return rc;
-    if ((rc = ensure_dev((void**)&c->d_npairs, &c->d_npairs_cap, (size_t)n * sizeof(int32_t)))) return rc;
-    if ((rc = ensure_dev((void**)&c->d_diag, &c->d_diag_cap, (size_t)n * sizeof(abea_read_diag)))) return rc;
-
     const int host_threads = (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
-    parallel_for(n, host_threads, [&](int32_t i) {         /* the reference flattens on one thread (f5c.cu:744-802) */
-        const size_t L = (size_t)read_len[(size_t)i], E = (size_t)n_events[(size_t)i];
-        if (L) memcpy(c->h_reads + read_ptr[(size_t)i], H->read[i], L);
-        c->h_reads[read_ptr[(size_t)i] + (int64_t)L] = '\0';
-        if (E) memcpy(c->h_events + event_ptr[(size_t)i], H->events[i], E * sizeof(abea_event_t));
-    });
-    const double t1 = now_ms();
-    HIP_TRY(hipMemcpyAsync(c->d_reads, c->h_reads, sum_read, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync(c->d_events, c->h_events, sum_ev * sizeof(abea_event_t), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    const double t2 = now_ms();
+    size_t target_events = (size_t)64 << 20;   /* a launch lasts as long as its longest read: keep chunks big */
+    if (const char* e = getenv("ABEA_HOST_CHUNK_EVENTS")) target_events = std::max<size_t>(1, strtoull(e, nullptr, 10));
+    const size_t slot_arena = c->arena_bytes / abea_ctx::N_SLOTS / 4096 * 4096;
 
-    abea_device_batch D;
-    memset(&D, 0, sizeof D);
-    D.n_reads = n;
-    D.read_ptr = read_ptr.data(); D.read_len = read_len.data();
-    D.event_ptr = event_ptr.data(); D.n_events = n_events.data(); D.pair_ptr = pair_ptr.data();
-    D.scalings = H->scalings;
-    D.reads = c->d_reads; D.events = c->d_events; D.pairs = c->d_pairs; D.n_pairs = c->d_npairs;
-    D.diag = H->diag ? c->d_diag : nullptr;
-    rc = abea_align_batch_device(c, &D);
-    if (rc) return rc;
-    abea_stats st = c->stats;
+    /* device + pinned bytes one read adds to a chunk besides scratch_bytes(): sequence, pair capacity, n_pairs, diag */
+    auto io_bytes = [](const plan_read& r) {
+        return align_up((size_t)r.L + 1, 16) + ((size_t)r.E + (size_t)r.L) * sizeof(abea_pair_t) + 4 + sizeof(abea_read_diag);
+    };
+    int32_t pos = 0, turn = 0;
+    std::vector<int32_t> order;
+    while (pos < n) {
+        /* ---- carve a chunk ---- */
+        size_t bytes = 65536, ev = 0;
+        int32_t end = pos;
+        bool whole_arena = false;
+        while (end < n) {
+            const plan_read& r = reads[(size_t)end];
+            const size_t need = (r.run ? scratch_bytes(r) : sizeof(abea_read_desc)) + io_bytes(r) + 1024;
+            if (bytes + need > slot_arena) {
+                if (end > pos) break;
+                if (bytes + need > c->arena_bytes)
+                    return fail(ABEA_ENOMEM, "read %d (L=%d, E=%d) needs more scratch than the %zu-byte arena", end, r.L, r.E,
+                                c->arena_bytes);
+                whole_arena = true;                      /* an over-long read: give it the whole arena, alone */
+            }
+            bytes += need; ev += (size_t)r.E; ++end;
+            if (ev >= target_events || whole_arena) break;
+        }
+        const int32_t m = end - pos;
+        abea_ctx::host_slot& sl = c->slot[whole_arena ? 0 : turn % abea_ctx::N_SLOTS];
+        int rc;
+        if (whole_arena) { for (auto& o : c->slot) if ((rc = host_retire(c, o, H, host_threads, st, host_ms))) return rc; }
+        else if ((rc = host_retire(c, sl, H, host_threads, st, host_ms))) return rc;
+        uint8_t* arena = whole_arena ? c->arena : c->arena + (size_t)(turn % abea_ctx::N_SLOTS) * slot_arena;
 
-    const double t3 = now_ms();
-    HIP_TRY(hipMemcpyAsync(c->h_npairs, c->d_npairs, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipMemcpyAsync(c->h_pairs, c->d_pairs, sum_pair * sizeof(abea_pair_t), hipMemcpyDeviceToHost, c->stream));
-    if (H->diag)
-        HIP_TRY(hipMemcpyAsync(c->h_diag, c->d_diag, (size_t)n * sizeof(abea_read_diag), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    const double t4 = now_ms();
-    /* un-flatten into the caller-owned per-read buffers (f5c.cu:1003-1030; pairs already ascending) */
-    parallel_for(n, host_threads, [&](int32_t i) {
-        const int32_t np = c->h_npairs[i];
-        H->n_pairs[i] = np;
-        if (np > 0) memcpy(H->pairs[i], c->h_pairs + pair_ptr[(size_t)i], (size_t)np * sizeof(abea_pair_t));
-        if (H->diag) H->diag[i] = c->h_diag[i];
-    });
-    for (int32_t i = 0; i < n; ++i) st.sum_pairs += c->h_npairs[i];
-    const double t5 = now_ms();
-    st.h2d_ms = t2 - t1; st.d2h_ms = t4 - t3; st.host_ms = (t1 - t0) + (t5 - t4);
-    st.total_ms = t5 - t0;
+        /* ---- plan: longest first, skipped reads last (n_groups == 0 descriptors) ---- */
+        const double t0 = now_ms();
+        order.clear();
+        for (int32_t i = pos; i < end; ++i) if (reads[(size_t)i].run) order.push_back(i);
+        std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) {
+            return reads[(size_t)a].n_bands > reads[(size_t)b].n_bands; });
+        for (int32_t i = pos; i < end; ++i) if (!reads[(size_t)i].run) order.push_back(i);
+        size_t n_read = 0, n_pair = 0;
+        for (int32_t i = pos; i < end; ++i) {
+            n_read += align_up((size_t)reads[(size_t)i].L + 1, 16);
+            n_pair += (size_t)reads[(size_t)i].E + (size_t)reads[(size_t)i].L;
+        }
+        /* pinned block: [desc][reads][evm] go up, [npairs][pairs][diag] come down */
+        std::vector<abea_read_desc> descs((size_t)m);
+        sub_layout lay;
+        {
+            size_t ro = 0, po = 0;
+            std::vector<int64_t> roff((size_t)m);
+            std::vector<int64_t>& poff = sl.pair_off;
+            poff.resize((size_t)m + 1);
+            for (int32_t i = pos; i < end; ++i) {         /* sequences and pair lists keep the caller's order */
+                roff[(size_t)(i - pos)] = (int64_t)ro; ro += align_up((size_t)reads[(size_t)i].L + 1, 16);
+                poff[(size_t)(i - pos)] = (int64_t)po; po += (size_t)reads[(size_t)i].E + (size_t)reads[(size_t)i].L;
+            }
+            poff[(size_t)m] = (int64_t)po;
+            for (int32_t j = 0; j < m; ++j) {
+                plan_read r = reads[(size_t)order[(size_t)j]];
+                r.idx = order[(size_t)j] - pos;           /* out_idx is chunk-local */
+                plan_desc(descs[(size_t)j], r, (int)c->k, H->scalings[order[(size_t)j]], lay, st);
+                descs[(size_t)j].read_off = roff[(size_t)r.idx];
+                descs[(size_t)j].pair_off = poff[(size_t)r.idx];
+            }
+        }
+        size_t o = 0;
+        sl.o_desc = o;                 o = align_up(o + (size_t)m * sizeof(abea_read_desc), 256);
+        const size_t o_reads = o;      o = align_up(o + n_read, 256);
+        const size_t o_evm = o;        o = align_up(o + lay.n_evm * 4 + 512, 256);
+        sl.o_npairs = o;               o = align_up(o + (size_t)m * 4, 256);
+        sl.o_pairs = o;                o = align_up(o + n_pair * sizeof(abea_pair_t), 256);
+        sl.o_diag = o;                 o = align_up(o + (size_t)m * sizeof(abea_read_diag), 256);
+        if ((rc = ensure_pinned((void**)&sl.pinned, &sl.pinned_cap, o))) return rc;
+        memcpy(sl.pinned + sl.o_desc, descs.data(), (size_t)m * sizeof(abea_read_desc));
+
+        /* ---- arena layout: [desc][kpar][evm][codes][trace][reads][npairs][pairs][diag] ---- */
+        uint8_t* p = arena;
+        abea_read_desc* d_desc = (abea_read_desc*)p;        p += align_up((size_t)m * sizeof(abea_read_desc), 256);
+        abea_kpar_t* d_kpar = (abea_kpar_t*)p;              p += align_up(lay.n_kpar * sizeof(abea_kpar_t), 256);
+        float* d_evm = (float*)p;                           p += align_up(lay.n_evm * 4 + 512, 256);
+        uint32_t* d_codes = (uint32_t*)p;                   p += align_up(lay.n_code * 4, 256);
+        uint4* d_trace = (uint4*)p;                         p += align_up(lay.n_trace * sizeof(uint4), 256);
+        char* d_reads = (char*)p;                           p += align_up(n_read, 256);
+        int32_t* d_npairs = (int32_t*)p;                    p += align_up((size_t)m * 4, 256);
+        abea_pair_t* d_pairs = (abea_pair_t*)p;             p += align_up(n_pair * sizeof(abea_pair_t), 256);
+        abea_read_diag* d_diag = (abea_read_diag*)p;        p += align_up((size_t)m * sizeof(abea_read_diag), 256);
+        if ((size_t)(p - arena) > (whole_arena ? c->arena_bytes : slot_arena))
+            return fail(ABEA_ENOMEM, "internal: chunk layout %zu exceeds its arena share %zu", (size_t)(p - arena),
+                        whole_arena ? c->arena_bytes : slot_arena);
+
+        /* ---- flatten (the role of f5c.cu:744-802, which runs on one thread) and copy up, piece by piece ---- */
+        const int NP = abea_ctx::host_slot::N_PIECES;
+        char* h_reads = (char*)(sl.pinned + o_reads);
+        float* h_evm = (float*)(sl.pinned + o_evm);
+        parallel_for(m, host_threads, [&](int32_t j) {
+            const abea_read_desc& d = descs[(size_t)j];
+            const size_t L = (size_t)d.read_len;
+            if (L) memcpy(h_reads + d.read_off, H->read[pos + d.out_idx], L);
+            h_reads[d.read_off + (int64_t)L] = '\0';
+        });
+        HIP_TRY(hipMemcpyAsync(d_desc, sl.pinned + sl.o_desc, (size_t)m * sizeof(abea_read_desc), hipMemcpyHostToDevice, sl.stream));
+        HIP_TRY(hipMemcpyAsync(d_reads, h_reads, n_read, hipMemcpyHostToDevice, sl.stream));
+        int32_t j0 = 0;
+        for (int q = 0; q < NP; ++q) {                     /* descriptors are in evm order: a j-range is one contiguous span */
+            const size_t want = lay.n_evm * (size_t)(q + 1) / NP;
+            int32_t j1 = j0;
+            while (j1 < m && (q == NP - 1 || descs[(size_t)j1].n_groups == 0 || (size_t)descs[(size_t)j1].evm_off < want)) ++j1;
+            parallel_for(j1 - j0, host_threads, [&](int32_t t) {
+                const abea_read_desc& d = descs[(size_t)(j0 + t)];
+                if (d.n_groups == 0) return;
+                const abea_event_t* ev = H->events[pos + d.out_idx];
+                float* dst = h_evm + d.evm_off;
+                for (int32_t e = 0; e < d.n_events; ++e) dst[e] = ev[e].mean;
+            });
+            size_t e0 = lay.n_evm, e1 = lay.n_evm;         /* span of this piece in evm (skipped reads own none) */
+            for (int32_t j = j0; j < j1; ++j) if (descs[(size_t)j].n_groups) { e0 = (size_t)descs[(size_t)j].evm_off; break; }
+            for (int32_t j = j1; j < m; ++j) if (descs[(size_t)j].n_groups) { e1 = (size_t)descs[(size_t)j].evm_off; break; }
+            if (e1 > e0)
+                HIP_TRY(hipMemcpyAsync(d_evm + e0, h_evm + e0, (e1 - e0) * 4, hipMemcpyHostToDevice, sl.stream));
+            j0 = j1;
+        }
+        host_ms += now_ms() - t0;
+
+        /* ---- kernels, then copy down in pieces of the caller's order ---- */
+        HIP_TRY(hipEventRecord(sl.k0, sl.stream));
+        hipLaunchKernelGGL(abea_pre_kernel, dim3((unsigned)m), dim3(256), 0, sl.stream,
+                           d_desc, d_reads, (const abea_event_t*)nullptr, c->d_model, (int)c->k, d_kpar, d_evm);
+        hipLaunchKernelGGL(abea_align_kernel, dim3((unsigned)m), dim3(64), 0, sl.stream,
+                           d_desc, d_evm, d_kpar, d_trace, d_codes, d_pairs, d_npairs, H->diag ? d_diag : nullptr);
+        HIP_TRY(hipEventRecord(sl.k1, sl.stream));
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(sl.pinned + sl.o_npairs, d_npairs, (size_t)m * 4, hipMemcpyDeviceToHost, sl.stream));
+        if (H->diag)
+            HIP_TRY(hipMemcpyAsync(sl.pinned + sl.o_diag, d_diag, (size_t)m * sizeof(abea_read_diag), hipMemcpyDeviceToHost, sl.stream));
+        int32_t i0 = 0;
+        for (int q = 0; q < NP; ++q) {
+            const int64_t want = sl.pair_off[(size_t)m] * (q + 1) / NP;
+            int32_t i1 = i0;
+            while (i1 < m && (q == NP - 1 || sl.pair_off[(size_t)i1 + 1] <= want)) ++i1;
+            const int64_t p0 = sl.pair_off[(size_t)i0], p1 = sl.pair_off[(size_t)i1];
+            if (p1 > p0)
+                HIP_TRY(hipMemcpyAsync(sl.pinned + sl.o_pairs + (size_t)p0 * sizeof(abea_pair_t), d_pairs + p0,
+                                       (size_t)(p1 - p0) * sizeof(abea_pair_t), hipMemcpyDeviceToHost, sl.stream));
+            HIP_TRY(hipEventRecord(sl.piece_done[q], sl.stream));
+            sl.piece_end[q] = i1;
+            i0 = i1;
+        }
+        HIP_TRY(hipEventRecord(sl.done, sl.stream));
+        sl.busy = true; sl.first = pos; sl.count = m;
+        st.n_sub_batches += 1; st.fill_launches += 1;
+        if (whole_arena) { if ((rc = host_retire(c, sl, H, host_threads, st, host_ms))) return rc; }
+        else ++turn;
+        pos = end;
+    }
+    /* ---- drain, oldest chunk first ---- */
+    for (int q = 0; q < abea_ctx::N_SLOTS; ++q) {
+        int rc = host_retire(c, c->slot[(turn + q) % abea_ctx::N_SLOTS], H, host_threads, st, host_ms);
+        if (rc) return rc;
+    }
+    st.host_ms = host_ms;              /* flatten + un-flatten wall time; the copies overlap it, so h2d/d2h stay 0 */
+    st.total_ms = now_ms() - t_start;
     c->stats = st;
     return ABEA_OK;
 }

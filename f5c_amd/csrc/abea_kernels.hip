@@ -112,6 +112,7 @@ void abea_pre_kernel(const abea_read_desc* __restrict__ descs,
         p.istd = 1.0 / (double)m.level_stdv;
         kp[i] = p;
     }
+    if (!events) return;                               /* host path: the means were uploaded straight into evm */
     const abea_event_t* ev = events + d->event_off;
     float* evm = evm_all + d->evm_off;
     for (int i = threadIdx.x; i < E; i += blockDim.x) evm[i] = ev[i].mean;   /* align.c:131 reads .mean only */

@@ -238,3 +238,36 @@ def test_scaling_single_on_device(ctx, orc, r9):
                 assert sc["var"][i] == r["scalings"]["var"]
                 n_cal += 1
     assert n_cal >= 35 and (flags == 2).sum() >= 2
+
+
+def test_baseline_config2_full_size_bit_exact(orc, r9):
+    """BASELINE.json configs[1] at full size (10 000 reads, ~160 M events, seed 20250002): every pair list, n_pairs and
+    the integer diagnostics equal the oracle's (16 host threads, ~20 s), plus two size-independent properties:
+    pairs strictly ascending per read, and a second run is bit-identical (no uninitialised scratch)."""
+    import os, zlib
+    from f5c_amd import abea, synth
+    k, model = r9
+    cfg = synth.CONFIGS["r9_10k_8kb"]
+    workers = max(1, min(16, len(os.sched_getaffinity(0))))
+    batch = synth.make_batch(cfg["n_reads"], model, k, seed=cfg["seed"], law=cfg["law"], workers=workers)
+    big = abea.AbeaContext(model, k, max_arena_bytes=48 << 30)
+    try:
+        d = abea.AbeaContext.upload(batch)
+        big.align_db_device(d)
+        pairs, n_pairs, diag = big.download(d)
+        crc1 = zlib.crc32(pairs.tobytes()) ^ zlib.crc32(n_pairs.tobytes())
+        ora = orc.align_batch(batch, model, k, n_threads=workers)
+        _check_batch(batch, (pairs, n_pairs, diag), ora, "config2")
+        assert (n_pairs > 0).mean() > 0.95                       # SURVEY 8d: QC-pass fraction
+        flat = pairs.view(np.int32).reshape(-1, 2)
+        for i in np.random.default_rng(0).choice(len(n_pairs), 200, replace=False):
+            s, m = int(batch["pair_ptr"][i]), int(n_pairs[i])
+            if m > 1:
+                seg = flat[s:s + m].astype(np.int64)
+                step = np.diff(seg, axis=0)
+                assert (step >= 0).all() and (step.sum(axis=1) > 0).all()
+        big.align_db_device(d)
+        pairs2, n_pairs2, _ = big.download(d)
+        assert (zlib.crc32(pairs2.tobytes()) ^ zlib.crc32(n_pairs2.tobytes())) == crc1
+    finally:
+        big.close()

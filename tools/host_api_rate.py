@@ -3,9 +3,10 @@
 un-flatten) and the cost of the optional scaling kernel; numbers quoted in DESIGN.md §6."""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 from f5c_amd import abea, synth, load_model_f32
-k, model = load_model_f32("tests/golden/r9.4_450bps.6mer.f32")
+k, model = load_model_f32(os.path.join(ROOT, "tests/golden/r9.4_450bps.6mer.f32"))
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
 b = synth.make_batch(n, model, k, seed=20250002, law="gamma8k", workers=16)
 ev = int(b["n_events"].sum())
