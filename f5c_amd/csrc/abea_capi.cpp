@@ -41,7 +41,15 @@ __global__ void abea_ev_sums_kernel(int, const int32_t*, const int16_t*, const i
 __global__ void abea_ev_tstat_kernel(int, const int32_t*, const int32_t*, const int64_t*, const int32_t*, const double*,
                                      const double*, float*, float*);
 __global__ void abea_ev_detect_kernel(int, const int32_t*, const int32_t*, const int64_t*, const float*, const float*,
-                                      const int64_t*, const int32_t*, int32_t*, int32_t*);
+                                      const int64_t*, const int32_t*, int32_t*, int32_t*, const int32_t*);
+__global__ void abea_ev_spec_kernel(int, const int32_t*, const int32_t*, const int64_t*, const float*, const float*,
+                                    const int64_t*, const int32_t*, uint16_t*, int32_t*);
+__global__ void abea_ev_fix_kernel(int, const int32_t*, const int32_t*, const int64_t*, const float*, const float*,
+                                   const int64_t*, const int32_t*, int32_t*, int32_t*, int32_t*);
+__global__ void abea_ev_scan_kernel(int, const int32_t*, const int32_t*, const int64_t*, int32_t*, int32_t*);
+__global__ void abea_ev_gather_kernel(int, const int32_t*, const int32_t*, const int64_t*, const int32_t*,
+                                      const uint16_t*, const int32_t*, const int32_t*, const int64_t*, const int32_t*,
+                                      int32_t*);
 __global__ void abea_ev_create_kernel(int, const int32_t*, const int32_t*, const int64_t*, const double*, const double*,
                                       const int64_t*, const int32_t*, const int32_t*, const int32_t*, const int32_t*,
                                       abea_event_t*, const int64_t*, float*);
@@ -416,11 +424,12 @@ extern "C" int abea_detect_events_device(abea_ctx* c, const abea_signal_batch* B
     while (w0 < n_waves_all) {
         /* ---- carve waves whose interleaved scratch fits the arena: per sample S,Q fp64 + two float t-statistics
          *      (24 B), per event slot a peak position + a mean (8 B) ---- */
-        const size_t idx_bytes = N * (4 + 8 + 4 + 12 + 8 + 4 + 8 + 4) + (size_t)n_waves_all * 40 + 8192;
+        const size_t idx_bytes = N * (4 + 8 + 4 + 12 + 8 + 4 + 8 + 4 + 4) + (size_t)n_waves_all * 56 + 8192;
         if (idx_bytes + (1u << 20) > c->arena_bytes) return fail(ABEA_ENOMEM, "arena too small for %d index records", n);
         const size_t budget = c->arena_bytes - idx_bytes - 4096;
-        std::vector<int64_t> wave_base, peak_base, kmer_base; std::vector<int32_t> wave_len, wave_cap, wave_k;
-        size_t entries = 0, pentries = 0, kentries = 0;
+        std::vector<int64_t> wave_base, peak_base, kmer_base, seg_base; std::vector<int32_t> wave_len, wave_cap, wave_k, wave_nseg;
+        size_t entries = 0, pentries = 0, kentries = 0, segs = 0;
+        const size_t EV_SEG = 512, EV_FIXCAP = 48, SEG_BYTES = 64 * (EV_SEG * 2 + EV_FIXCAP * 4 + 12 * 4);   /* abea_kernels.hip */
         int w1 = w0;
         while (w1 < n_waves_all) {
             const int32_t len = B->n_samples[order[(size_t)w1 * 64]] + 1;      /* longest read of the wave, +1 for S[n] */
@@ -430,7 +439,9 @@ extern "C" int abea_detect_events_device(abea_ctx* c, const abea_signal_batch* B
                 if (B->scalings) wk = std::max(wk, B->read_len[order[(size_t)q]] - (int32_t)c->k + 1);
             }
             const size_t need = (size_t)std::max(len, 1) * 64, pneed = (size_t)cap * 64, kneed = (size_t)wk * 64;
-            if ((entries + need) * 24 + (pentries + pneed) * 8 + (kentries + kneed) * 4 > budget) break;
+            const size_t nseg = std::max<size_t>(1, ((size_t)std::max(len - 1, 0) + EV_SEG - 1) / EV_SEG);
+            if ((entries + need) * 24 + (pentries + pneed) * 8 + (kentries + kneed) * 4 + (segs + nseg) * SEG_BYTES + 4096 > budget) break;
+            seg_base.push_back((int64_t)segs); wave_nseg.push_back((int32_t)nseg); segs += nseg;
             wave_base.push_back((int64_t)entries); wave_len.push_back(len);
             peak_base.push_back((int64_t)pentries); wave_cap.push_back(cap);
             kmer_base.push_back((int64_t)kentries); wave_k.push_back(wk);
@@ -452,6 +463,8 @@ extern "C" int abea_detect_events_device(abea_ctx* c, const abea_signal_batch* B
         const size_t o_wb = put(wave_base.data(), (size_t)nw * 8), o_wl = put(wave_len.data(), (size_t)nw * 4);
         const size_t o_pb = put(peak_base.data(), (size_t)nw * 8), o_wc = put(wave_cap.data(), (size_t)nw * 4);
         const size_t o_kb = put(kmer_base.data(), (size_t)nw * 8), o_wk = put(wave_k.data(), (size_t)nw * 4);
+        const size_t o_sb = put(seg_base.data(), (size_t)nw * 8), o_wn = put(wave_nseg.data(), (size_t)nw * 4);
+        const size_t o_need = put(nullptr, N * 4);                    /* per-read "segments never met" flags, zeroed */
         double* dS = (double*)(d + align_up(o, 256));
         double* dQ = dS + entries;
         float* dT1 = (float*)(dQ + entries);
@@ -459,6 +472,11 @@ extern "C" int abea_detect_events_device(abea_ctx* c, const abea_signal_batch* B
         int32_t* dPk = (int32_t*)(dT2 + entries);
         float* dMean = (float*)(dPk + pentries);
         float* dKm = dMean + pentries;
+        uint8_t* dSegs = (uint8_t*)(dKm + kentries);
+        dSegs += (256 - ((uintptr_t)dSegs & 255)) & 255;
+        uint16_t* dSpec = (uint16_t*)dSegs;
+        int32_t* dFix = (int32_t*)(dSpec + segs * EV_SEG * 64);
+        int32_t* dRec = dFix + segs * EV_FIXCAP * 64;
         HIP_TRY(hipMemcpyAsync(d, h, o, hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipEventRecord(c->ev[0], c->stream));
         hipLaunchKernelGGL(abea_ev_sums_kernel, dim3((unsigned)nw), dim3(64), 0, c->stream,
@@ -468,9 +486,28 @@ extern "C" int abea_detect_events_device(abea_ctx* c, const abea_signal_batch* B
         hipLaunchKernelGGL(abea_ev_tstat_kernel, dim3(tiles, (unsigned)nw), dim3(256), 0, c->stream,
                            nr, (const int32_t*)(d + o_order), (const int32_t*)(d + o_ns), (const int64_t*)(d + o_wb),
                            (const int32_t*)(d + o_wl), dS, dQ, dT1, dT2);
+        /* pass 3: the automaton over (read, segment) pairs, then the sequential one for reads whose segments never met */
+        const int max_nseg = *std::max_element(wave_nseg.begin(), wave_nseg.end());
+        const dim3 sgrid((unsigned)((max_nseg + 3) / 4), (unsigned)nw);
+        hipLaunchKernelGGL(abea_ev_spec_kernel, sgrid, dim3(256), 0, c->stream,
+                           nr, (const int32_t*)(d + o_order), (const int32_t*)(d + o_ns), (const int64_t*)(d + o_wb),
+                           dT1, dT2, (const int64_t*)(d + o_sb), (const int32_t*)(d + o_wn), dSpec, dRec);
+        if (max_nseg > 1)
+            hipLaunchKernelGGL(abea_ev_fix_kernel, dim3((unsigned)((max_nseg - 1 + 3) / 4), (unsigned)nw), dim3(256), 0, c->stream,
+                               nr, (const int32_t*)(d + o_order), (const int32_t*)(d + o_ns), (const int64_t*)(d + o_wb),
+                               dT1, dT2, (const int64_t*)(d + o_sb), (const int32_t*)(d + o_wn), dFix, dRec,
+                               (int32_t*)(d + o_need));
+        hipLaunchKernelGGL(abea_ev_scan_kernel, dim3((unsigned)nw), dim3(64), 0, c->stream,
+                           nr, (const int32_t*)(d + o_order), (const int32_t*)(d + o_ns), (const int64_t*)(d + o_sb), dRec,
+                           B->n_events);
+        hipLaunchKernelGGL(abea_ev_gather_kernel, sgrid, dim3(256), 0, c->stream,
+                           nr, (const int32_t*)(d + o_order), (const int32_t*)(d + o_ns), (const int64_t*)(d + o_sb),
+                           (const int32_t*)(d + o_wn), dSpec, dFix, dRec, (const int64_t*)(d + o_pb),
+                           (const int32_t*)(d + o_ec), dPk);
         hipLaunchKernelGGL(abea_ev_detect_kernel, dim3((unsigned)nw), dim3(64), 0, c->stream,
                            nr, (const int32_t*)(d + o_order), (const int32_t*)(d + o_ns), (const int64_t*)(d + o_wb),
-                           dT1, dT2, (const int64_t*)(d + o_pb), (const int32_t*)(d + o_ec), dPk, B->n_events);
+                           dT1, dT2, (const int64_t*)(d + o_pb), (const int32_t*)(d + o_ec), dPk, B->n_events,
+                           getenv("ABEA_EV_SEQUENTIAL") ? (const int32_t*)nullptr : (const int32_t*)(d + o_need));
         const unsigned etiles = (unsigned)std::min<int64_t>(256, (wave_cap[0] + 3) / 4);
         hipLaunchKernelGGL(abea_ev_create_kernel, dim3(etiles, (unsigned)nw), dim3(256), 0, c->stream,
                            nr, (const int32_t*)(d + o_order), (const int32_t*)(d + o_ns), (const int64_t*)(d + o_wb),

@@ -730,8 +730,19 @@ void abea_scaling_kernel(const abea_read_desc* __restrict__ descs, const char* _
  *   pass 1  abea_ev_sums_kernel    lane-per-read: x = (adc+offset)*raw_unit, S[i+1] = S[i] + x, Q[i+1] = Q[i] + x*x
  *                                  (fp64, sample order; events.c:303-313)                      ~12 instr / sample
  *   pass 2  abea_ev_tstat_kernel   fully parallel over samples: the two windowed t-statistics (events.c:324-369)
- *   pass 3  abea_ev_detect_kernel  lane-per-read: the two-detector peak-picking automaton (events.c:380-452); its only
- *                                  output is the list of peak positions
+ *   pass 3  the two-detector peak-picking automaton (events.c:380-452); its only output is the list of peak
+ *           positions.  A fired peak resets its detector to a state that depends on the current sample alone, so a
+ *           run started from the reset state anywhere in the read falls into step with the true trajectory within a
+ *           few samples (measured: 4 on average, tools/proto/spec_detect.c).  That makes the automaton parallel over
+ *           segments of ABEA_EV_SEG samples, exactly:
+ *             3a abea_ev_spec_kernel   every (read, segment) from the reset state -> its peaks + end state
+ *             3b abea_ev_fix_kernel    every segment again from its predecessor's end state, in lockstep with a replay
+ *                                      of 3a, until the two states are equal: the true peaks of the prefix, how many of
+ *                                      3a's peaks that prefix replaces, and a per-read flag if they never met
+ *             3c abea_ev_scan_kernel   lane-per-read running sum of the per-segment peak counts
+ *             3d abea_ev_gather_kernel peaks into the per-read list
+ *             3e abea_ev_detect_kernel the sequential automaton, lane-per-read, for flagged reads only (by induction
+ *                                      over segments an unflagged read's list is the sequential one)
  *   pass 4  abea_ev_create_kernel  fully parallel over events: event_t from the prefix sums at consecutive peaks
  *                                  (events.c:466-513)
  *   pass 5  abea_ev_scalings_kernel lane-per-read: method-of-moments scalings (align.c:58-106)
@@ -825,16 +836,228 @@ void abea_ev_tstat_kernel(int n_reads, const int32_t* __restrict__ order, const 
     }
 }
 
+/* ---- pass 3: segment-parallel automaton ---- */
+#define ABEA_EV_SEG   512     /* samples per segment */
+#define ABEA_EV_FIX   64      /* a segment must meet its speculative replay within this many samples */
+#define ABEA_EV_FIXCAP 48     /* > 2 * (ABEA_EV_FIX / 3 + 1): a detector fires at most every third sample */
+
+struct abea_det2 { float pv0, pv1; int pp0, pp1; int v0, v1; int masked; };
+
+static __device__ __forceinline__ void det2_reset(abea_det2& s) {
+    s.pv0 = s.pv1 = 3.402823466e+38f; s.pp0 = s.pp1 = -1; s.v0 = s.v1 = 0; s.masked = -1;
+}
+/* events.c:380-452 at position p for both detectors, with selects.  Returns bit 0 / bit 1 = short / long detector
+ * fired; f0 / f1 = the peak positions they emit (short first, as in the reference's k loop). */
+static __device__ __forceinline__ int det2_step(abea_det2& s, int p, float c0, float c1, int& f0, int& f1) {
+    const float h = 0.2f;                                            /* peak_height, events.c:52-56 DNA */
+    int fired = 0;
+    {   /* short window: threshold 1.4, window 3; nothing ever masks it after position 0 */
+        const bool srch = s.pp0 == -1;
+        const bool lower = c0 < s.pv0;
+        const bool rise = !lower && (c0 - s.pv0 > h);
+        const bool higher = c0 > s.pv0;
+        const float pv_i = higher ? c0 : s.pv0;
+        const int pp_i = higher ? p : s.pp0;
+        const bool dom = !srch && (pv_i > 1.4f);                     /* masks the long detector (events.c:418-424) */
+        const bool valid_i = s.v0 || ((pv_i - c0 > h) && (pv_i > 1.4f));
+        const bool fire = !srch && valid_i && ((p - pp_i) > 1);
+        f0 = pp_i;
+        fired |= fire ? 1 : 0;
+        s.pv0 = srch ? ((lower || rise) ? c0 : s.pv0) : (fire ? c0 : pv_i);
+        s.pp0 = srch ? (rise ? p : -1) : (fire ? -1 : pp_i);
+        s.v0 = srch ? s.v0 : (fire ? 0 : (valid_i ? 1 : 0));
+        s.masked = dom ? pp_i + 3 : s.masked;
+        s.pp1 = dom ? -1 : s.pp1;
+        s.pv1 = dom ? 3.402823466e+38f : s.pv1;
+        s.v1 = dom ? 0 : s.v1;
+    }
+    {   /* long window: threshold 9.0, window 6 */
+        const bool active = s.masked < p;
+        const bool srch = s.pp1 == -1;
+        const bool lower = c1 < s.pv1;
+        const bool rise = !lower && (c1 - s.pv1 > h);
+        const bool higher = c1 > s.pv1;
+        const float pv_i = higher ? c1 : s.pv1;
+        const int pp_i = higher ? p : s.pp1;
+        const bool inpeak = active && !srch;
+        const bool valid_i = s.v1 || ((pv_i - c1 > h) && (pv_i > 9.0f));
+        const bool fire = inpeak && valid_i && ((p - pp_i) > 3);
+        f1 = pp_i;
+        fired |= fire ? 2 : 0;
+        const bool sr = active && srch;
+        s.pv1 = sr ? ((lower || rise) ? c1 : s.pv1) : (inpeak ? (fire ? c1 : pv_i) : s.pv1);
+        s.pp1 = sr ? (rise ? p : -1) : (inpeak ? (fire ? -1 : pp_i) : s.pp1);
+        s.v1 = inpeak ? (fire ? 0 : (valid_i ? 1 : 0)) : s.v1;
+    }
+    return fired;
+}
+/* equal as far as any position > p can tell (a mask that has expired is no mask) */
+static __device__ __forceinline__ bool det2_equal(const abea_det2& a, const abea_det2& b, int p) {
+    return __float_as_int(a.pv0) == __float_as_int(b.pv0) && __float_as_int(a.pv1) == __float_as_int(b.pv1) &&
+           a.pp0 == b.pp0 && a.pp1 == b.pp1 && a.v0 == b.v0 && a.v1 == b.v1 && max(a.masked, p) == max(b.masked, p);
+}
+
+/* Segment records are interleaved like everything else: field f of segment j of the read in lane l of read-wave w is
+ * at ((seg_base[w] + j) * stride + f) * 64 + l. */
+extern "C" __global__ __launch_bounds__(256)
+void abea_ev_spec_kernel(int n_reads, const int32_t* __restrict__ order, const int32_t* __restrict__ n_samples,
+                         const int64_t* __restrict__ wave_base, const float* __restrict__ t1_all,
+                         const float* __restrict__ t2_all, const int64_t* __restrict__ seg_base,
+                         const int32_t* __restrict__ wave_nseg, uint16_t* __restrict__ spec_all,
+                         int32_t* __restrict__ segrec_all) {
+    const int w = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int slot = w * 64 + lane;
+    if (j >= wave_nseg[w] || slot >= n_reads) return;
+    const int r = order[slot];
+    const int n = n_samples[r];
+    const int lo = max(j * ABEA_EV_SEG, 1);                          /* masked_to starts at 0: position 0 is skipped */
+    const int hi = min((j + 1) * ABEA_EV_SEG, n);
+    if (lo >= hi && j > 0) return;
+    const int64_t base = wave_base[w] + lane;
+    const float* __restrict__ t1 = t1_all + base;
+    const float* __restrict__ t2 = t2_all + base;
+    const int64_t seg = seg_base[w] + j;
+    uint16_t* __restrict__ out = spec_all + seg * ABEA_EV_SEG * 64 + lane;
+    int32_t* __restrict__ rec = segrec_all + seg * 12 * 64 + lane;
+    abea_det2 s; det2_reset(s);
+    int cnt = 0;
+    const int last = max(n - 1, 0);
+    float a1[8], a2[8];
+    #pragma unroll
+    for (int q = 0; q < 8; ++q) { a1[q] = t1[(size_t)min(lo + q, last) * 64]; a2[q] = t2[(size_t)min(lo + q, last) * 64]; }
+    for (int p0 = lo; p0 < hi; p0 += 8) {
+        float b1[8], b2[8];
+        #pragma unroll
+        for (int q = 0; q < 8; ++q) { b1[q] = t1[(size_t)min(p0 + 8 + q, last) * 64]; b2[q] = t2[(size_t)min(p0 + 8 + q, last) * 64]; }
+        #pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            if (p0 + q < hi) {
+                int f0, f1;
+                const int fired = det2_step(s, p0 + q, a1[q], a2[q], f0, f1);
+                if (fired & 1) { out[(size_t)cnt * 64] = (uint16_t)(f0 - j * ABEA_EV_SEG); ++cnt; }
+                if (fired & 2) { out[(size_t)cnt * 64] = (uint16_t)(f1 - j * ABEA_EV_SEG); ++cnt; }
+            }
+        }
+        #pragma unroll
+        for (int q = 0; q < 8; ++q) { a1[q] = b1[q]; a2[q] = b2[q]; }
+    }
+    rec[0 * 64] = cnt;                                               /* peaks of the speculative run */
+    rec[1 * 64] = 0;                                                 /* peaks of the true prefix (3b) */
+    rec[2 * 64] = 0;                                                 /* speculative peaks the prefix replaces (3b) */
+    rec[4 * 64] = __float_as_int(s.pv0); rec[5 * 64] = __float_as_int(s.pv1);
+    rec[6 * 64] = s.pp0; rec[7 * 64] = s.pp1; rec[8 * 64] = s.v0; rec[9 * 64] = s.v1; rec[10 * 64] = s.masked;
+}
+
+extern "C" __global__ __launch_bounds__(256)
+void abea_ev_fix_kernel(int n_reads, const int32_t* __restrict__ order, const int32_t* __restrict__ n_samples,
+                        const int64_t* __restrict__ wave_base, const float* __restrict__ t1_all,
+                        const float* __restrict__ t2_all, const int64_t* __restrict__ seg_base,
+                        const int32_t* __restrict__ wave_nseg, int32_t* __restrict__ fix_all,
+                        int32_t* __restrict__ segrec_all, int32_t* __restrict__ need_seq) {
+    const int w = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6) + 1;           /* segment 0 starts from the true state already */
+    const int slot = w * 64 + lane;
+    if (j >= wave_nseg[w] || slot >= n_reads) return;
+    const int r = order[slot];
+    const int n = n_samples[r];
+    const int lo = j * ABEA_EV_SEG;
+    const int hi = min(lo + ABEA_EV_SEG, n);
+    if (lo >= hi) return;
+    const int64_t base = wave_base[w] + lane;
+    const float* __restrict__ t1 = t1_all + base;
+    const float* __restrict__ t2 = t2_all + base;
+    const int64_t seg = seg_base[w] + j;
+    int32_t* __restrict__ out = fix_all + seg * ABEA_EV_FIXCAP * 64 + lane;
+    int32_t* __restrict__ rec = segrec_all + seg * 12 * 64 + lane;
+    const int32_t* __restrict__ prev = rec - 12 * 64;
+    abea_det2 tr, sp;
+    tr.pv0 = __int_as_float(prev[4 * 64]); tr.pv1 = __int_as_float(prev[5 * 64]);
+    tr.pp0 = prev[6 * 64]; tr.pp1 = prev[7 * 64]; tr.v0 = prev[8 * 64]; tr.v1 = prev[9 * 64]; tr.masked = prev[10 * 64];
+    det2_reset(sp);
+    int nfix = 0, skip = 0, p = lo;
+    bool met = det2_equal(tr, sp, lo - 1);
+    const int stop = min(hi, lo + ABEA_EV_FIX);
+    while (!met && p < stop) {
+        const float c0 = t1[(size_t)p * 64], c1 = t2[(size_t)p * 64];
+        int f0, f1, g0, g1;
+        const int ft = det2_step(tr, p, c0, c1, f0, f1);
+        const int fs = det2_step(sp, p, c0, c1, g0, g1);
+        if (ft & 1) { if (nfix < ABEA_EV_FIXCAP) out[(size_t)nfix * 64] = f0; ++nfix; }
+        if (ft & 2) { if (nfix < ABEA_EV_FIXCAP) out[(size_t)nfix * 64] = f1; ++nfix; }
+        skip += (fs & 1) + ((fs >> 1) & 1);
+        met = det2_equal(tr, sp, p);
+        ++p;
+    }
+    /* a segment shorter than the window that never met still ends the read: nothing follows it, but its own peaks
+     * after the window are unknown, so it is flagged too unless the window covered it */
+    if ((!met && p < hi) || nfix > ABEA_EV_FIXCAP) need_seq[r] = 1;
+    if (!met && p >= hi) skip = rec[0 * 64];                         /* the true run covered the whole segment */
+    rec[1 * 64] = nfix;
+    rec[2 * 64] = skip;
+}
+
+extern "C" __global__ __launch_bounds__(64)
+void abea_ev_scan_kernel(int n_reads, const int32_t* __restrict__ order, const int32_t* __restrict__ n_samples,
+                         const int64_t* __restrict__ seg_base, int32_t* __restrict__ segrec_all,
+                         int32_t* __restrict__ n_events) {
+    const int lane = threadIdx.x;
+    const int slot = blockIdx.x * 64 + lane;
+    if (slot >= n_reads) return;
+    const int r = order[slot];
+    const int n = n_samples[r];
+    if (n <= 0) { n_events[r] = 0; return; }
+    const int nseg = (n + ABEA_EV_SEG - 1) / ABEA_EV_SEG;
+    int32_t* __restrict__ rec = segrec_all + seg_base[blockIdx.x] * 12 * 64 + lane;
+    int run = 0;
+    for (int j = 0; j < nseg; ++j) {
+        const int cnt = rec[0] + rec[64] - rec[128];
+        rec[3 * 64] = run;
+        run += cnt;
+        rec += 12 * 64;
+    }
+    n_events[r] = run + 1;                                           /* events.c:491-497: one more event than peaks */
+}
+
+extern "C" __global__ __launch_bounds__(256)
+void abea_ev_gather_kernel(int n_reads, const int32_t* __restrict__ order, const int32_t* __restrict__ n_samples,
+                           const int64_t* __restrict__ seg_base, const int32_t* __restrict__ wave_nseg,
+                           const uint16_t* __restrict__ spec_all, const int32_t* __restrict__ fix_all,
+                           const int32_t* __restrict__ segrec_all, const int64_t* __restrict__ peak_base,
+                           const int32_t* __restrict__ event_cap, int32_t* __restrict__ peaks_all) {
+    const int w = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int slot = w * 64 + lane;
+    if (j >= wave_nseg[w] || slot >= n_reads) return;
+    const int r = order[slot];
+    const int n = n_samples[r];
+    if (j * ABEA_EV_SEG >= n) return;
+    const int cap = event_cap[r];
+    const int64_t seg = seg_base[w] + j;
+    const int32_t* __restrict__ rec = segrec_all + seg * 12 * 64 + lane;
+    const uint16_t* __restrict__ sp = spec_all + seg * ABEA_EV_SEG * 64 + lane;
+    const int32_t* __restrict__ fx = fix_all + seg * ABEA_EV_FIXCAP * 64 + lane;
+    int32_t* __restrict__ pk = peaks_all + peak_base[w] + lane;
+    const int nspec = rec[0], nfix = min(rec[64], ABEA_EV_FIXCAP), skip = rec[128];
+    int at = rec[3 * 64];
+    for (int e = 0; e < nfix; ++e, ++at) if (at < cap) pk[(size_t)at * 64] = fx[(size_t)e * 64];
+    for (int e = skip; e < nspec; ++e, ++at) if (at < cap) pk[(size_t)at * 64] = j * ABEA_EV_SEG + (int)sp[(size_t)e * 64];
+}
+
 extern "C" __global__ __launch_bounds__(64)
 void abea_ev_detect_kernel(int n_reads, const int32_t* __restrict__ order, const int32_t* __restrict__ n_samples,
                            const int64_t* __restrict__ wave_base, const float* __restrict__ t1_all,
                            const float* __restrict__ t2_all, const int64_t* __restrict__ peak_base,
                            const int32_t* __restrict__ event_cap, int32_t* __restrict__ peaks_all,
-                           int32_t* __restrict__ n_events) {
+                           int32_t* __restrict__ n_events, const int32_t* __restrict__ need_seq) {
     const int lane = threadIdx.x;
     const int slot = blockIdx.x * 64 + lane;
     if (slot >= n_reads) return;
     const int r = order[slot];
+    if (need_seq && !need_seq[r]) return;                           /* pass 3e: only reads whose segments never met */
     const int n = n_samples[r];
     const int cap = event_cap[r];
     if (n <= 0) { n_events[r] = 0; return; }

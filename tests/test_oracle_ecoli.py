@@ -104,6 +104,28 @@ def test_gpu_event_detection_bit_exact(ctx, orc, r9):
 
 
 @pytest.mark.gpu
+def test_gpu_event_detection_adversarial_signals(ctx, orc):
+    """The segment-parallel detector must equal the sequential one on signals where speculative segments do not
+    re-synchronise quickly (plateaus, pure noise, slow waves: these take the per-read sequential fallback) and on
+    degenerate lengths."""
+    r = np.random.default_rng(5)
+    sigs = [np.full(5000, 500, np.int16), np.full(7, 500, np.int16), np.full(1, 500, np.int16),
+            np.full(513, 480, np.int16), np.arange(400, 1424, dtype=np.int16),
+            r.integers(300, 700, 100000).astype(np.int16),
+            np.repeat(r.integers(300, 700, 400), 250).astype(np.int16),
+            (np.repeat(r.integers(300, 700, 30000), 3) + r.integers(-2, 3, 90000)).astype(np.int16),
+            (500 + 100 * np.sin(np.arange(200000) / 50.0)).astype(np.int16),
+            (500 + 60 * np.sin(np.arange(70000) / 700.0) + r.normal(0, 0.6, 70000)).astype(np.int16)]
+    scal = np.tile(np.array([10.0, 1467.61, 8192.0], dtype=np.float32), (len(sigs), 1))
+    evs, ne, _ = ctx.detect_events_device(sigs, scal, cap_div=1)
+    for i, sig in enumerate(sigs):
+        o_ev, _ = orc.getevents(sig, scal[i, 0], scal[i, 1], scal[i, 2])
+        assert ne[i] == len(o_ev), (i, ne[i], len(o_ev))
+        for f in ("start", "length", "mean", "stdv"):
+            assert (evs[i][f] == o_ev[f]).all(), (i, f)
+
+
+@pytest.mark.gpu
 def test_gpu_raw_signal_to_recalibrated_scalings(ctx, orc, r9):
     """Whole device chain on real reads: raw signal -> events -> scalings -> ABEA -> scaling_single; the printed
     recalib_scalings.exp / adaptive.exp values of the reference come out of the GPU."""
