@@ -149,7 +149,7 @@ static __device__ __forceinline__ void abea_cell(float x, float gpm, float ck, d
  *
  * Phase-1 state layout:
  *   lane l owns band offsets o0 = 2l and o1 = 2l+1.  Offsets 0..99 (lanes 0..49) are the band;
- *   offsets 100..127 (lanes 50..63) never hold scores (pinned to -inf) but DO hold k-mer parameters:
+ *   offsets 100..127 (lanes 50..63) never hold scores (offset 100 is pinned to -inf, the rest is never read) but DO hold k-mer parameters:
  *   they are the FIFO through which upcoming k-mers slide towards offset 99, so a "right" move is
  *   one DPP wave shift per register with the new k-mer entering at lane 63 through the DPP `old`
  *   operand.  Events enter at offset 0 (lane 0) the same way on "down" moves.
@@ -158,8 +158,9 @@ static __device__ __forceinline__ void abea_cell(float x, float gpm, float ck, d
  *   issued one refill period before its data is needed.
  *   Neighbours (DESIGN.md "frames"): right move: left = P[o], up = P[o+1], diag = previous band's up;
  *   down move: left = P[o-1], up = P[o], diag = previous band's left.
- * Trace layout (per read): per 32 bands one uint4 per lane = 128 bits, band (b & 31) at bits
- *   [4*(b&31), 4*(b&31)+4) = {from(o0) | from(o1) << 2}.  Lane 50 instead carries the band moves:
+ * Trace layout (per read): per 32 bands one uint4 per lane = 128 bits, 8 bands per dword with the OLDEST band in the
+ *   top nibble: band (b & 31) at bits [4*((b&31)^7), +4) = {f(o0) | f(o1) << 2}, f = 2*[left == max] + [up >= diag]
+ *   (0 FROM_D, 1 FROM_U, 2 and 3 FROM_L; the border variant only writes 0..2).  Lane 50 instead carries the band moves:
  *   .x = move bits of this group (bit 31-(b&31), 1 = right), .y = move bits of the group below. */
 
 static __device__ __forceinline__ int wave_excl_scan(int v, int lane, int& total) {
@@ -250,7 +251,9 @@ void abea_align_kernel(const abea_read_desc* __restrict__ descs,
     float nkg, nkc; double nki;                         /* incoming k-mer (uniform) */
     { const abea_kpar_t t = k_ring[k_next & 127]; nkg = t.gpm; nkc = t.ck; nki = t.istd; }
 
-    uint32_t acc = (lane == 25) ? (1u << 28) : 0u;     /* bands 0,1: only band 1 offset 50 = FROM_U */
+    /* trace accumulator: 4 bits per band shifted in from the right, COMPLEMENTED (see abea_fill.inc); bands 0,1:
+     * only band 1 offset 50 = FROM_U */
+    uint32_t acc = (lane == 25) ? 0xFEu : 0xFFu;
     uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
     uint32_t mvacc = 0, mvprev = 0;                     /* band-move bits of this group / the group below */
     int b = 2;
@@ -336,10 +339,10 @@ void abea_align_kernel(const abea_read_desc* __restrict__ descs,
         U0 = nU0; U1 = nU1; L0 = nL0; L1 = nL1;
         Pf0 = m0; Pf1 = m1; P0 = (double)m0; P1 = (double)m1;
 
-        /* ---- trace: newest band in the top nibble, 8 bands per dword, 4 dwords per store ---- */
-        acc = __builtin_amdgcn_alignbit(f0 | (f1 << 2), acc, 4);       /* (acc >> 4) | (t << 28) */
+        /* ---- trace: oldest band in the top nibble, 8 bands per dword, 4 dwords per store ---- */
+        acc = (acc << 4) | (~(f0 | (f1 << 2)) & 15u);
         if ((b & 7) == 7) {
-            a0 = a1; a1 = a2; a2 = a3; a3 = acc;
+            a0 = a1; a1 = a2; a2 = a3; a3 = ~acc;
             if ((b & 31) == 31) {
                 const bool ml = lane == ABEA_MOVE_LANE;
                 trace[(size_t)(b >> 5) * 64 + lane] = make_uint4(ml ? mvacc : a0, ml ? mvprev : a1, a2, a3);
@@ -472,9 +475,9 @@ void abea_align_kernel(const abea_read_desc* __restrict__ descs,
                     thi = ((uint64_t)(uint32_t)readlane_i(cw.w, lp) << 32) | (uint32_t)readlane_i(cw.z, lp);
                 }
                 const int bi = b & 31;
-                const int bp = 4 * bi + 2 * (off & 1);
+                const int bp = 4 * (bi ^ 7) + 2 * (off & 1);
                 const uint64_t t64 = (bp & 64) ? thi : tlo;
-                const uint32_t from = (uint32_t)(t64 >> (bp & 63)) & 3u;
+                const uint32_t from = min((uint32_t)(t64 >> (bp & 63)) & 3u, 2u);   /* 3 = FROM_L and FROM_U tie */
                 const uint32_t two = (uint32_t)(mv64 >> (31 - bi)) & 3u;   /* bit0 = move(b), bit1 = move(b-1) */
                 cwd |= from << ((n & 15) << 1);
                 ++n;
@@ -793,16 +796,29 @@ void abea_ev_sums_kernel(int n_reads, const int32_t* __restrict__ order, const i
     int i = 0;
     const int head = min(n, (int)(((16u - ((uintptr_t)sig & 15u)) & 15u) >> 1));
     for (; i < head; ++i) sample(i, sig[i]);
-    if (i + 8 <= n) {
-        uint4 nxt = *reinterpret_cast<const uint4*>(sig + i);
-        while (i + 8 <= n) {
-            const uint4 cur = nxt;
-            if (i + 16 <= n) nxt = *reinterpret_cast<const uint4*>(sig + i + 8);
-            sample(i + 0, (int)(short)(cur.x & 0xffffu)); sample(i + 1, (int)(short)(cur.x >> 16));
-            sample(i + 2, (int)(short)(cur.y & 0xffffu)); sample(i + 3, (int)(short)(cur.y >> 16));
-            sample(i + 4, (int)(short)(cur.z & 0xffffu)); sample(i + 5, (int)(short)(cur.z >> 16));
-            sample(i + 6, (int)(short)(cur.w & 0xffffu)); sample(i + 7, (int)(short)(cur.w >> 16));
-            i += 8;
+    /* every lane streams its own read, so a 16-byte load is 64 different cache lines and takes ~1-2 us: keep 32
+     * samples (four loads) in flight ahead of the 32 being summed */
+    auto load4 = [&](int at, uint4* q) {
+        #pragma unroll
+        for (int u = 0; u < 4; ++u) q[u] = *reinterpret_cast<const uint4*>(sig + at + 8 * u);   /* callers keep at + 32 <= n */
+    };
+    if (i + 32 <= n) {
+        uint4 nxt[4];
+        load4(i, nxt);
+        while (i + 32 <= n) {
+            uint4 cur[4];
+            #pragma unroll
+            for (int u = 0; u < 4; ++u) cur[u] = nxt[u];
+            if (i + 64 <= n) load4(i + 32, nxt);
+            #pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int b = i + 8 * u;
+                sample(b + 0, (int)(short)(cur[u].x & 0xffffu)); sample(b + 1, (int)(short)(cur[u].x >> 16));
+                sample(b + 2, (int)(short)(cur[u].y & 0xffffu)); sample(b + 3, (int)(short)(cur[u].y >> 16));
+                sample(b + 4, (int)(short)(cur[u].z & 0xffffu)); sample(b + 5, (int)(short)(cur[u].z >> 16));
+                sample(b + 6, (int)(short)(cur[u].w & 0xffffu)); sample(b + 7, (int)(short)(cur[u].w >> 16));
+            }
+            i += 32;
         }
     }
     for (; i < n; ++i) sample(i, sig[i]);

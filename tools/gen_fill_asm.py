@@ -102,16 +102,28 @@ def cell_ops(j, D, U, L):
         f"v_cvt_f32_f64 {v(sd)}, {vp(td)}",
         f"v_cvt_f32_f64 {v(su)}, {vp(tu)}",
         f"v_cvt_f32_f64 {v(sl)}, {vp(lpd)}",
-        f"v_max3_f32 {v(F[j])}, {v(sd)}, {v(su)}, {v(sl)}",          # F[j] temporarily holds the max
-        f"v_cmp_ge_f32 {cm1}, {v(su)}, {v(sd)}",
-        f"v_cmp_eq_f32 {cm2}, {v(sl)}, {v(F[j])}",
-        # >= 2 wait states before the masks are read: the mf write and a nop-equivalent come first
-        (f"v_cndmask_b32 {v(mf)}, {v(NINF)}, {v(F[j])}, %[cv{j}]" if BORDER else       # out-of-matrix cells -> -inf
-         f"v_cndmask_b32 {v(mf)}, {v(F[j])}, {v(NINF)}, %[hi_mask]"),                   # lanes >= 50 pinned to -inf
-        "s_nop 0",
-        f"v_cndmask_b32 {v(F[j])}, 0, 1, {cm1}",
-        f"v_cndmask_b32 {v(F[j])}, {v(F[j])}, 2, {cm2}",
     ]
+    if BORDER:
+        ops += [
+            f"v_max3_f32 {v(F[j])}, {v(sd)}, {v(su)}, {v(sl)}",          # F[j] temporarily holds the max
+            f"v_cmp_ge_f32 {cm1}, {v(su)}, {v(sd)}",
+            f"v_cmp_eq_f32 {cm2}, {v(sl)}, {v(F[j])}",
+            # >= 2 wait states before the masks are read: the mf write and a nop-equivalent come first
+            f"v_cndmask_b32 {v(mf)}, {v(NINF)}, {v(F[j])}, %[cv{j}]",     # out-of-matrix cells -> -inf
+            "s_nop 0",
+            f"v_cndmask_b32 {v(F[j])}, 0, 1, {cm1}",
+            f"v_cndmask_b32 {v(F[j])}, {v(F[j])}, 2, {cm2}",
+        ]
+    else:
+        # Interior: the two tie-break facts are SIGN BITS of float differences (x - x = +0, (-inf) - (-inf) = +NaN on
+        # gfx950, so "not less" covers equality and the all--inf cell exactly like align.c:386-392):
+        #   sign(su - sd) = [su < sd]   -> FROM_U loses to FROM_D      sign(sl - max) = [sl < max] -> FROM_L loses
+        # v_alignbit shifts them straight into the trace accumulator (tail of body()); no masks, no selects.
+        ops += [
+            f"v_max3_f32 {v(mf)}, {v(sd)}, {v(su)}, {v(sl)}",
+            f"v_sub_f32 {v(F[j])}, {v(su)}, {v(sd)}",
+            f"v_sub_f32 {v(sd)}, {v(sl)}, {v(mf)}",
+        ]
     return ops
 
 
@@ -221,11 +233,14 @@ def body(p, ml, m):
         emit(f"v_cmp_gt_u32 %[cv0], %[t3], {v(F[0])}")
         emit(f"v_cmp_gt_u32 %[cv1], %[t3], {v(F[1])}")
     ops0 = cell_ops(0, D[0], U[0], L[0]); ops1 = cell_ops(1, D[1], U[1], L[1])
-    # split off the two trailing from-code selects of each cell: they go after the next band's decision
-    # reads have been issued (hides the v_readlane / v_cmp -> SALU latency)
-    tail0, tail1 = ops0[-2:], ops1[-2:]
-    for ins in interleave(ops0[:-3], ops1[:-3]):         # drops the s_nop as well
-        emit(ins)
+    if BORDER:
+        # split off the two trailing from-code selects of each cell (and the s_nop before them)
+        tail0, tail1 = ops0[-2:], ops1[-2:]
+        for ins in interleave(ops0[:-3], ops1[:-3]):
+            emit(ins)
+    else:
+        for ins in interleave(ops0, ops1):
+            emit(ins)
     if BORDER:
         emit("s_nop 0")
         emit(tail0[0]); emit(tail1[0]); emit(tail0[1]); emit(tail1[1])
@@ -282,15 +297,25 @@ def body(p, ml, m):
         emit(f"v_readlane_b32 %[t0], {v(MF0)}, 0")
         emit("s_nop 1")
         emit(f"v_cmp_lt_f32 vcc, %[t0], {v(MF1)}")
+        # trace nibble f0 | f1 << 2, stored inverted: the accumulator is complemented when its dword completes
+        emit(f"v_lshl_or_b32 {v(F[0])}, {v(F[1])}, 2, {v(F[0])}")
+        emit(f"v_xor_b32 {v(F[0])}, 15, {v(F[0])}")
+        emit("s_add_u32 %[b], %[b], 1")
+        emit(f"v_lshl_or_b32 {v(ACC)}, {v(ACC)}, 4, {v(F[0])}")
     else:
-        emit(f"v_readlane_b32 %[t0], {v(MF0)}, 0")          # mf0 was written 2 instructions ago
-        emit(tail0[0]); emit(tail1[0])
+        # lanes >= 50 are the k-mer FIFO; the only one of their scores a band cell ever reads is lane 50's slot 0
+        # (lane 49's right-move shift), so only slot 0 is pinned to -inf
+        emit(f"v_cndmask_b32 {v(MF0)}, {v(MF0)}, {v(NINF)}, %[hi_mask]")
+        # trace bits, oldest first: cell 1 [sl<max], cell 1 [su<sd], cell 0 [sl<max], cell 0 [su<sd]; each v_alignbit
+        # is acc = acc << 1 | sign(difference).  Complemented per dword they read f = 2*[sl==max] + [su>=sd]:
+        # 0 FROM_D, 1 FROM_U, 2 or 3 FROM_L (align.c:386-392 priority).
+        emit(f"v_alignbit_b32 {v(ACC)}, {v(ACC)}, {v(TD[1])}, 31")
+        emit(f"v_alignbit_b32 {v(ACC)}, {v(ACC)}, {v(F[1])}, 31")
+        emit(f"v_readlane_b32 %[t0], {v(MF0)}, 0")          # mf0 was written 3 instructions ago
+        emit(f"v_alignbit_b32 {v(ACC)}, {v(ACC)}, {v(TD[0])}, 31")
+        emit(f"v_alignbit_b32 {v(ACC)}, {v(ACC)}, {v(F[0])}, 31")
         emit(f"v_cmp_lt_f32 vcc, %[t0], {v(MF1)}")          # t0 written 3 instructions ago
-        emit(tail0[1]); emit(tail1[1])
-    # trace nibble: newest band in the top nibble
-    emit(f"v_lshl_or_b32 {v(F[0])}, {v(F[1])}, 2, {v(F[0])}")
-    emit("s_add_u32 %[b], %[b], 1")
-    emit(f"v_alignbit_b32 {v(ACC)}, {v(F[0])}, {v(ACC)}, 4")
+        emit("s_add_u32 %[b], %[b], 1")
     emit("s_and_b32 %[t1], %[b], 7")
     emit(f"s_cbranch_scc0 rot_{tag}_%=")                 # band b-1 completed a dword: every 8th band, out of line
     emit(f"rotret_{tag}_%=:")
@@ -303,7 +328,7 @@ def body(p, ml, m):
     emit(f"v_mov_b32 {v(Q)}, %[mvacc]")
     emit(f"v_mov_b32 {v(Q+1)}, %[mvprev]")
     emit(f"v_mov_b32 {v(Q+2)}, {v(A2)}")
-    emit(f"v_mov_b32 {v(Q+3)}, {v(ACC)}")
+    emit(f"v_not_b32 {v(Q+3)}, {v(ACC)}")
     emit(f"v_cndmask_b32 {v(Q)}, {v(A0)}, {v(Q)}, %[m50]")
     emit(f"v_cndmask_b32 {v(Q+1)}, {v(A1)}, {v(Q+1)}, %[m50]")
     emit("s_nop 1")
@@ -314,7 +339,7 @@ def body(p, ml, m):
     emit(f"nostore_{tag}_%=:")
     emit(f"v_mov_b32 {v(A0)}, {v(A1)}")
     emit(f"v_mov_b32 {v(A1)}, {v(A2)}")
-    emit(f"v_mov_b32 {v(A2)}, {v(ACC)}")
+    emit(f"v_not_b32 {v(A2)}, {v(ACC)}")                   # the accumulator collects complemented bits
     emit(f"s_branch rotret_{tag}_%=")
     # ---- out-of-line: ring refills
     if m == 'R':
@@ -482,11 +507,14 @@ def gen_walk():
     e(f"s_cmp_eq_u32 {U}, {LP}")
     e("s_cbranch_scc0 reload_lp_%=")
     e("step_cont_%=:")
-    e(f"s_and_b32 {T}, {T}, 1"); e(f"s_lshl_b32 {T}, {T}, 1"); e(f"s_lshl2_add_u32 {T}, {BI}, {T}")   # bit position
+    e(f"s_and_b32 {T}, {T}, 1"); e(f"s_lshl_b32 {T}, {T}, 1")
+    e(f"s_xor_b32 {X}, {BI}, 7")                                          # newest band in the LOW nibble of its dword
+    e(f"s_lshl2_add_u32 {T}, {X}, {T}")                                   # bit position
     e(f"s_bitcmp1_b32 {T}, 6")
     e(f"s_cselect_b64 {T64}, {THI}, {TLO}")
     e(f"s_lshr_b64 {T64}, {T64}, {T}")
-    e(f"s_and_b32 {U}, {T64LO}, 3")                                        # from code: 0 D, 1 U, 2 L
+    e(f"s_and_b32 {U}, {T64LO}, 3")
+    e(f"s_min_u32 {U}, {U}, 2")                                            # from code: 0 D, 1 U, 2 L (3 = L and U tie)
     e(f"s_sub_u32 {T}, 31, {BI}")
     e(f"s_lshr_b64 {T64}, {MV}, {T}")
     e(f"s_and_b32 {T}, {T64LO}, 3")                                        # bit0 = move(b), bit1 = move(b-1)
