@@ -246,10 +246,14 @@ class AbeaContext:
         dev = torch.device("cuda", torch.cuda.current_device())
         n = len(signals)
         ns = np.array([len(s) for s in signals], dtype=np.int32)
-        sig_ptr = np.concatenate([[0], np.cumsum(ns.astype(np.int64))[:-1]]).astype(np.int64)
+        pad = (ns.astype(np.int64) + 7) // 8 * 8           # reads start on 16-byte boundaries: the sums passes load 8 samples at a time
+        sig_ptr = np.concatenate([[0], np.cumsum(pad)[:-1]]).astype(np.int64)
         cap = (ns // cap_div + 16).astype(np.int32)
         ev_ptr = np.concatenate([[0], np.cumsum(cap.astype(np.int64))[:-1]]).astype(np.int64)
-        d_sig = torch.from_numpy(np.concatenate(signals).astype(np.int16)).to(dev)
+        flat_sig = np.zeros(int(pad.sum()), dtype=np.int16)
+        for i, sg in enumerate(signals):
+            flat_sig[sig_ptr[i]:sig_ptr[i] + ns[i]] = sg
+        d_sig = torch.from_numpy(flat_sig).to(dev)
         d_ev = torch.zeros(int(cap.sum()) * EVENT_DT.itemsize, dtype=torch.uint8, device=dev)
         d_ne = torch.zeros(n, dtype=torch.int32, device=dev)
         sc = np.ascontiguousarray(scaling, dtype=np.float32).reshape(n, 3)

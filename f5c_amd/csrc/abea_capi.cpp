@@ -37,7 +37,13 @@ __global__ void abea_scaling_kernel(const abea_read_desc*, const char*, const ab
                                     const abea_pair_t*, const int32_t*, abea_index_pair_t*, abea_scalings_t*, double*,
                                     int32_t*, int32_t*, int);
 __global__ void abea_ev_sums_kernel(int, const int32_t*, const int16_t*, const int64_t*, const int32_t*, const float*,
-                                    const int64_t*, double*, double*);
+                                    const int64_t*, double*, double*, const int32_t*);
+__global__ void abea_ev_psum_kernel(int, const int32_t*, const int16_t*, const int64_t*, const int32_t*, const float*,
+                                    const int64_t*, const int32_t*, double*, uint32_t*);
+__global__ void abea_ev_pscan_kernel(int, const int32_t*, const int32_t*, const int64_t*, double*, const uint32_t*, int32_t*);
+__global__ void abea_ev_pwrite_kernel(int, const int32_t*, const int16_t*, const int64_t*, const int32_t*, const float*,
+                                      const int64_t*, const int64_t*, const int32_t*, const double*, const int32_t*,
+                                      double*, double*);
 __global__ void abea_ev_tstat_kernel(int, const int32_t*, const int32_t*, const int64_t*, const int32_t*, const double*,
                                      const double*, float*, float*);
 __global__ void abea_ev_detect_kernel(int, const int32_t*, const int32_t*, const int64_t*, const float*, const float*,
@@ -424,12 +430,12 @@ extern "C" int abea_detect_events_device(abea_ctx* c, const abea_signal_batch* B
     while (w0 < n_waves_all) {
         /* ---- carve waves whose interleaved scratch fits the arena: per sample S,Q fp64 + two float t-statistics
          *      (24 B), per event slot a peak position + a mean (8 B) ---- */
-        const size_t idx_bytes = N * (4 + 8 + 4 + 12 + 8 + 4 + 8 + 4 + 4) + (size_t)n_waves_all * 56 + 8192;
+        const size_t idx_bytes = N * (4 + 8 + 4 + 12 + 8 + 4 + 8 + 4 + 4 + 4) + (size_t)n_waves_all * 56 + 8192;
         if (idx_bytes + (1u << 20) > c->arena_bytes) return fail(ABEA_ENOMEM, "arena too small for %d index records", n);
         const size_t budget = c->arena_bytes - idx_bytes - 4096;
         std::vector<int64_t> wave_base, peak_base, kmer_base, seg_base; std::vector<int32_t> wave_len, wave_cap, wave_k, wave_nseg;
         size_t entries = 0, pentries = 0, kentries = 0, segs = 0;
-        const size_t EV_SEG = 512, EV_FIXCAP = 48, SEG_BYTES = 64 * (EV_SEG * 2 + EV_FIXCAP * 4 + 12 * 4);   /* abea_kernels.hip */
+        const size_t EV_SEG = 512, EV_FIXCAP = 48, SEG_BYTES = 64 * (EV_SEG * 2 + EV_FIXCAP * 4 + 12 * 4 + 2 * 8 + 4 * 4);   /* abea_kernels.hip */
         int w1 = w0;
         while (w1 < n_waves_all) {
             const int32_t len = B->n_samples[order[(size_t)w1 * 64]] + 1;      /* longest read of the wave, +1 for S[n] */
@@ -465,6 +471,7 @@ extern "C" int abea_detect_events_device(abea_ctx* c, const abea_signal_batch* B
         const size_t o_kb = put(kmer_base.data(), (size_t)nw * 8), o_wk = put(wave_k.data(), (size_t)nw * 4);
         const size_t o_sb = put(seg_base.data(), (size_t)nw * 8), o_wn = put(wave_nseg.data(), (size_t)nw * 4);
         const size_t o_need = put(nullptr, N * 4);                    /* per-read "segments never met" flags, zeroed */
+        const size_t o_need_s = put(nullptr, N * 4);                  /* per-read "prefix sums may round" flags */
         double* dS = (double*)(d + align_up(o, 256));
         double* dQ = dS + entries;
         float* dT1 = (float*)(dQ + entries);
@@ -477,18 +484,37 @@ extern "C" int abea_detect_events_device(abea_ctx* c, const abea_signal_batch* B
         uint16_t* dSpec = (uint16_t*)dSegs;
         int32_t* dFix = (int32_t*)(dSpec + segs * EV_SEG * 64);
         int32_t* dRec = dFix + segs * EV_FIXCAP * 64;
+        double* dSegSum = (double*)(dRec + segs * 12 * 64);
+        uint32_t* dSegExp = (uint32_t*)(dSegSum + segs * 2 * 64);
         HIP_TRY(hipMemcpyAsync(d, h, o, hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipEventRecord(c->ev[0], c->stream));
+        /* pass 1: prefix sums by segments where that is provably exact, sequentially otherwise */
+        const int max_nseg = *std::max_element(wave_nseg.begin(), wave_nseg.end());
+        const dim3 sgrid((unsigned)((max_nseg + 3) / 4), (unsigned)nw);
+        const bool seq_only = getenv("ABEA_EV_SEQUENTIAL") != nullptr;
+        if (!seq_only) {
+            hipLaunchKernelGGL(abea_ev_psum_kernel, sgrid, dim3(256), 0, c->stream,
+                               nr, (const int32_t*)(d + o_order), B->signal, (const int64_t*)(d + o_sig),
+                               (const int32_t*)(d + o_ns), (const float*)(d + o_sc), (const int64_t*)(d + o_sb),
+                               (const int32_t*)(d + o_wn), dSegSum, dSegExp);
+            hipLaunchKernelGGL(abea_ev_pscan_kernel, dim3((unsigned)nw), dim3(64), 0, c->stream,
+                               nr, (const int32_t*)(d + o_order), (const int32_t*)(d + o_ns), (const int64_t*)(d + o_sb),
+                               dSegSum, dSegExp, (int32_t*)(d + o_need_s));
+            hipLaunchKernelGGL(abea_ev_pwrite_kernel, sgrid, dim3(256), 0, c->stream,
+                               nr, (const int32_t*)(d + o_order), B->signal, (const int64_t*)(d + o_sig),
+                               (const int32_t*)(d + o_ns), (const float*)(d + o_sc), (const int64_t*)(d + o_wb),
+                               (const int64_t*)(d + o_sb), (const int32_t*)(d + o_wn), dSegSum,
+                               (const int32_t*)(d + o_need_s), dS, dQ);
+        }
         hipLaunchKernelGGL(abea_ev_sums_kernel, dim3((unsigned)nw), dim3(64), 0, c->stream,
                            nr, (const int32_t*)(d + o_order), B->signal, (const int64_t*)(d + o_sig),
-                           (const int32_t*)(d + o_ns), (const float*)(d + o_sc), (const int64_t*)(d + o_wb), dS, dQ);
+                           (const int32_t*)(d + o_ns), (const float*)(d + o_sc), (const int64_t*)(d + o_wb), dS, dQ,
+                           seq_only ? (const int32_t*)nullptr : (const int32_t*)(d + o_need_s));
         const unsigned tiles = (unsigned)std::min<int64_t>(1024, (wave_len[0] + 3) / 4);
         hipLaunchKernelGGL(abea_ev_tstat_kernel, dim3(tiles, (unsigned)nw), dim3(256), 0, c->stream,
                            nr, (const int32_t*)(d + o_order), (const int32_t*)(d + o_ns), (const int64_t*)(d + o_wb),
                            (const int32_t*)(d + o_wl), dS, dQ, dT1, dT2);
         /* pass 3: the automaton over (read, segment) pairs, then the sequential one for reads whose segments never met */
-        const int max_nseg = *std::max_element(wave_nseg.begin(), wave_nseg.end());
-        const dim3 sgrid((unsigned)((max_nseg + 3) / 4), (unsigned)nw);
         hipLaunchKernelGGL(abea_ev_spec_kernel, sgrid, dim3(256), 0, c->stream,
                            nr, (const int32_t*)(d + o_order), (const int32_t*)(d + o_ns), (const int64_t*)(d + o_wb),
                            dT1, dT2, (const int64_t*)(d + o_sb), (const int32_t*)(d + o_wn), dSpec, dRec);
@@ -507,7 +533,7 @@ extern "C" int abea_detect_events_device(abea_ctx* c, const abea_signal_batch* B
         hipLaunchKernelGGL(abea_ev_detect_kernel, dim3((unsigned)nw), dim3(64), 0, c->stream,
                            nr, (const int32_t*)(d + o_order), (const int32_t*)(d + o_ns), (const int64_t*)(d + o_wb),
                            dT1, dT2, (const int64_t*)(d + o_pb), (const int32_t*)(d + o_ec), dPk, B->n_events,
-                           getenv("ABEA_EV_SEQUENTIAL") ? (const int32_t*)nullptr : (const int32_t*)(d + o_need));
+                           seq_only ? (const int32_t*)nullptr : (const int32_t*)(d + o_need));
         const unsigned etiles = (unsigned)std::min<int64_t>(256, (wave_cap[0] + 3) / 4);
         hipLaunchKernelGGL(abea_ev_create_kernel, dim3(etiles, (unsigned)nw), dim3(256), 0, c->stream,
                            nr, (const int32_t*)(d + o_order), (const int32_t*)(d + o_ns), (const int64_t*)(d + o_wb),

@@ -770,15 +770,144 @@ static __device__ __forceinline__ float abea_tstat(double s_lo, double s_mid, do
     return fabsf(delta_mean) / sqrtf(combined_var / wf);
 }
 
-extern "C" __global__ __launch_bounds__(64)
-void abea_ev_sums_kernel(int n_reads, const int32_t* __restrict__ order, const int16_t* __restrict__ signal,
+/* ---- pass 1, parallel form.  S and Q are sequential fp64 sums (events.c:303-313), but when every sample of a read is a
+ * multiple of one quantum 2^q and n * max|x| < 2^(q+53), every partial sum in ANY order is exactly representable, no
+ * addition rounds, and a segmented scan gives the sequential result bit for bit.  1a sums segments of ABEA_EV_SEG
+ * samples and records the exponent range of x and of the float squares; 1b scans the segment totals per read and
+ * decides; 1c rewrites the prefix sums from the segment offsets; reads that fail the test (a sample near 0 pA among
+ * ~100 pA ones, or a very long read) take the sequential kernel (1d). ---- */
+#define ABEA_EV_SEG_SUM 512
+static __device__ __forceinline__ float abea_pa(int raw, float offset, float raw_unit) {
+    return __fmul_rn(__fadd_rn((float)raw, offset), raw_unit);       /* f5c.c:694-696 */
+}
+
+extern "C" __global__ __launch_bounds__(256)
+void abea_ev_psum_kernel(int n_reads, const int32_t* __restrict__ order, const int16_t* __restrict__ signal,
                          const int64_t* __restrict__ sig_ptr, const int32_t* __restrict__ n_samples,
-                         const float* __restrict__ scaling, const int64_t* __restrict__ wave_base,
-                         double* __restrict__ S_all, double* __restrict__ Q_all) {
+                         const float* __restrict__ scaling, const int64_t* __restrict__ seg_base,
+                         const int32_t* __restrict__ wave_nseg, double* __restrict__ segsum_all,
+                         uint32_t* __restrict__ segexp_all) {
+    const int w = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int slot = w * 64 + lane;
+    if (j >= wave_nseg[w] || slot >= n_reads) return;
+    const int r = order[slot];
+    const int n = n_samples[r];
+    const int lo = j * ABEA_EV_SEG_SUM, hi = min(lo + ABEA_EV_SEG_SUM, n);
+    if (lo >= hi) return;
+    const int16_t* __restrict__ sig = signal + sig_ptr[r];
+    const float offset = scaling[3 * r], raw_unit = scaling[3 * r + 1] / scaling[3 * r + 2];   /* f5c.c:693 */
+    double S = 0.0, Q = 0.0;
+    uint32_t xmin = 0x7f800000u, xmax = 0u, ymin = 0x7f800000u, ymax = 0u;
+    auto take = [&](int raw) {
+        const float x = abea_pa(raw, offset, raw_unit);
+        const float y = __fmul_rn(x, x);
+        S += (double)x; Q += (double)y;
+        const uint32_t ax = __float_as_uint(x) & 0x7fffffffu, ay = __float_as_uint(y);
+        xmax = max(xmax, ax); ymax = max(ymax, ay);
+        xmin = min(xmin, ax ? ax : 0x7f800000u); ymin = min(ymin, ay ? ay : 0x7f800000u);
+    };
+    int p = lo;
+    if ((((uintptr_t)(sig + lo)) & 15u) == 0u)                       /* sig_ptr a multiple of 8 samples: 16-byte loads */
+        for (; p + 8 <= hi; p += 8) {
+            const uint4 q = *reinterpret_cast<const uint4*>(sig + p);
+            take((int)(short)(q.x & 0xffffu)); take((int)(short)(q.x >> 16)); take((int)(short)(q.y & 0xffffu)); take((int)(short)(q.y >> 16));
+            take((int)(short)(q.z & 0xffffu)); take((int)(short)(q.z >> 16)); take((int)(short)(q.w & 0xffffu)); take((int)(short)(q.w >> 16));
+        }
+    for (; p < hi; ++p) take(sig[p]);
+    const int64_t seg = seg_base[w] + j;
+    double* __restrict__ ss = segsum_all + seg * 2 * 64 + lane;
+    uint32_t* __restrict__ se = segexp_all + seg * 4 * 64 + lane;
+    ss[0] = S; ss[64] = Q;
+    se[0] = xmin; se[64] = xmax; se[128] = ymin; se[192] = ymax;
+}
+
+extern "C" __global__ __launch_bounds__(64)
+void abea_ev_pscan_kernel(int n_reads, const int32_t* __restrict__ order, const int32_t* __restrict__ n_samples,
+                          const int64_t* __restrict__ seg_base, double* __restrict__ segsum_all,
+                          const uint32_t* __restrict__ segexp_all, int32_t* __restrict__ need_seq) {
     const int lane = threadIdx.x;
     const int slot = blockIdx.x * 64 + lane;
     if (slot >= n_reads) return;
     const int r = order[slot];
+    const int n = n_samples[r];
+    if (n <= 0) return;
+    const int nseg = (n + ABEA_EV_SEG_SUM - 1) / ABEA_EV_SEG_SUM;
+    double* __restrict__ ss = segsum_all + seg_base[blockIdx.x] * 2 * 64 + lane;
+    const uint32_t* __restrict__ se = segexp_all + seg_base[blockIdx.x] * 4 * 64 + lane;
+    double S = 0.0, Q = 0.0;
+    uint32_t xmin = 0x7f800000u, xmax = 0u, ymin = 0x7f800000u, ymax = 0u;
+    for (int j = 0; j < nseg; ++j) {
+        const double s = ss[0], q = ss[64];
+        ss[0] = S; ss[64] = Q;                                       /* exclusive offsets for 1c */
+        S += s; Q += q;
+        xmin = min(xmin, se[0]); xmax = max(xmax, se[64]); ymin = min(ymin, se[128]); ymax = max(ymax, se[192]);
+        ss += 2 * 64; se += 4 * 64;
+    }
+    /* biased exponents; quantum of a float with exponent field e is 2^(max(e,1) - 150); the sum of n values below
+     * 2^(emax + 1 - 127) stays below 2^(emax - 126 + nbits) */
+    const int nbits = 32 - __clz(n);
+    auto exact = [&](uint32_t lo, uint32_t hi) {
+        if (hi == 0u) return true;                                   /* all zeros */
+        if (hi >= 0x7f800000u) return false;                         /* inf / NaN: leave it to the sequential form */
+        const int emin = max((int)(lo >> 23), 1), emax = max((int)(hi >> 23), 1);
+        return (emax - emin) + nbits + 24 <= 53;
+    };
+    need_seq[r] = (exact(xmin, xmax) && exact(ymin, ymax)) ? 0 : 1;
+}
+
+extern "C" __global__ __launch_bounds__(256)
+void abea_ev_pwrite_kernel(int n_reads, const int32_t* __restrict__ order, const int16_t* __restrict__ signal,
+                           const int64_t* __restrict__ sig_ptr, const int32_t* __restrict__ n_samples,
+                           const float* __restrict__ scaling, const int64_t* __restrict__ wave_base,
+                           const int64_t* __restrict__ seg_base, const int32_t* __restrict__ wave_nseg,
+                           const double* __restrict__ segsum_all, const int32_t* __restrict__ need_seq,
+                           double* __restrict__ S_all, double* __restrict__ Q_all) {
+    const int w = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int slot = w * 64 + lane;
+    if (j >= wave_nseg[w] || slot >= n_reads) return;
+    const int r = order[slot];
+    if (need_seq[r]) return;
+    const int n = n_samples[r];
+    const int lo = j * ABEA_EV_SEG_SUM, hi = min(lo + ABEA_EV_SEG_SUM, n);
+    double* __restrict__ Sw = S_all + wave_base[w] + lane;
+    double* __restrict__ Qw = Q_all + wave_base[w] + lane;
+    if (j == 0) { Sw[0] = 0.0; Qw[0] = 0.0; }
+    if (lo >= hi) return;
+    const int16_t* __restrict__ sig = signal + sig_ptr[r];
+    const float offset = scaling[3 * r], raw_unit = scaling[3 * r + 1] / scaling[3 * r + 2];
+    const double* __restrict__ ss = segsum_all + (seg_base[w] + j) * 2 * 64 + lane;
+    double S = ss[0], Q = ss[64];
+    auto take = [&](int p, int raw) {
+        const float x = abea_pa(raw, offset, raw_unit);
+        S += (double)x; Q += (double)__fmul_rn(x, x);
+        Sw[(size_t)(p + 1) * 64] = S; Qw[(size_t)(p + 1) * 64] = Q;
+    };
+    int p = lo;
+    if ((((uintptr_t)(sig + lo)) & 15u) == 0u)
+        for (; p + 8 <= hi; p += 8) {
+            const uint4 q = *reinterpret_cast<const uint4*>(sig + p);
+            take(p + 0, (int)(short)(q.x & 0xffffu)); take(p + 1, (int)(short)(q.x >> 16));
+            take(p + 2, (int)(short)(q.y & 0xffffu)); take(p + 3, (int)(short)(q.y >> 16));
+            take(p + 4, (int)(short)(q.z & 0xffffu)); take(p + 5, (int)(short)(q.z >> 16));
+            take(p + 6, (int)(short)(q.w & 0xffffu)); take(p + 7, (int)(short)(q.w >> 16));
+        }
+    for (; p < hi; ++p) take(p, sig[p]);
+}
+
+extern "C" __global__ __launch_bounds__(64)
+void abea_ev_sums_kernel(int n_reads, const int32_t* __restrict__ order, const int16_t* __restrict__ signal,
+                         const int64_t* __restrict__ sig_ptr, const int32_t* __restrict__ n_samples,
+                         const float* __restrict__ scaling, const int64_t* __restrict__ wave_base,
+                         double* __restrict__ S_all, double* __restrict__ Q_all, const int32_t* __restrict__ need_seq) {
+    const int lane = threadIdx.x;
+    const int slot = blockIdx.x * 64 + lane;
+    if (slot >= n_reads) return;
+    const int r = order[slot];
+    if (need_seq && !need_seq[r]) return;                           /* pass 1d: only reads whose sums may round */
     const int n = n_samples[r];
     const int16_t* __restrict__ sig = signal + sig_ptr[r];
     const float offset = scaling[3 * r], range = scaling[3 * r + 1], digitisation = scaling[3 * r + 2];

@@ -129,7 +129,7 @@ int abea_align_batch_device(abea_ctx* ctx, const abea_device_batch* batch);
  * events[event_ptr[i] ...] up to event_cap[i] entries; n_events[i] is the true count (> cap means truncated). */
 typedef struct {
     int32_t n_reads;
-    const int64_t* sig_ptr;        /* HOST: offset of read i in `signal` (samples) */
+    const int64_t* sig_ptr;        /* HOST: offset of read i in `signal` (samples); multiples of 8 are fastest (16-byte loads) */
     const int32_t* n_samples;      /* HOST: db->sig[i]->nsample */
     const float*   scaling;        /* HOST [n_reads][3]: offset, range, digitisation (signal_t, src/f5c.h:276-286) */
     const int64_t* event_ptr;      /* HOST */
