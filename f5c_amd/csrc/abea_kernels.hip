@@ -646,7 +646,8 @@ void abea_scaling_kernel(const abea_read_desc* __restrict__ descs, const char* _
         const unsigned long long vm = __ballot(valid);
         const unsigned long long lower = vm & ((1ull << lane) - 1ull);
         const int src = lower ? 63 - __clzll(lower) : 0;
-        const int prev_rank = lower ? __shfl(rank, src, 64) : carry_rank;
+        const int below = __shfl(rank, src, 64);          /* every lane takes part: the source lane may have lower == 0 */
+        const int prev_rank = lower ? below : carry_rank;
         const bool isM = valid && (rank != prev_rank);
         double t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
         if (isM) {
@@ -688,7 +689,8 @@ void abea_scaling_kernel(const abea_read_desc* __restrict__ descs, const char* _
             const unsigned long long vm = __ballot(valid);
             const unsigned long long lower = vm & ((1ull << lane) - 1ull);
             const int src = lower ? 63 - __clzll(lower) : 0;
-            const int prev_rank = lower ? __shfl(rank, src, 64) : carry_rank;
+            const int below = __shfl(rank, src, 64);          /* every lane takes part: the source lane may have lower == 0 */
+        const int prev_rank = lower ? below : carry_rank;
             double t = 0;
             if (valid && rank != prev_rank) {
                 const abea_model_t mo = model[rank];

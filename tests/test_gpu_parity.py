@@ -281,6 +281,51 @@ def test_scaling_single_on_device(ctx, orc, r9):
     assert n_cal >= 35 and (flags == 2).sum() >= 2
 
 
+def _homopolymer_read(model, k, n_bases=1400, seed=5):
+    """A read with TTTTTTT runs placed so that two consecutive k-mers of equal rank fall on k-mer indices 64m and 64m+1
+    (the recalibration's 'M'/'E' decision then crosses a 64-k-mer chunk boundary of the device kernel)."""
+    from f5c_amd.types import EVENT_DT
+    rng = np.random.default_rng(seed)
+    seq = rng.choice(list(b"ACGT"), n_bases).astype(np.uint8)
+    for m in range(1, n_bases // 64 - 1):
+        seq[64 * m:64 * m + 7] = ord("T")
+        seq[64 * m - 1] = ord("G"); seq[64 * m + 7] = ord("A")
+    code = np.zeros(256, np.int64); code[list(b"ACGT")] = [0, 1, 2, 3]
+    K = n_bases - k + 1
+    ranks = np.zeros(K, np.int64)
+    for j in range(k):
+        ranks = ranks * 4 + code[seq[j:j + K]]
+    means = np.repeat(model["level_mean"][ranks], 2) + rng.normal(0, 0.4, 2 * K).astype(np.float32) * np.repeat(model["level_stdv"][ranks], 2)
+    ev = np.zeros(2 * K, dtype=EVENT_DT)
+    ev["mean"] = means.astype(np.float32); ev["length"] = 8.0; ev["stdv"] = 1.0
+    ev["start"] = np.arange(2 * K, dtype=np.uint64) * 8
+    return seq.tobytes(), ev
+
+
+def test_scaling_single_equal_rank_kmers_across_a_chunk_boundary(ctx, orc, r9):
+    """Regression (found by tools/fuzz_parity.py): k-mers 64m and 64m+1 with the same rank; the second one is an 'E'
+    state and must not enter the recalibration sums."""
+    from f5c_amd import synth
+    k, model = r9
+    seq, ev = _homopolymer_read(model, k)
+    batch = synth.batch_from_reads([seq] * 3, [ev] * 3, [(1.0, 0.0)] * 3)
+    d = ctx.upload(batch)
+    ctx.align_db_device(d, scaling=True)
+    pairs, n_pairs, _ = ctx.download(d)
+    b2e, sc, epb, flags, nalign = ctx.download_scaling(d)
+    assert (n_pairs > 0).all()
+    for i in range(3):
+        ps = int(batch["pair_ptr"][i])
+        r = orc.scaling_single(pairs[ps:ps + n_pairs[i]], seq, ev, model, k, 1.0, 0.0)
+        m = r["base_to_event_map"]
+        both = [(m["start"][64 * j] != -1) and (m["start"][64 * j + 1] != -1) for j in range(1, 20)]
+        assert sum(both) >= 10                                   # the construction does exercise the boundary
+        assert not (r["flag"] & 1)
+        assert sc["shift"][i] == r["scalings"]["shift"] and sc["scale"][i] == r["scalings"]["scale"]
+        assert sc["var"][i] == r["scalings"]["var"]
+        assert flags[i] == r["flag"] and nalign[i] == r["n_alignment"] and epb[i] == r["events_per_base"]
+
+
 def test_baseline_config2_full_size_bit_exact(orc, r9):
     """BASELINE.json configs[1] at full size (10 000 reads, ~160 M events, seed 20250002): every pair list, n_pairs and
     the integer diagnostics equal the oracle's (16 host threads, ~20 s), plus two size-independent properties:

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised parity sweep (GPU): many small batches with extreme shapes — reads of k..k+5 bases, 1-event reads,
 events-per-base ratios from 0.2 to just under / over the 15.0 guard, repeated and sub-sampled event tables, odd
-scalings, constant signals — through both entry points against the CPU oracle.  Not part of the pytest suite (time);
+scalings, constant signals — through both entry points (and the device scaling_single, row N1) against the CPU oracle.  Not part of the pytest suite (time);
 run:  python tools/fuzz_parity.py [seconds] [seed]"""
 import os, sys, time
 import numpy as np
@@ -46,8 +46,9 @@ while time.time() - t0 < budget:
         scs.append(sc)
     b = synth.batch_from_reads(seqs, evs, scs)
     ora = orc.align_batch(b, model, k, n_threads=16)
-    d = ctx.upload(b); ctx.align_db_device(d)
+    d = ctx.upload(b); ctx.align_db_device(d, scaling=True)           # row N1 rides along
     pairs, n_pairs, diag = ctx.download(d)
+    b2e, rsc, epb, flags, nalign = ctx.download_scaling(d)
     plist, n_pairs_h, diag_h = ctx.align_flat_host(b)
     o_pairs, o_n, o_diag = ora
     for i in range(n):
@@ -60,5 +61,15 @@ while time.time() - t0 < budget:
             for f in ("n_aligned", "best_event", "max_gap"):
                 assert diag[f][i] == o_diag[f][i] == diag_h[f][i], (tag, f)
             assert abs(diag["sum_emission"][i] - o_diag["sum_emission"][i]) <= 1e-4, tag
+        if len(seqs[i]) >= k and len(evs[i]) > 0:                      # scaling_single (f5c.c:736-807) on the device
+            r = orc.scaling_single(o_pairs[s:s + o_n[i]], seqs[i], evs[i], model, k, scs[i][0], scs[i][1])
+            assert flags[i] == r["flag"] and nalign[i] == r["n_alignment"] and epb[i] == r["events_per_base"], (tag, "N1 scalars")
+            if o_n[i] > 0:
+                K, ko = len(seqs[i]) - k + 1, int(d["kmer_ptr"][i])
+                assert (b2e[ko:ko + K, 0] == r["base_to_event_map"]["start"]).all() and \
+                       (b2e[ko:ko + K, 1] == r["base_to_event_map"]["stop"]).all(), (tag, "N1 map")
+                if not (r["flag"] & 1) or r["scalings"]["var"] != 0:
+                    assert rsc["shift"][i] == r["scalings"]["shift"] and rsc["scale"][i] == r["scalings"]["scale"] and \
+                           rsc["var"][i] == r["scalings"]["var"], (tag, "N1 scalings", rsc[i], r["scalings"], r["flag"], scs[i])
     n_batches += 1; n_reads += n; n_pass += int((o_n > 0).sum())
 print(f"fuzz OK: {n_batches} batches, {n_reads} reads ({n_pass} pass QC) bit-exact through both entry points in {time.time()-t0:.0f} s")
