@@ -43,7 +43,10 @@ while time.time() - t0 < budget:
     m = int(rng.integers(1, 90))
     sigs, scal = zip(*[signal() for _ in range(m)])
     scal = np.array(scal, dtype=np.float32)
-    evs, ne, _ = ctx.detect_events_device(list(sigs), scal, cap_div=1)
+    seqs = None
+    if nb % 2 == 1:                                                  # every other batch also asks for the scalings
+        seqs = [bytes(rng.choice(list(b"ACGT"), int(rng.integers(k, 4000))).astype(np.uint8)) for _ in range(m)]
+    evs, ne, dsc = ctx.detect_events_device(list(sigs), scal, seqs=seqs, cap_div=1)
     for i, sg in enumerate(sigs):
         o_ev, _ = orc.getevents(sg, scal[i, 0], scal[i, 1], scal[i, 2])
         tag = f"batch {nb} signal {i} n={len(sg)} scaling={scal[i]}"
@@ -51,5 +54,9 @@ while time.time() - t0 < budget:
         for f in ("start", "length", "mean", "stdv"):
             a, b = evs[i][f], o_ev[f]
             assert ((a == b) | ((a != a) & (b != b))).all(), (tag, f)
+        if seqs is not None:                                         # estimate_scalings_using_mom (align.c:58-106)
+            scale, shift = orc.estimate_scalings(seqs[i], model, k, o_ev)
+            got = (np.float32(dsc["scale"][i]), np.float32(dsc["shift"][i])); want = (np.float32(scale), np.float32(shift))
+            assert all((g == w) or (g != g and w != w) for g, w in zip(got, want)), (tag, "scalings", got, want)
     nb += 1; ns += m; ne_tot += int(ne.sum())
 print(f"fuzz OK: {nb} batches, {ns} signals, {ne_tot} events bit-exact in {time.time()-t0:.0f} s")

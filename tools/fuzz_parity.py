@@ -2,7 +2,7 @@
 """Randomised parity sweep (GPU): many small batches with extreme shapes — reads of k..k+5 bases, 1-event reads,
 events-per-base ratios from 0.2 to just under / over the 15.0 guard, repeated and sub-sampled event tables, odd
 scalings, constant signals — through both entry points (and the device scaling_single, row N1) against the CPU oracle.  Not part of the pytest suite (time);
-run:  python tools/fuzz_parity.py [seconds] [seed]"""
+run:  python tools/fuzz_parity.py [seconds] [seed] [k9]"""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -12,6 +12,9 @@ from f5c_amd.types import EVENT_DT
 from oracle import orc
 
 k, model = load_model_f32(os.path.join(ROOT, "tests/golden/r9.4_450bps.6mer.f32"))
+if len(sys.argv) > 3 and sys.argv[3] == "k9":                        # R10-style 9-mer table (synthetic, BASELINE configs[4])
+    from f5c_amd import synthetic_model
+    k, model = 9, synthetic_model(9, seed=9)
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 ctx = abea.AbeaContext(model, k, max_arena_bytes=2 << 30)
