@@ -1,0 +1,81 @@
+"""CPU evidence for the two exactness arguments the device event detection (row N2) rests on.  No GPU, no product
+code: (1) the segment-parallel form of the peak automaton, as prototyped in tools/proto/spec_detect.c, reproduces
+the sequential automaton on real and adversarial signals; (2) when the exponent-range test of abea_ev_pscan_kernel
+passes, fp64 sums of the samples are the same in every order."""
+import os, subprocess, sys
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _pa(raw, sc):
+    off, rng, dig = (np.float32(x) for x in sc)
+    return ((raw.astype(np.float32) + off) * (rng / dig)).astype(np.float32)
+
+
+def test_segment_parallel_automaton_prototype(tmp_path):
+    exe = tmp_path / "spec_detect"
+    subprocess.check_call(["gcc", "-O2", "-w", "-o", str(exe), os.path.join(ROOT, "tools/proto/spec_detect.c"), "-lm", "-lpthread"])
+    g = np.load(os.path.join(ROOT, "tests/golden/ecoli_reads.npz"), allow_pickle=True)
+    r = np.random.default_rng(5)
+    sc0 = (10.0, 1467.61, 8192.0)
+    sigs = [_pa(g[f"sig{i}"], g["scaling"][i]) for i in range(int(g["n"]))]
+    sigs += [_pa(np.full(5000, 500, np.int16), sc0), _pa(np.full(7, 500, np.int16), sc0), _pa(np.full(1, 500, np.int16), sc0),
+             _pa(r.integers(300, 700, 100000).astype(np.int16), sc0),
+             _pa(np.repeat(r.integers(300, 700, 400), 250).astype(np.int16), sc0),
+             _pa((np.repeat(r.integers(300, 700, 30000), 3) + r.integers(-2, 3, 90000)).astype(np.int16), sc0),
+             _pa((500 + 100 * np.sin(np.arange(200000) / 50.0)).astype(np.int16), sc0)]
+    path = tmp_path / "sigs.bin"
+    with open(path, "wb") as f:
+        for pa in sigs:
+            f.write(np.int64(len(pa)).tobytes()); f.write(np.ascontiguousarray(pa).tobytes())
+    for G, F in ((512, 64), (128, 64), (1024, 128)):          # the device uses 512 / 64
+        out = subprocess.check_output([str(exe), str(path), str(G), str(F)], text=True)
+        head = dict(kv.split("=") for kv in out.splitlines()[0].split())
+        assert int(head["mismatches"]) == 0, out                # exit status is non-zero on a mismatch as well
+        assert int(head["reads"]) == len(sigs)
+        assert float(head["mean_sync"]) < 8.0                   # segments meet their replay within a few samples
+        assert int(head["fallback_reads"]) <= 3                 # plateaus / slow waves: sequential fallback, by design
+
+
+def _exact_by_rule(x):
+    """The decision of abea_ev_pscan_kernel for one array of floats (all entries, not squares)."""
+    ax = np.abs(x).view(np.uint32)
+    nz = ax[ax != 0]
+    if len(nz) == 0:
+        return True
+    if nz.max() >= 0x7f800000:
+        return False
+    emin, emax = max(int(nz.min() >> 23), 1), max(int(nz.max() >> 23), 1)
+    nbits = int(len(x)).bit_length()
+    return (emax - emin) + nbits + 24 <= 53
+
+
+def test_exponent_range_rule_implies_order_independent_sums():
+    r = np.random.default_rng(11)
+    n_pass = n_fail_caught = 0
+    for trial in range(300):
+        n = int(r.integers(2, 200000))
+        kind = trial % 4
+        if kind == 0:   x = r.uniform(40, 200, n)
+        elif kind == 1: x = r.uniform(30, 300, n) * r.choice([-1.0, 1.0], n)
+        elif kind == 2: x = np.concatenate([r.uniform(60, 130, n - 1), [r.uniform(1e-6, 1e-3)]])
+        else:           x = r.uniform(1, 2, n) * 2.0 ** r.integers(-20, 20, n)
+        x = x.astype(np.float32)
+        seq = 0.0
+        for v in x[:2000]:                                      # python loop only for a prefix; numpy cumsum is sequential too
+            seq += float(v)
+        assert seq == float(np.cumsum(x[:2000].astype(np.float64))[-1])
+        total_seq = float(np.cumsum(x.astype(np.float64))[-1])
+        perm = r.permutation(n)
+        total_perm = float(np.cumsum(x[perm].astype(np.float64))[-1])
+        pair = x.astype(np.float64)
+        while len(pair) > 1:                                    # pairwise tree, a third association
+            if len(pair) & 1: pair = np.concatenate([pair, [0.0]])
+            pair = pair[0::2] + pair[1::2]
+        if _exact_by_rule(x):
+            n_pass += 1
+            assert total_seq == total_perm == float(pair[0]), (trial, n)
+        elif total_seq != total_perm or total_seq != float(pair[0]):
+            n_fail_caught += 1
+    assert n_pass >= 100 and n_fail_caught >= 5                 # the rule accepts ordinary signals and rejects ones that do round
