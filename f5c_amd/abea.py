@@ -238,10 +238,9 @@ class AbeaContext:
                        dbatch["n_pairs"].data_ptr(), dbatch["diag"].data_ptr() if want_diag else None, *sc)
         self._chk(self._lib.abea_align_batch_device(self._h, C.byref(db)), "abea_align_batch_device")
 
-    def detect_events_device(self, signals, scaling, seqs=None, cap_div=4):
-        """Row N2: raw ADC signals -> event tables (+ method-of-moments scalings when `seqs` is given) on the
-        device. signals: list of int16 arrays; scaling: float32 [n,3] (offset, range, digitisation).
-        Returns (list of EVENT_DT arrays, n_events int32[n], scalings SCAL_DT[n] or None)."""
+    def _detect(self, signals, scaling, seqs, cap_div):
+        """Shared plumbing of the N2 entry: flatten + upload the signals, run abea_detect_events_device, keep every
+        output in HBM.  Returns a dict of the device tensors and host index arrays."""
         import torch
         dev = torch.device("cuda", torch.cuda.current_device())
         n = len(signals)
@@ -272,10 +271,37 @@ class AbeaContext:
                        d_reads.data_ptr() if d_reads is not None else None, d_ev.data_ptr(), d_ne.data_ptr(),
                        d_scal.data_ptr() if d_scal is not None else None)
         self._chk(self._lib.abea_detect_events_device(self._h, C.byref(sb)), "abea_detect_events_device")
-        ne = d_ne.cpu().numpy()
-        allev = d_ev.cpu().numpy().view(EVENT_DT)
-        evs = [allev[ev_ptr[i]:ev_ptr[i] + min(ne[i], cap[i])] for i in range(n)]
-        return evs, ne, (d_scal.cpu().numpy().view(SCAL_DT) if d_scal is not None else None)
+        return dict(n=n, cap=cap, ev_ptr=ev_ptr, read_ptr=rp, read_len=rl, d_ev=d_ev, d_ne=d_ne, d_scal=d_scal,
+                    d_reads=d_reads)
+
+    def detect_events_device(self, signals, scaling, seqs=None, cap_div=4):
+        """Row N2: raw ADC signals -> event tables (+ method-of-moments scalings when `seqs` is given) on the
+        device. signals: list of int16 arrays; scaling: float32 [n,3] (offset, range, digitisation).
+        Returns (list of EVENT_DT arrays, n_events int32[n], scalings SCAL_DT[n] or None)."""
+        r = self._detect(signals, scaling, seqs, cap_div)
+        ne = r["d_ne"].cpu().numpy()
+        allev = r["d_ev"].cpu().numpy().view(EVENT_DT)
+        evs = [allev[r["ev_ptr"][i]:r["ev_ptr"][i] + min(ne[i], r["cap"][i])] for i in range(r["n"])]
+        return evs, ne, (r["d_scal"].cpu().numpy().view(SCAL_DT) if r["d_scal"] is not None else None)
+
+    def signals_to_device_batch(self, signals, scaling, seqs, cap_div=4):
+        """Rows N2 -> hot path without the event tables leaving HBM: run event detection and return a device batch
+        for align_db_device whose `events` are the detector's output buffer.  Only the per-read n_events (4 B) and
+        estimated scalings (16 B) cross to the host, because abea_device_batch takes them as host arrays."""
+        import torch
+        r = self._detect(signals, scaling, seqs, cap_div)
+        n = r["n"]
+        ne = np.minimum(r["d_ne"].cpu().numpy(), r["cap"]).astype(np.int32)
+        cap_pairs = ne.astype(np.int64) + r["read_len"].astype(np.int64)
+        dev = r["d_ev"].device
+        d = dict(n_reads=n, read_ptr=r["read_ptr"], read_len=r["read_len"], event_ptr=r["ev_ptr"], n_events=ne,
+                 pair_ptr=np.concatenate([[0], np.cumsum(cap_pairs)[:-1]]).astype(np.int64),
+                 scalings=np.ascontiguousarray(r["d_scal"].cpu().numpy().view(SCAL_DT)),
+                 reads=r["d_reads"], events=r["d_ev"])
+        d["pairs"] = torch.zeros(max(1, int(cap_pairs.sum())) * 2, dtype=torch.int32, device=dev)
+        d["n_pairs"] = torch.zeros(max(1, n), dtype=torch.int32, device=dev)
+        d["diag"] = torch.zeros(max(1, n) * DIAG_DT.itemsize, dtype=torch.uint8, device=dev)
+        return d
 
     @staticmethod
     def download_scaling(dbatch):

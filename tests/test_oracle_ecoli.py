@@ -136,12 +136,10 @@ def test_gpu_raw_signal_to_recalibrated_scalings(ctx, orc, r9):
     from f5c_amd import synth
     k, model = r9
     reads = list(_reads())
-    evs, ne, sc = ctx.detect_events_device([r["sig"] for r in reads],
-                                           np.array([[r["offset"], r["range"], r["digitisation"]] for r in reads]),
-                                           seqs=[r["seq"] for r in reads])
-    batch = synth.batch_from_reads([r["seq"] for r in reads], [e.copy() for e in evs],
-                                   [(sc["scale"][i], sc["shift"][i]) for i in range(len(reads))])
-    d = ctx.upload(batch)
+    # the event tables stay in HBM between the two calls (only n_events and the estimated scalings come to the host)
+    d = ctx.signals_to_device_batch([r["sig"] for r in reads],
+                                    np.array([[r["offset"], r["range"], r["digitisation"]] for r in reads]),
+                                    [r["seq"] for r in reads])
     ctx.align_db_device(d, scaling=True)
     _, n_pairs, diag = ctx.download(d)
     _, rsc, _, flags, _ = ctx.download_scaling(d)
