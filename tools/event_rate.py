@@ -17,6 +17,18 @@ for rep in range(2):
     evs, ne, scal = ctx.detect_events_device(sigs, sc, seqs=seqs)
     ms = ctx.stats()["event_ms"]
     print(f"device: {n} reads, {ns/1e6:.1f} Msamples, {int(ne.sum())/1e6:.2f} Mevents: kernel {ms:.2f} ms = {ns/ms/1e3:.1f} Msamples/s, {ne.sum()/ms/1e3:.1f} Mevents/s")
+# whole device chain: raw signal -> events + scalings -> ABEA -> scaling_single, event tables resident in HBM
+import torch
+for rep in range(2):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    d = ctx.signals_to_device_batch(sigs, sc, seqs)
+    t1 = time.perf_counter()
+    ctx.align_db_device(d, want_diag=False, scaling=True)
+    torch.cuda.synchronize(); t2 = time.perf_counter()
+    st = ctx.stats()
+    print(f"chain: detect call {1e3*(t1-t0):.0f} ms wall (incl. python flatten + H2D of the signal), align+scaling kernels "
+          f"{st['pre_ms']+st['fill_ms']+st['trace_ms']:.1f} ms (call {1e3*(t2-t1):.0f} ms): device time ~{ms + st['pre_ms']+st['fill_ms']+st['trace_ms']:.0f} ms "
+          f"for {n} reads = {n/(ms + st['pre_ms']+st['fill_ms']+st['trace_ms'])*1e3:.0f} reads/s, {ns/(ms + st['pre_ms']+st['fill_ms']+st['trace_ms'])/1e3:.0f} Msamples/s")
 t0 = time.perf_counter()
 m = 0
 for i in range(0, n, max(1, n // 16)):
