@@ -274,6 +274,9 @@ static void plan_desc(abea_read_desc& d, const plan_read& r, int k, const abea_s
 
 /* the align_single guard (f5c.c:813-814, E/L < 15.0f in float); reads shorter than k are UB in the reference
  * (size_t underflow, align.c:191) and rejected here */
+/* the kernels address the trace with 32-bit byte offsets (32 B per band): 2^27 bands = a read of ~40 Mbases */
+static const int64_t ABEA_MAX_BANDS = (int64_t)1 << 27;
+
 static plan_read make_plan(int32_t idx, int32_t L, int32_t E, uint32_t k) {
     plan_read r;
     r.idx = idx; r.L = L; r.E = E;
@@ -325,6 +328,8 @@ extern "C" int abea_align_batch_device(abea_ctx* c, const abea_device_batch* B) 
     for (int32_t i = 0; i < n; ++i) {
         plan_read& r = reads[(size_t)i];
         r = make_plan(i, B->read_len[i], B->n_events[i], c->k);
+        if (r.run && r.n_bands > ABEA_MAX_BANDS)
+            return fail(ABEA_EINVAL, "read %d has %lld bands; the limit is %lld", i, (long long)r.n_bands, (long long)ABEA_MAX_BANDS);
         if (r.run) order.push_back(i); else skipped.push_back(i);
     }
     std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) {
@@ -633,6 +638,9 @@ extern "C" int abea_align_batch_host(abea_ctx* c, const abea_host_batch* H) {
                           H->read_len[i] > 0 && H->n_events[i] > 0 && H->n_events[i] < (uint64_t)INT32_MAX;
         /* bad read (nsample == 0): n_pairs = 0 (f5c.c:826-828) */
         reads[(size_t)i] = make_plan(i, good ? H->read_len[i] : 0, good ? (int32_t)H->n_events[i] : 0, c->k);
+        if (reads[(size_t)i].run && reads[(size_t)i].n_bands > ABEA_MAX_BANDS)
+            return fail(ABEA_EINVAL, "read %d has %lld bands; the limit is %lld", i, (long long)reads[(size_t)i].n_bands,
+                        (long long)ABEA_MAX_BANDS);
         if (reads[(size_t)i].run) ++st.n_reads_gpu; else ++st.n_reads_skipped;
     }
     const int host_threads = (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
