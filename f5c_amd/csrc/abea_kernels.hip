@@ -1379,23 +1379,23 @@ void abea_ev_scalings_kernel(int n_reads, const int32_t* __restrict__ order, con
     const int n_ev = n_events[r];
     const int ne = min(n_ev, event_cap[r]);
     const float* __restrict__ mean = mean_all + peak_base[blockIdx.x] + lane;
-    double ev_sum = 0.0;
-    for (int i0 = 0; i0 < ne; i0 += 8) {
-        float m[8];
-        #pragma unroll
-        for (int j = 0; j < 8; ++j) m[j] = mean[(size_t)min(i0 + j, ne - 1) * 64];
-        #pragma unroll
-        for (int j = 0; j < 8; ++j) if (i0 + j < ne) ev_sum += m[j];
-    }
+    /* the event-mean sum and the two k-mer sums are independent sequential chains: one loop carries all three */
     const int K = read_len[r] - kmer_size + 1;
     const float* __restrict__ km = kmean_all + kmer_base[blockIdx.x] + lane;
-    double km_sum = 0.0, km_sq = 0.0;
-    for (int i0 = 0; i0 < K; i0 += 8) {
-        float m[8];
+    double ev_sum = 0.0, km_sum = 0.0, km_sq = 0.0;
+    const int n_it = max(ne, K);
+    for (int i0 = 0; i0 < n_it; i0 += 8) {
+        float m[8], l[8];
         #pragma unroll
-        for (int j = 0; j < 8; ++j) m[j] = km[(size_t)min(i0 + j, K - 1) * 64];
+        for (int j = 0; j < 8; ++j) {
+            m[j] = mean[(size_t)min(i0 + j, max(ne - 1, 0)) * 64];
+            l[j] = km[(size_t)min(i0 + j, max(K - 1, 0)) * 64];
+        }
         #pragma unroll
-        for (int j = 0; j < 8; ++j) if (i0 + j < K) { const double l = m[j]; km_sum += l; km_sq += l * l; }
+        for (int j = 0; j < 8; ++j) {
+            if (i0 + j < ne) ev_sum += m[j];
+            if (i0 + j < K) { const double x = l[j]; km_sum += x; km_sq += x * x; }
+        }
     }
     const double shift = ev_sum / n_ev - km_sum / K;
     double ev_sq = 0.0;
