@@ -50,3 +50,14 @@ def test_product_does_not_import_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".h")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in src and "from oracle" not in src and "abea_oracle" not in src, f
+
+
+def test_generated_asm_is_current():
+    """abea_fill.inc / abea_walk.inc are generated; the committed copies must be what tools/gen_fill_asm.py emits."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "gen_fill_asm.py"), "--check"],
+                         capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.count("up to date") == 2
+

@@ -55,6 +55,21 @@ def emit(s):
     out.append(s)
 
 
+CHECK_ONLY = "--check" in __import__("sys").argv     # compare with the committed .inc files instead of writing them
+stale = []
+
+
+def _emit_file(path, text, n_lines):
+    if CHECK_ONLY:
+        same = os.path.exists(path) and open(path).read() == text
+        print(f"{'up to date' if same else 'STALE'}: {path}")
+        if not same:
+            stale.append(path)
+    else:
+        open(path, "w").write(text)
+        print(f"wrote {path}: {n_lines} asm lines")
+
+
 def v(n):
     return f"v{n}"
 
@@ -457,8 +472,7 @@ def main():
 #define ABEA_FILL_CLOBBERS {clob}, "vcc", "scc", "memory"
 """
     path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "f5c_amd", "csrc", "abea_fill.inc")
-    open(path, "w").write(inc)
-    print(f"wrote {path}: {len(lines)} asm lines")
+    _emit_file(path, inc, len(lines))
 
 
 if __name__ == "__main__":
@@ -575,9 +589,10 @@ def gen_walk():
 #define ABEA_WALK_CLOBBERS {clob}, "vcc", "scc", "memory"
 """
     path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "f5c_amd", "csrc", "abea_walk.inc")
-    open(path, "w").write(inc)
-    print(f"wrote {path}: {len(o)} asm lines")
+    _emit_file(path, inc, len(o))
 
 
 if __name__ == "__main__":
     gen_walk()
+    if stale:
+        raise SystemExit(f"generated files differ from tools/gen_fill_asm.py output: {stale}")
