@@ -17,8 +17,13 @@
 #include <hip/hip_runtime.h>
 #include <type_traits>
 #include "abea_device.h"
+#ifdef ABEA_EXP          /* next-round register-layout experiments (tools/gen_fill_asm.py, ABEA_VBASE / ABEA_TIED) */
+#include "abea_fill_exp.inc"
+#include "abea_walk_exp.inc"
+#else
 #include "abea_fill.inc"
 #include "abea_walk.inc"
+#endif
 
 #define NINF (-__builtin_inff())
 
@@ -401,20 +406,27 @@ void abea_align_kernel(const abea_read_desc* __restrict__ descs,
             uint4* u_trace = (uint4*)uni_p(trace);
             uint32_t s_best = (uint32_t)uni((int)__float_as_uint(best));
             int s_best_e = uni(best_e), s_best_llk = uni(best_llk);
-#define ABEA_FILL_OUTS \
+#ifdef ABEA_FILL_TIED_VOUTS      /* experiment: the loop state is bound to its physical registers, no entry/exit copies */
+#define ABEA_FILL_VOUTS ABEA_FILL_TIED_VOUTS
+#define ABEA_FILL_VINS ABEA_FILL_TIED_VINS
+#else
+#define ABEA_FILL_VOUTS \
                   [Pf0] "+v"(Pf0), [Pf1] "+v"(Pf1), [x0] "+v"(x0), [x1] "+v"(x1), \
                   [g0] "+v"(g0), [c0] "+v"(c0), [g1] "+v"(g1), [c1] "+v"(c1), \
                   [nkg] "+v"(nkg), [nkc] "+v"(nkc), [nx] "+v"(nx), [e_pend] "+v"(e_pend), \
                   [kpg] "+v"(kpg), [kpc] "+v"(kpc), [a1] "+v"(a1), [a2] "+v"(a2), [a3] "+v"(a3), \
                   [acc] "+v"(acc), [toff] "+v"(toff), \
                   [i0] "+v"(i0), [i1] "+v"(i1), [nki] "+v"(nki), [kpi] "+v"(kpi), \
-                  [L0] "+v"(L0), [L1] "+v"(L1), [U0] "+v"(U0), [U1] "+v"(U1), \
+                  [L0] "+v"(L0), [L1] "+v"(L1), [U0] "+v"(U0), [U1] "+v"(U1)
+#define ABEA_FILL_VINS [lane] "v"(lane)
+#endif
+#define ABEA_FILL_OUTS ABEA_FILL_VOUTS, \
                   [ll_e] "+s"(s_ll_e), [ll_k] "+s"(s_ll_k), [e_addr] "+s"(s_e_addr), [k_addr] "+s"(s_k_addr), \
                   [mvacc] "+s"(s_mvacc), [mvprev] "+s"(s_mvprev), [b] "+s"(s_b), \
                   [t0] "=&s"(t0), [t1] "=&s"(t1), [cm0a] "=&s"(cm0a), [cm0b] "=&s"(cm0b), \
                   [cm1a] "=&s"(cm1a), [cm1b] "=&s"(cm1b)
 #define ABEA_FILL_INS \
-                  [lane] "v"(lane), [lp_step] "s"(u_step), [lp_stay] "s"(u_stay), [lp_skip] "s"(u_skip), \
+                  ABEA_FILL_VINS, [lp_step] "s"(u_step), [lp_stay] "s"(u_stay), [lp_skip] "s"(u_skip), \
                   [Km1] "s"(uni(Km1)), [Em1] "s"(uni(Em1)), [kring] "s"(kring_a), [ering] "s"(ering_a), \
                   [b_end] "s"(s_b_end), [m50] "s"(m50), [evm] "s"(u_evm), [kpar] "s"(u_kpar), [trace] "s"(u_trace)
             asm volatile(ABEA_FILL_ASM

@@ -22,28 +22,34 @@ Hazards honoured by construction (gfx940/950, no assembler help inside inline as
 """
 import os
 
-VB = 64  # first fixed VGPR (v64..v119)
-MF0, MF1, SHR, SHD = 64, 65, 66, 67
-TR = [dict(c0=68, c1=70, cs=72), dict(c0=74, c1=76, cs=78)]
-X0, X1 = 80, 81
-G0, C0, G1, C1 = 82, 83, 84, 85
-I0, I1 = 86, 88
-NK = 90            # v[90:93] = incoming k-mer {gpm, ck, istd}
-NX = 94
-EPEND = 95
-KPEND = 96         # v[96:99]
-A0, A1, A2, ACC = 100, 101, 102, 103
-NINF = 104
-LANE = 105
-LPD = [106, 108]
-TD = [110, 112]    # per-cell f64 temps
-TU = [114, 116]
-Q = 106            # store quad v[106:109] aliases the LPD temps (free at the end of a band)
-TMP = 118          # 32-bit address temp
-TOFF = 119         # trace store offset (lane*16 + group*1024)
-F = [111, 113]     # from codes: high halves of the TD pairs (free once sd is rounded)
-O0, O1 = 120, 121   # band offsets owned by the lane (border variant only)
-VEND = 122         # one past the last fixed VGPR
+# Experimental layout switches (next-round A/B, never the shipped build): ABEA_VBASE moves the fixed VGPR window,
+# ABEA_TIED=1 binds the loop state to the C++ values with physical-register constraints instead of entry/exit copies.
+# Either one writes abea_fill_exp.inc / abea_walk_exp.inc (compiled under -DABEA_EXP) and leaves the shipped files alone.
+VB = int(os.environ.get("ABEA_VBASE", "64"))  # first fixed VGPR (v64..v121 in the shipped build)
+TIED = os.environ.get("ABEA_TIED", "0") == "1"
+EXPERIMENT = VB != 64 or TIED
+MF0, MF1, SHR, SHD = VB + 0, VB + 1, VB + 2, VB + 3
+TR = [dict(c0=VB + 4, c1=VB + 6, cs=VB + 8), dict(c0=VB + 10, c1=VB + 12, cs=VB + 14)]
+X0, X1 = VB + 16, VB + 17
+G0, C0, G1, C1 = VB + 18, VB + 19, VB + 20, VB + 21
+I0, I1 = VB + 22, VB + 24
+NK = VB + 26       # v[90:93] = incoming k-mer {gpm, ck, istd}
+NX = VB + 30
+EPEND = VB + 31
+KPEND = VB + 32    # v[96:99]
+A0, A1, A2, ACC = VB + 36, VB + 37, VB + 38, VB + 39
+NINF = VB + 40
+LANE = VB + 41
+LPD = [VB + 42, VB + 44]
+TD = [VB + 46, VB + 48]    # per-cell f64 temps
+TU = [VB + 50, VB + 52]
+Q = VB + 42        # store quad v[106:109] aliases the LPD temps (free at the end of a band)
+TMP = VB + 54      # 32-bit address temp
+TOFF = VB + 55     # trace store offset (lane*16 + group*1024)
+F = [VB + 47, VB + 49]     # from codes: high halves of the TD pairs (free once sd is rounded)
+O0, O1 = VB + 56, VB + 57   # band offsets owned by the lane (border variant only)
+VEND = VB + 58     # one past the last fixed VGPR
+TIED_HOME = {"L0": TR[1]['c0'], "L1": TR[1]['c1'], "U1": TR[1]['cs'], "U0": TR[0]['c0']}   # exit homes of the row doubles
 BORDER = False     # generator mode: True adds validity masks + the online end-point scan
 # extra per-cell 32-bit temps reuse the low halves of f64 temps where noted
 
@@ -409,8 +415,16 @@ def exit_stub(p, ml):
         mv = [("L0", Tl['c0']), ("L1", Tl['c1']), ("U0", Tl['c1']), ("U1", Tl['cs'])]
     else:
         mv = [("U0", Tl['c0']), ("U1", Tl['c1']), ("L0", Tl['cs']), ("L1", Tl['c0'])]
-    for name, reg in mv:
-        emit(f"v_mov_b64 %[{name}], {vp(reg)}")
+    if TIED:
+        # the operands live in fixed pairs (TIED_HOME); sources and homes overlap, so go through four free temp pairs
+        tmp = [LPD[0], LPD[1], TD[0], TD[1]]
+        for t, (name, reg) in zip(tmp, mv):
+            emit(f"v_mov_b64 {vp(t)}, {vp(reg)}")
+        for t, (name, reg) in zip(tmp, mv):
+            emit(f"v_mov_b64 {vp(TIED_HOME[name])}, {vp(t)}")
+    else:
+        for name, reg in mv:
+            emit(f"v_mov_b64 %[{name}], {vp(reg)}")
     emit("s_branch done_%=")
 
 
@@ -443,35 +457,52 @@ def main():
         (NK, "nkg"), (NK + 1, "nkc"), (NX, "nx"), (EPEND, "e_pend"), (KPEND, "kpg"), (KPEND + 1, "kpc"),
         (A0, "a1"), (A1, "a2"), (A2, "a3"), (ACC, "acc"), (TOFF, "toff"), (LANE, "lane"),
     ]
+    wide = [(I0, "i0"), (I1, "i1"), (NK + 2, "nki"), (KPEND + 2, "kpi")]
     head = []
-    for reg, name in ent:
-        head.append(f"v_mov_b32 {v(reg)}, %[{name}]")
-    for reg, name in [(I0, "i0"), (I1, "i1"), (NK + 2, "nki"), (KPEND + 2, "kpi"),
-                      (TR[1]['c0'], "L0"), (TR[1]['c1'], "L1"), (TR[1]['cs'], "U1")]:
-        head.append(f"v_mov_b64 {vp(reg)}, %[{name}]")
+    if not TIED:
+        for reg, name in ent:
+            head.append(f"v_mov_b32 {v(reg)}, %[{name}]")
+        for reg, name in wide + [(TR[1]['c0'], "L0"), (TR[1]['c1'], "L1"), (TR[1]['cs'], "U1")]:
+            head.append(f"v_mov_b64 {vp(reg)}, %[{name}]")
     head += [f"v_mov_b32 {v(NINF)}, 0xff800000", f"v_mov_b32 {v(SHR)}, 0xff800000", f"v_mov_b32 {v(SHD)}, 0xff800000",
              f"v_lshlrev_b32 {v(O0)}, 1, {v(LANE)}", f"v_lshl_or_b32 {v(O1)}, {v(LANE)}, 1, 1",
              "s_cmp_eq_u32 %[mode], 0", "s_cbranch_scc0 border_start_%="]
     interior = variant_code(False)
     border = ["border_start_%=:"] + variant_code(True)
     tail = ["done_%=:", "s_waitcnt vmcnt(0) lgkmcnt(0)"]
-    for reg, name in ent:
-        if name in ("lane",):
-            continue
-        tail.append(f"v_mov_b32 %[{name}], {v(reg)}")
-    for reg, name in [(I0, "i0"), (I1, "i1"), (NK + 2, "nki"), (KPEND + 2, "kpi")]:
-        tail.append(f"v_mov_b64 %[{name}], {vp(reg)}")
+    if not TIED:
+        for reg, name in ent:
+            if name in ("lane",):
+                continue
+            tail.append(f"v_mov_b32 %[{name}], {v(reg)}")
+        for reg, name in wide:
+            tail.append(f"v_mov_b64 %[{name}], {vp(reg)}")
     tail.append("s_nop 1")
     lines = head + interior + border + tail
     text = "\n".join(f'    "{ln}\\n\\t"' for ln in lines)
-    clob = ", ".join(f'"v{i}"' for i in range(VB, VEND))
+    tied_regs = set()
+    extra = ""
+    if TIED:
+        vouts, vins = [], []
+        for reg, name in ent:
+            if name == "lane":
+                vins.append(f'[lane] "{{v{reg}}}"(lane)')
+            else:
+                vouts.append(f'[{name}] "+{{v{reg}}}"({name})')
+            tied_regs.add(reg)
+        for reg, name in wide + [(TIED_HOME[n], n) for n in ("L0", "L1", "U0", "U1")]:
+            vouts.append(f'[{name}] "+{{v[{reg}:{reg+1}]}}"({name})')
+            tied_regs.update((reg, reg + 1))
+        extra = ("#define ABEA_FILL_TIED_VOUTS " + ", ".join(vouts) + "\n" +
+                 "#define ABEA_FILL_TIED_VINS " + ", ".join(vins) + "\n")
+    clob = ", ".join(f'"v{i}"' for i in range(VB, VEND) if i not in tied_regs)
     inc = f"""/* GENERATED by tools/gen_fill_asm.py — do not edit. See that file for the register map and hazards.
  * One statement, two variants selected by %[mode]: 0 = interior (no masks), 1 = border (masks + end-point scan). */
 #define ABEA_FILL_ASM \\
 {text.replace(chr(10), " " + chr(92) + chr(10))}
 #define ABEA_FILL_CLOBBERS {clob}, "vcc", "scc", "memory"
-"""
-    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "f5c_amd", "csrc", "abea_fill.inc")
+{extra}"""
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "f5c_amd", "csrc", "abea_fill_exp.inc" if EXPERIMENT else "abea_fill.inc")
     _emit_file(path, inc, len(lines))
 
 
@@ -490,9 +521,9 @@ def gen_walk():
     TLO, THI, MV, T64 = "s[88:89]", "s[90:91]", "s[92:93]", "s[94:95]"
     T64LO = "s94"
     T, U, X, Y = "s96", "s97", "s98", "s99"
-    CW = [f"v{i}" for i in range(64, 68)]      # current 32-band trace group: one uint4 per lane
-    NXG = [f"v{i}" for i in range(68, 72)]     # prefetched group below
-    CV, VT, L16, L4 = "v72", "v73", "v74", "v75"
+    CW = [f"v{i}" for i in range(VB, VB + 4)]      # current 32-band trace group: one uint4 per lane
+    NXG = [f"v{i}" for i in range(VB + 4, VB + 8)] # prefetched group below
+    CV, VT, L16, L4 = f"v{VB + 8}", f"v{VB + 9}", f"v{VB + 10}", f"v{VB + 11}"
     # ---- entry
     e(f"s_mov_b32 {K}, %[k0]"); e(f"s_mov_b32 {E}, %[e0]"); e(f"s_mov_b32 {LLK}, %[llk0]")
     e(f"s_add_u32 {T}, {K}, {E}"); e(f"s_add_u32 {T}, {T}, 2")           # b = e + k + 2
@@ -502,15 +533,15 @@ def gen_walk():
     e(f"v_mov_b32 {CV}, 0")
     e(f"v_lshlrev_b32 {L16}, 4, %[lane]"); e(f"v_lshlrev_b32 {L4}, 2, %[lane]")
     e(f"s_lshl_b32 {T}, {G}, 10")
-    e(f"global_load_dwordx4 v[64:67], {L16}, %[trace]")                    # placeholder, patched below with soffset add
+    e(f"global_load_dwordx4 v[{VB}:{VB + 3}], {L16}, %[trace]")                    # placeholder, patched below with soffset add
     o.pop()
     # 64-bit base + (g << 10): trace groups are 1 KiB
     e(f"s_mov_b64 {T64}, %[trace]"); e(f"s_add_u32 s94, s94, {T}"); e("s_addc_u32 s95, s95, 0")
-    e(f"global_load_dwordx4 v[64:67], {L16}, {T64}")
+    e(f"global_load_dwordx4 v[{VB}:{VB + 3}], {L16}, {T64}")
     e("group_top_%=:")
     e(f"s_max_i32 {T}, {G}, 1"); e(f"s_sub_u32 {T}, {T}, 1"); e(f"s_lshl_b32 {T}, {T}, 10")
     e(f"s_mov_b64 {T64}, %[trace]"); e(f"s_add_u32 s94, s94, {T}"); e("s_addc_u32 s95, s95, 0")
-    e(f"global_load_dwordx4 v[68:71], {L16}, {T64}")                       # prefetch the group below
+    e(f"global_load_dwordx4 v[{VB + 4}:{VB + 7}], {L16}, {T64}")                       # prefetch the group below
     e("s_waitcnt vmcnt(1)")                                                 # the current group has landed
     e(f"v_readlane_b32 s92, {CW[0]}, 50")                                  # band moves of this group ...
     e(f"v_readlane_b32 s93, {CW[1]}, 50")                                  # ... and of the group below
@@ -582,13 +613,13 @@ def gen_walk():
     e(f"s_mov_b32 %[o_maxgap], {MAXGAP}")
     e(f"v_mov_b32 %[o_cv], {CV}")
     text = "\n".join(f'    "{ln}\\n\\t"' for ln in o)
-    clob = ", ".join([f'"s{i}"' for i in range(76, 100)] + [f'"v{i}"' for i in range(64, 76)])
+    clob = ", ".join([f'"s{i}"' for i in range(76, 100)] + [f'"v{i}"' for i in range(VB, VB + 12)])
     inc = f"""/* GENERATED by tools/gen_fill_asm.py — do not edit. Scalar-unit traceback walk. */
 #define ABEA_WALK_ASM \\
 {text.replace(chr(10), " " + chr(92) + chr(10))}
 #define ABEA_WALK_CLOBBERS {clob}, "vcc", "scc", "memory"
 """
-    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "f5c_amd", "csrc", "abea_walk.inc")
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "f5c_amd", "csrc", "abea_walk_exp.inc" if EXPERIMENT else "abea_walk.inc")
     _emit_file(path, inc, len(o))
 
 
