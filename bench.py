@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """bench.py — ABEA throughput on MI355X (BASELINE.json metric: ABEA Mevents/s, + % HBM roofline).
 
-A "step" is one pass of the hot path (align-pre + band fill + align-post kernels through
-abea_align_batch_device) over one synthetic batch already resident in HBM.  Workload at N=1 is
+A "step" is one pass of the hot path (the align-pre kernel and the fused band fill + traceback + expansion kernel,
+through abea_align_batch_device) over one synthetic batch already resident in HBM.  Workload at N=1 is
 BASELINE.json configs[1]: synthetic R9.4.1 DNA, 10k reads, mean 8 kb, ~2 events/base, W=100.
 For N>1 every rank owns an independent batch of the same law (weak scaling, no data-path
 collective); RCCL carries only the final MAX-time / statistics gather.

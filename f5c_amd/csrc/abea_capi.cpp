@@ -4,8 +4,10 @@
  * MI355X path: owns a one-shot device arena, builds per-read descriptors (per-read log
  * constants via glibc), orders reads longest-first so the hardware workgroup
  * dispatcher load-balances 1..50 kb mixes, splits a batch into arena-sized sub-batches and
- * launches the three kernels of abea_kernels.hip on the library's own stream, timed with
- * HIP events on that stream.  No CPU alignment fallback exists in this library.
+ * launches the kernels of abea_kernels.hip (align-pre, the fused fill + traceback + expansion kernel, optionally
+ * scaling_single) on the library's own stream, timed with HIP events on that stream.  The host-buffer entry cuts the
+ * batch into chunks that rotate through three slot streams so that host copies, PCIe and kernels overlap; the raw-signal
+ * entry runs event detection (row N2).  No CPU alignment fallback exists in this library.
  */
 #include <hip/hip_runtime.h>
 #include <algorithm>
@@ -228,7 +230,7 @@ struct plan_read {
     bool run;
 };
 
-/* per-read scratch bytes (kpar, evm, codes, trace, fill_out, desc) */
+/* per-read scratch bytes (kpar, evm, codes, trace, desc) */
 static size_t scratch_bytes(const plan_read& r) {
     const size_t n_groups = (size_t)(r.n_bands + ABEA_GROUP - 1) / ABEA_GROUP;
     return align_up((size_t)r.K * sizeof(abea_kpar_t), 16) + align_up((size_t)r.E * 4 + 256, 16) +

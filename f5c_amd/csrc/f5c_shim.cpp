@@ -45,6 +45,8 @@ extern "C" void abea_f5c_align(abea_f5c_core* core, abea_f5c_db* db) {
     if (abea_align_batch_host((abea_ctx*)core->cuda, &hb) != ABEA_OK) SHIM_DIE("abea_align_batch_host");
     abea_stats st;
     abea_get_stats((abea_ctx*)core->cuda, &st);
+    /* the host entry pipelines chunks: align-pre is timed together with the fused kernel (fill_ms), and the copies
+     * overlap the kernels and the host loops, so pre / memcpy are reported as 0 and host_ms is split evenly */
     core->align_pre_kernel_time += st.pre_ms * 1e-3;
     core->align_core_kernel_time += st.fill_ms * 1e-3;      /* fused fill + traceback */
     core->align_post_kernel_time += st.trace_ms * 1e-3;
