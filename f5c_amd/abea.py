@@ -15,12 +15,31 @@ LIB_PATH = os.environ.get("ABEA_LIB_PATH", os.path.join(_HERE, "libabea_hip.so")
 
 EXPORTS = ["abea_init", "abea_free", "abea_last_error", "abea_align_batch_host",
            "abea_align_batch_device", "abea_detect_events_device", "abea_get_stats", "abea_device_info",
-           "abea_selftest"]
+           "abea_selftest", "abea_rsq_format"]
 SHIM_EXPORTS = ["abea_f5c_init", "abea_f5c_align", "abea_f5c_free"]      # include/abea_f5c_shim.h
 
 
 class AbeaError(RuntimeError):
     pass
+
+
+def rsq_format(fmt, read_id, seq_len, kmer_size, base_to_event_map, events, n_samples, scale, shift, rna=False):
+    """Row N3: the text `f5c resquiggle` prints for one read (abea_rsq_format: TSV fmt=0, PAF fmt=1).  Host-only.
+    base_to_event_map: IDXPAIR-like int32 [K,2] array (a copy is passed, so the caller's array is not reversed)."""
+    lib = load_library()
+    lib.abea_rsq_format.restype = C.c_int64
+    lib.abea_rsq_format.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_char_p, C.c_int32, C.c_uint32, C.c_void_p,
+                                    C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_int]
+    m = np.ascontiguousarray(np.asarray(base_to_event_map).view(np.int32).reshape(-1, 2).copy())
+    ev = np.ascontiguousarray(events)
+    rid = read_id.encode() if isinstance(read_id, str) else read_id
+    buf = C.create_string_buffer(len(m) * (len(rid) + 64) + 2 * len(rid) + 512)     # bounds both formats
+    got = lib.abea_rsq_format(buf, len(buf), fmt, rid, seq_len, kmer_size, m.ctypes.data, ev.ctypes.data, n_samples,
+                              scale, shift, 1 if rna else 0)
+    if got < 0:
+        raise AbeaError(f"abea_rsq_format: inconsistent base_to_event_map ({got})")
+    assert got < len(buf)
+    return buf.value.decode()
 
 
 class _Cfg(C.Structure):

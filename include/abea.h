@@ -144,6 +144,18 @@ typedef struct {
 } abea_signal_batch;
 int abea_detect_events_device(abea_ctx* ctx, const abea_signal_batch* batch);
 
+/* ---- resquiggle output of one read (row N3): the per-read body of output_db_rsq() (src/resquiggle.c:319-449) ----
+ * fmt 0 = TSV (one line per k-mer: read_id, k-mer index, first sample, one-past-last sample or "."), fmt 1 = PAF
+ * (one line; the ss:Z: string encodes matched samples "n,", skipped samples "nI", k-mers without events "nD").
+ * `base_to_event_map` is db->base_to_event_map[i] (host copy; reversed IN PLACE when rna != 0, as the reference does),
+ * `events` = db->et[i].event, `n_samples` = db->sig[i]->nsample.  scale / shift are what the reference prints in the
+ * sc:f: / sh:f: tags: db->scalings->scale, i.e. the FIRST read's of the batch (resquiggle.c:443-444).
+ * snprintf-like: writes at most cap-1 bytes plus a NUL and returns the length of the full text; < 0 when the map is
+ * inconsistent (the reference asserts / exits there).  Host-only. */
+int64_t abea_rsq_format(char* out, size_t cap, int fmt, const char* read_id, int32_t read_len, uint32_t kmer_size,
+                        abea_index_pair_t* base_to_event_map, const abea_event_t* events, int64_t n_samples,
+                        float scale, float shift, int rna);
+
 /* ---- timing / accounting of the last batch (core_t timing fields, src/f5c.h:457-466) ---- */
 typedef struct {
     double pre_ms, fill_ms, trace_ms;     /* HIP-event kernel times on the library's stream, summed over sub-batches

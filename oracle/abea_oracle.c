@@ -10,8 +10,12 @@
  * no FMA on x86-64; contraction must stay off so float expressions round
  * exactly like the reference build).
  */
+#ifndef _GNU_SOURCE
+#define _GNU_SOURCE            /* open_memstream */
+#endif
 #include "abea_oracle.h"
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <pthread.h>
@@ -499,4 +503,73 @@ size_t orc_getevents(size_t nsample, const float* raw, orc_event_t* out) {
     }
     free(peaks); free(t1); free(t2); free(sums); free(sumsqs);
     return ne;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * resquiggle output of one read: the per-read body of output_db_rsq(), src/resquiggle.c:319-449, with printf
+ * redirected into a memory stream.  fmt 0 = TSV, 1 = PAF.  `map` is reversed in place when rna (resquiggle.c:346-357).
+ * scale/shift: the reference prints db->scalings->scale / ->shift (element 0 of the batch array, :443-444).
+ * Returns the text length (the text is copied to out, NUL-terminated, if it fits cap) or -1 where the reference would
+ * assert / exit. */
+long orc_rsq_format(char* out, size_t cap, int fmt, const char* read_id, int32_t read_len, uint32_t kmer_size,
+                    orc_index_pair_t* map, const orc_event_t* event, long nsample, float sc_scale, float sc_shift, int rna) {
+    char* buf = NULL; size_t blen = 0;
+    FILE* fp = open_memstream(&buf, &blen);
+    char* ss = (char*)malloc((size_t)read_len * 24 + 64); size_t sl = 0; ss[0] = 0;
+    int bad = 0;
+    int32_t n_kmers = read_len - (int32_t)kmer_size + 1;
+    int64_t signal_start_point = -1, signal_start_point2 = -1, signal_end_point = -1, signal_end_point2 = -1;
+    int64_t read_start = -1, read_end = -1;
+    int64_t ci = 0, mi = 0, d = 0; int8_t ff = 1; int matches = 0; int64_t count_samples = 0;
+    if (rna) {
+        for (int j = 0; j < n_kmers / 2; ++j) { orc_index_pair_t tmp = map[j]; map[j] = map[n_kmers - 1 - j]; map[n_kmers - 1 - j] = tmp; }
+        for (int j = 0; j < n_kmers; ++j) { int32_t tmp = map[j].start; map[j].start = map[j].stop; map[j].stop = tmp; }
+    }
+    for (int j = 0; j < n_kmers; j++) {
+        int32_t start_event_idx = map[j].start, end_event_idx = map[j].stop;
+        if (start_event_idx == -1) {                                          /* :361-368 */
+            if (end_event_idx != -1) bad = 1;
+            signal_start_point = signal_end_point = -1;
+            if (!ff) d++;
+        } else {                                                              /* :370-402 */
+            if (end_event_idx == -1) { bad = 1; break; }
+            signal_start_point = (int64_t)event[start_event_idx].start;
+            if (ff) { signal_start_point2 = signal_start_point; read_start = j; ci = signal_start_point; ff = 0; }
+            signal_end_point2 = signal_end_point = (int64_t)event[end_event_idx].start + (int)event[end_event_idx].length;
+            read_end = j;
+            if (fmt) {
+                if (d > 0) { sl += (size_t)sprintf(ss + sl, "%dD", (int)d); d = 0; }
+                if (j == 0) ci = signal_start_point;
+                ci += (mi = signal_start_point - ci);
+                if (mi) { sl += (size_t)sprintf(ss + sl, "%dI", (int)mi); count_samples += mi; }
+                ci += (mi = signal_end_point - signal_start_point);
+                if (mi) { matches++; sl += (size_t)sprintf(ss + sl, "%d,", (int)mi); count_samples += mi; }
+            }
+        }
+        if (fmt == 0) {                                                       /* :406-427 */
+            fprintf(fp, "%s\t%d\t", read_id, rna ? n_kmers - j - 1 : j);
+            if (signal_start_point < 0) fprintf(fp, ".\t"); else fprintf(fp, "%ld\t", (long)signal_start_point);
+            if (signal_end_point < 0) fprintf(fp, "."); else fprintf(fp, "%ld", (long)signal_end_point);
+            fprintf(fp, "\n");
+            if (signal_start_point >= 0 && signal_end_point >= 0 && signal_end_point <= signal_start_point) { bad = 1; break; }
+        }
+    }
+    if (fmt == 1 && !bad) {                                                   /* :431-447 */
+        if (count_samples != (signal_end_point2 - signal_start_point2) || n_kmers <= 0 || signal_start_point2 == -1 ||
+            signal_end_point2 == -1) bad = 1;
+        else {
+            fprintf(fp, "%s\t%ld\t%ld\t%ld\t+\t", read_id, (long)nsample, (long)signal_start_point2, (long)signal_end_point2);
+            fprintf(fp, "%s\t%d\t%ld\t%ld\t", read_id, n_kmers, (long)(rna ? n_kmers - read_start : read_start),
+                    (long)(rna ? n_kmers - 1 - read_end : read_end + 1));
+            fprintf(fp, "%d\t%d\t%d\t", matches, n_kmers, 255);
+            fprintf(fp, "sc:f:%f\t", sc_scale);
+            fprintf(fp, "sh:f:%f\t", sc_shift);
+            fprintf(fp, "ss:Z:%s\n", ss);
+        }
+    }
+    fclose(fp);
+    long n = bad ? -1 : (long)blen;
+    if (!bad && out && cap > blen) memcpy(out, buf, blen + 1);
+    free(buf); free(ss);
+    return n;
 }

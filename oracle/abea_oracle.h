@@ -75,6 +75,10 @@ int32_t orc_scaling_single(const orc_pair_t* pairs, int32_t n_pairs, const char*
                            const orc_event_t* ev, size_t n_events, const orc_model_t* model, uint32_t k,
                            orc_scalings_t* scalings /*in/out*/, orc_index_pair_t* base_to_event_map /*K*/,
                            double* events_per_base, int32_t* read_stat_flag);
+/* resquiggle text of one read = the per-read body of output_db_rsq() (src/resquiggle.c:319-449); see abea_oracle.c */
+long orc_rsq_format(char* out, size_t cap, int fmt, const char* read_id, int32_t read_len, uint32_t kmer_size,
+                    orc_index_pair_t* map, const orc_event_t* event, long nsample, float sc_scale, float sc_shift, int rna);
+
 #ifdef __cplusplus
 }
 #endif

@@ -111,6 +111,22 @@ def getevents(raw_adc, offset, rng, digitisation):
     return ev[:n].copy(), pa
 
 
+def rsq_format(fmt, read_id, seq_len, k, base_to_event_map, events, n_samples, scale, shift, rna=False):
+    """output_db_rsq() for one read (resquiggle.c:319-449): TSV (fmt 0) or PAF (fmt 1) text; None where the reference
+    would assert / exit."""
+    L = lib()
+    L.orc_rsq_format.restype = C.c_long
+    L.orc_rsq_format.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_char_p, C.c_int32, C.c_uint32, C.c_void_p,
+                                 C.c_void_p, C.c_long, C.c_float, C.c_float, C.c_int]
+    m = np.ascontiguousarray(np.asarray(base_to_event_map).view(np.int32).reshape(-1, 2).copy())
+    ev = np.ascontiguousarray(events)
+    buf = C.create_string_buffer(seq_len * 64 + 4096)
+    rid = read_id.encode() if isinstance(read_id, str) else read_id
+    n = L.orc_rsq_format(buf, len(buf), fmt, rid, seq_len, k, m.ctypes.data, ev.ctypes.data, n_samples, scale, shift,
+                         1 if rna else 0)
+    return None if n < 0 else buf.value.decode()
+
+
 def malloc_tuning(on: bool):
     lib().orc_malloc_tuning(1 if on else 0)
 
