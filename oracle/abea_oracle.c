@@ -573,3 +573,122 @@ long orc_rsq_format(char* out, size_t cap, int fmt, const char* read_id, int32_t
     free(buf); free(ss);
     return n;
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * Profile-HMM forward score of one event range against one (possibly methylated) sequence: row N4 of SURVEY §8f.
+ * Restates profile_hmm_score -> profile_hmm_score_r9 -> profile_hmm_fill_generic_r9<ProfileHMMForwardOutputR9>
+ * (src/hmm.c:314-535, 613-735) as it is compiled in the reference: ESL_LOG_SUM = 1 (f5c.h:88: table-driven float
+ * log-sum, logsum.h:40-71), CACHED_LOG, HMM_REVERSE_FIX undefined, USE_EXTERNAL_PARAMS undefined.
+ * UNPINNED: the reference's only goldens for this path (meth.exp) need draft.fa, which the mount does not hold. */
+#define ORC_LOGSUM_TBL 16000
+static float orc_flogsum_tbl[ORC_LOGSUM_TBL];
+static int orc_flogsum_ready = 0;
+void orc_flogsum_init(void) {                                        /* logsum.h:33-48 */
+    for (int i = 0; i < ORC_LOGSUM_TBL; i++) orc_flogsum_tbl[i] = log(1. + exp((double)-i / 1000.f));
+    orc_flogsum_ready = 1;
+}
+const float* orc_flogsum_table(void) { if (!orc_flogsum_ready) orc_flogsum_init(); return orc_flogsum_tbl; }
+static inline float orc_flogsum(float a, float b) {                  /* logsum.h:61-71 */
+    const float max = (a > b) ? a : b, min = (a < b) ? a : b;
+    return (min == -INFINITY || (max - min) >= 15.7f) ? max : max + orc_flogsum_tbl[(int)((max - min) * 1000.f)];
+}
+static inline double orc_add_logs(const double a, const double b) { return orc_flogsum(a, b); }   /* hmm.c:537-541 */
+
+uint32_t orc_cpg_kmer_rank(const char* str, uint32_t k) {            /* hmm.c:30-61: alphabet A,C,G,M,T */
+    uint32_t p = 1, r = 0;
+    for (uint32_t i = 0; i < k; ++i) {
+        char b = str[k - i - 1];
+        uint32_t v = (b == 'A') ? 0 : (b == 'C') ? 1 : (b == 'G') ? 2 : (b == 'M') ? 3 : (b == 'T') ? 4 : 0;
+        r += v * p; p *= 5;
+    }
+    return r;
+}
+
+float orc_profile_hmm_score(const char* m_seq, const char* m_rc_seq, const orc_event_t* event, orc_scalings_t scaling,
+                            const orc_model_t* cpgmodel, uint32_t kmer_size, uint32_t event_start_idx,
+                            uint32_t event_stop_idx, int8_t event_stride, uint8_t rc, double events_per_base,
+                            uint32_t hmm_flags) {
+    if (!orc_flogsum_ready) orc_flogsum_init();
+    enum { KSKIP = 0, BAD = 1, MATCH = 2, NST = 3 };                 /* hmm.c:104-111 */
+    const uint32_t k = kmer_size;
+    const uint32_t n_kmers = (uint32_t)strlen(m_seq) - k + 1;        /* hmm.c:642-656 */
+    const uint32_t n_cols = NST * (n_kmers + 2);
+    const uint32_t e_start = event_start_idx;
+    const uint32_t n_events = (event_stop_idx > e_start) ? event_stop_idx - e_start + 1 : e_start - event_stop_idx + 1;
+    const uint32_t n_rows = n_events + 1;
+    float* fm = (float*)malloc(sizeof(float) * (size_t)n_rows * n_cols);
+    #define FM(r, c) fm[(size_t)(r) * n_cols + (c)]
+    for (uint32_t r = 0; r < n_rows; r++) for (uint32_t c = 0; c < n_cols; c++) FM(r, c) = -INFINITY;   /* hmm.c:613-625; the
+        reference leaves the other cells uninitialised but never reads them before writing (row 0 and block 0 are set) */
+    /* transitions, identical for every k-mer (hmm.c:240-310) */
+    float p_stay = 1 - (1 / events_per_base);
+    float p_skip = 0.0025, p_bad = 0.001, p_bad_self = p_bad, p_skip_self = 0.3;
+    float p_mk = p_skip, p_mb = p_bad, p_mm_self = p_stay, p_mm_next = 1.0f - p_mm_self - p_mk - p_mb;
+    float p_bb = p_bad_self, p_bk, p_bm_next, p_bm_self;
+    p_bk = p_bm_next = p_bm_self = (1.0f - p_bb) / 3;
+    float p_kk = p_skip_self, p_km = 1.0f - p_kk;
+    const float lp_mk = log(p_mk), lp_mb = log(p_mb), lp_mm_self = log(p_mm_self), lp_mm_next = log(p_mm_next);
+    const float lp_bb = log(p_bb), lp_bk = log(p_bk), lp_bm_next = log(p_bm_next), lp_bm_self = log(p_bm_self);
+    const float lp_kk = log(p_kk), lp_km = log(p_km);
+    /* k-mer ranks (hmm.c:383-397) */
+    uint32_t* ranks = (uint32_t*)malloc(sizeof(uint32_t) * n_kmers);
+    const int32_t seq_len = (int32_t)strlen(m_seq);
+    for (uint32_t ki = 0; ki < n_kmers; ++ki)
+        ranks[ki] = orc_cpg_kmer_rank(rc == 0 ? m_seq + ki : m_rc_seq + seq_len - ki - k, k);
+    /* flanks (hmm.c:141-233) */
+    float* pre = (float*)calloc(n_events + 1, sizeof(float));
+    float* post = (float*)calloc(n_events, sizeof(float));
+    pre[0] = log(1 - 0.5);
+    pre[1] = log(0.5) + -3.0f + log(1 - 0.9);
+    for (uint32_t i = 2; i < n_events + 1; ++i) pre[i] = log(0.9) + -3.0f + pre[i - 1];
+    post[n_events - 1] = log(1 - 0.5);
+    if (n_events > 1) {
+        post[n_events - 2] = log(0.5) + -3.0f + log(1 - 0.9);
+        for (int i = (int)n_events - 3; i >= 0; --i) post[i] = log(0.9) + -3.0f + post[i + 1];
+    }
+    const float lp_sm = 0.0f, lp_ms = 0.0f;
+    float lp_end = -INFINITY;
+    const uint32_t num_blocks = n_kmers + 2, last_kmer_idx = n_kmers - 1, last_row = n_rows - 1;
+    for (uint32_t row = 1; row < n_rows; row++) {                    /* hmm.c:419-496 */
+        for (uint32_t block = 1; block < num_blocks - 1; block++) {
+            const uint32_t kmer_idx = block - 1, po = NST * (block - 1), co = NST * block;
+            const uint32_t event_idx = e_start + (row - 1) * event_stride;
+            const orc_model_t* m = &cpgmodel[ranks[kmer_idx]];
+            /* log_probability_match_r9 (hmm.c:73-118, CACHED_LOG) */
+            const float gp_mean = scaling.scale * m->level_mean + scaling.shift;
+            const float gp_stdv = m->level_stdv * scaling.var;
+            const float gp_log_stdv = m->level_log_stdv + scaling.log_var;
+            const float a = (event[event_idx].mean - gp_mean) / gp_stdv;
+            const float lp_em = -0.918938f - gp_log_stdv + (-0.5f * a * a);
+            float x[6], sum;
+            /* MATCH */
+            x[0] = lp_mm_self + FM(row - 1, co + MATCH);
+            x[1] = lp_mm_next + FM(row - 1, po + MATCH);
+            x[2] = lp_bm_self + FM(row - 1, co + BAD);
+            x[3] = lp_bm_next + FM(row - 1, po + BAD);
+            x[4] = lp_km + FM(row - 1, po + KSKIP);
+            x[5] = (kmer_idx == 0 && (event_idx == e_start || (hmm_flags & 1))) ? lp_sm + pre[row - 1] : -INFINITY;
+            sum = x[0]; for (int i = 1; i < 6; ++i) sum = orc_add_logs(sum, x[i]);
+            sum += lp_em; FM(row, co + MATCH) = sum;
+            /* BAD_EVENT */
+            x[0] = lp_mb + FM(row - 1, co + MATCH); x[1] = -INFINITY;
+            x[2] = lp_bb + FM(row - 1, co + BAD); x[3] = x[4] = x[5] = -INFINITY;
+            sum = x[0]; for (int i = 1; i < 6; ++i) sum = orc_add_logs(sum, x[i]);
+            sum += 0.0f; FM(row, co + BAD) = sum;
+            /* KMER_SKIP: same row, previous block */
+            x[0] = -INFINITY; x[1] = lp_mk + FM(row, po + MATCH); x[2] = -INFINITY;
+            x[3] = lp_bk + FM(row, po + BAD); x[4] = lp_kk + FM(row, po + KSKIP); x[5] = -INFINITY;
+            sum = x[0]; for (int i = 1; i < 6; ++i) sum = orc_add_logs(sum, x[i]);
+            sum += 0.0f; FM(row, co + KSKIP) = sum;
+            if (kmer_idx == last_kmer_idx && ((hmm_flags & 2) || row == last_row)) {   /* hmm.c:478-486 */
+                const float lp1 = lp_ms + FM(row, co + MATCH) + post[row - 1];
+                const float lp2 = lp_ms + FM(row, co + BAD) + post[row - 1];
+                const float lp3 = lp_ms + FM(row, co + KSKIP) + post[row - 1];
+                lp_end = orc_add_logs(lp_end, lp1); lp_end = orc_add_logs(lp_end, lp2); lp_end = orc_add_logs(lp_end, lp3);
+            }
+        }
+    }
+    #undef FM
+    free(fm); free(ranks); free(pre); free(post);
+    return lp_end;
+}

@@ -79,6 +79,16 @@ int32_t orc_scaling_single(const orc_pair_t* pairs, int32_t n_pairs, const char*
 long orc_rsq_format(char* out, size_t cap, int fmt, const char* read_id, int32_t read_len, uint32_t kmer_size,
                     orc_index_pair_t* map, const orc_event_t* event, long nsample, float sc_scale, float sc_shift, int rna);
 
+/* profile-HMM forward score (src/hmm.c:314-735), row N4; UNPINNED (see abea_oracle.c).  hmm_flags: 1 = HAF_ALLOW_PRE_CLIP,
+ * 2 = HAF_ALLOW_POST_CLIP (f5cmisc.h:40-41).  cpgmodel: 5^k entries over the alphabet A,C,G,M,T. */
+void orc_flogsum_init(void);
+const float* orc_flogsum_table(void);
+uint32_t orc_cpg_kmer_rank(const char* str, uint32_t k);
+float orc_profile_hmm_score(const char* m_seq, const char* m_rc_seq, const orc_event_t* event, orc_scalings_t scaling,
+                            const orc_model_t* cpgmodel, uint32_t kmer_size, uint32_t event_start_idx,
+                            uint32_t event_stop_idx, int8_t event_stride, uint8_t rc, double events_per_base,
+                            uint32_t hmm_flags);
+
 #ifdef __cplusplus
 }
 #endif

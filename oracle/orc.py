@@ -127,6 +127,39 @@ def rsq_format(fmt, read_id, seq_len, k, base_to_event_map, events, n_samples, s
     return None if n < 0 else buf.value.decode()
 
 
+def cpg_kmer_rank(kmer: bytes, k: int) -> int:
+    L = lib()
+    L.orc_cpg_kmer_rank.restype = C.c_uint32
+    L.orc_cpg_kmer_rank.argtypes = [C.c_char_p, C.c_uint32]
+    return int(L.orc_cpg_kmer_rank(kmer, k))
+
+
+def flogsum_table():
+    """The 16000-entry float table of p7_FLogsum (logsum.h:33-48) as the oracle (glibc log/exp) builds it."""
+    L = lib()
+    L.orc_flogsum_table.restype = C.POINTER(C.c_float)
+    return np.ctypeslib.as_array(L.orc_flogsum_table(), shape=(16000,)).copy()
+
+
+class _Scal(C.Structure):
+    _fields_ = [("scale", C.c_float), ("shift", C.c_float), ("var", C.c_float), ("log_var", C.c_float)]
+
+
+def profile_hmm_score(m_seq: bytes, m_rc_seq: bytes, events, scaling, cpgmodel, k, e_start, e_stop, stride, rc,
+                      events_per_base, hmm_flags=3):
+    """profile_hmm_score (hmm.c:692 -> :628): forward log-likelihood of events e_start..e_stop against m_seq.
+    scaling = (scale, shift, var, log_var); UNPINNED restatement (row N4)."""
+    L = lib()
+    L.orc_profile_hmm_score.restype = C.c_float
+    L.orc_profile_hmm_score.argtypes = [C.c_char_p, C.c_char_p, C.c_void_p, _Scal, C.c_void_p, C.c_uint32, C.c_uint32,
+                                        C.c_uint32, C.c_int8, C.c_uint8, C.c_double, C.c_uint32]
+    ev = np.ascontiguousarray(events)
+    mod = np.ascontiguousarray(cpgmodel)
+    return float(L.orc_profile_hmm_score(m_seq, m_rc_seq, ev.ctypes.data, _Scal(*[float(x) for x in scaling]),
+                                         mod.ctypes.data, k, e_start, e_stop, stride, 1 if rc else 0,
+                                         float(events_per_base), hmm_flags))
+
+
 def malloc_tuning(on: bool):
     lib().orc_malloc_tuning(1 if on else 0)
 
