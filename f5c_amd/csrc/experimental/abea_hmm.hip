@@ -3,7 +3,7 @@
  *
  * Row N4 of SURVEY §8f: the profile-HMM forward score of call-methylation, profile_hmm_score_r9
  * (reference src/hmm.c:314-735, called from meth.c:473 twice per CpG group: unmethylated and methylated sequence).
- * The CPU statement of the same computation is oracle/abea_oracle.c::orc_profile_hmm_score (tests/test_hmm_oracle.py).
+ * The CPU statement of the same computation lives with the test infrastructure (tests/test_hmm_oracle.py).
  *
  * Mapping.  The matrix has one row per event and three states (K skip, B bad event, M match) per k-mer block:
  *     M[r][b] <- row r-1 : M,B of block b and M,B,K of block b-1 (+ the soft start in block 0)
