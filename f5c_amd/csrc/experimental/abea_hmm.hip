@@ -140,9 +140,10 @@ void abea_hmm_forward_kernel(int n_jobs, const abea_hmm_job* __restrict__ jobs, 
         }
         if (t + 1 < n_tiles) {
             if (lane == 0) { col[0] = NINF_F; col[1] = NINF_F; col[2] = NINF_F; }   /* row 0 */
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-            __builtin_amdgcn_s_barrier();   /* NOTE: four jobs share the workgroup; jobs of one workgroup must have the same
-                                               n_tiles (the host groups them) or this barrier must become a wave-local wait */
+            /* the column is written and read back by this wavefront only (other wavefronts of the workgroup run other
+             * jobs, possibly with a different number of tiles: no workgroup barrier here) */
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_s_waitcnt(0);
         }
     }
     const int last_lane = (n_k - 1) & 63;
