@@ -13,10 +13,10 @@ from .types import EVENT_DT, MODEL_DT, PAIR_DT, SCAL_DT, DIAG_DT
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ABEA_LIB_PATH", os.path.join(_HERE, "libabea_hip.so"))   # override only for kernel A/B experiments
 
-EXPORTS = ["abea_init", "abea_free", "abea_last_error", "abea_align_batch_host",
-           "abea_align_batch_device", "abea_detect_events_device", "abea_get_stats", "abea_device_info",
-           "abea_selftest", "abea_rsq_format"]
-SHIM_EXPORTS = ["abea_f5c_init", "abea_f5c_align", "abea_f5c_free"]      # include/abea_f5c_shim.h
+EXPORTS = ["abea_init", "abea_init_multi", "abea_device_count", "abea_free", "abea_last_error", "abea_align_batch_host",
+           "abea_align_batch_device", "abea_detect_events_device", "abea_get_stats", "abea_get_device_stats",
+           "abea_device_info", "abea_selftest", "abea_rsq_format", "abea_lpt_split"]
+SHIM_EXPORTS = ["abea_f5c_init", "abea_f5c_align", "abea_f5c_align_scale", "abea_f5c_free"]      # include/abea_f5c_shim.h
 
 
 class AbeaError(RuntimeError):
@@ -52,7 +52,10 @@ class _HostBatch(C.Structure):
     _fields_ = [("n_reads", C.c_int32), ("read", C.c_void_p), ("read_len", C.c_void_p),
                 ("events", C.c_void_p), ("n_events", C.c_void_p), ("scalings", C.c_void_p),
                 ("n_samples", C.c_void_p), ("pairs", C.c_void_p), ("n_pairs", C.c_void_p),
-                ("diag", C.c_void_p)]
+                ("diag", C.c_void_p),
+                ("base_to_event_map", C.c_void_p), ("scalings_out", C.c_void_p), ("events_per_base", C.c_void_p),
+                ("read_stat_flag", C.c_void_p), ("n_event_alignment", C.c_void_p),
+                ("min_num_events_to_rescale", C.c_int32), ("reserved", C.c_int32)]
 
 
 class _DevBatch(C.Structure):
@@ -80,7 +83,10 @@ class Stats(C.Structure):
                 ("sum_events", C.c_int64), ("sum_bands", C.c_int64), ("sum_pairs", C.c_int64),
                 ("fill_launches", C.c_int64),
                 ("arena_bytes", C.c_uint64), ("bytes_ref", C.c_uint64), ("bytes_min", C.c_uint64),
-                ("bytes_moved", C.c_uint64)]
+                ("bytes_moved", C.c_uint64),
+                ("flatten_ms", C.c_double), ("unflatten_ms", C.c_double), ("wait_ms", C.c_double),
+                ("h2d_bytes", C.c_uint64), ("d2h_bytes", C.c_uint64), ("n_devices", C.c_int32),
+                ("host_threads", C.c_int32)]
 
     def asdict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -106,6 +112,14 @@ def load_library():
         L = C.CDLL(LIB_PATH)
         L.abea_init.restype = C.c_int
         L.abea_init.argtypes = [C.POINTER(C.c_void_p), C.POINTER(_Cfg)]
+        L.abea_init_multi.restype = C.c_int
+        L.abea_init_multi.argtypes = [C.POINTER(C.c_void_p), C.POINTER(_Cfg), C.c_void_p, C.c_int32]
+        L.abea_device_count.restype = C.c_int32
+        L.abea_device_count.argtypes = [C.c_void_p]
+        L.abea_get_device_stats.restype = C.c_int
+        L.abea_get_device_stats.argtypes = [C.c_void_p, C.c_int32, C.POINTER(Stats)]
+        L.abea_lpt_split.restype = C.c_int
+        L.abea_lpt_split.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
         L.abea_free.restype = None
         L.abea_free.argtypes = [C.c_void_p]
         L.abea_last_error.restype = C.c_char_p
@@ -133,17 +147,30 @@ def _p(a):
 class AbeaContext:
     """Device context: model copy + scratch arena + stream (init_cuda / free_cuda)."""
 
-    def __init__(self, model, kmer_size, device_id=0, mem_frac=0.9, max_arena_bytes=0, verbosity=0):
+    def __init__(self, model, kmer_size, device_id=0, mem_frac=0.9, max_arena_bytes=0, verbosity=0, device_ids=None):
+        """device_ids: list of devices for one multi-GPU context (abea_init_multi); overrides device_id."""
         assert model.dtype == MODEL_DT and len(model) == 4 ** kmer_size
         self._lib = load_library()
         self._model = np.ascontiguousarray(model)
         self.kmer_size = kmer_size
         cfg = _Cfg(device_id, kmer_size, self._model.ctypes.data, mem_frac, max_arena_bytes, verbosity, 0)
         h = C.c_void_p()
-        rc = self._lib.abea_init(C.byref(h), C.byref(cfg))
+        if device_ids is not None:
+            ids = np.ascontiguousarray(device_ids, dtype=np.int32)
+            rc = self._lib.abea_init_multi(C.byref(h), C.byref(cfg), _p(ids), len(ids))
+        else:
+            rc = self._lib.abea_init(C.byref(h), C.byref(cfg))
         if rc != 0:
             raise AbeaError(f"abea_init failed ({rc}): {self._lib.abea_last_error().decode()}")
         self._h = h
+
+    def device_count(self):
+        return int(self._lib.abea_device_count(self._h))
+
+    def device_stats(self, d):
+        s = Stats()
+        self._chk(self._lib.abea_get_device_stats(self._h, d, C.byref(s)), "abea_get_device_stats")
+        return s.asdict()
 
     def close(self):
         if getattr(self, "_h", None):
@@ -178,29 +205,48 @@ class AbeaContext:
         return s.asdict()
 
     # ---- db_t view: arrays of per-read pointers (align_cuda, f5c.cu:647) ----
-    def align_db_host(self, seqs, events_list, scalings, n_samples=None, want_diag=True):
+    def align_db_host(self, seqs, events_list, scalings, n_samples=None, want_diag=True, scaling=False, want_pairs=True,
+                      read_stat_flag=None):
         """seqs: list[bytes]; events_list: list[EVENT_DT array]; scalings: SCAL_DT array.
-        Returns (list of PAIR_DT arrays, n_pairs int32[n], diag DIAG_DT[n] or None)."""
+        Returns (list of PAIR_DT arrays, n_pairs int32[n], diag DIAG_DT[n] or None); with scaling=True a 4th item:
+        dict(base_to_event_map=list of int32 [K,2] arrays, scalings, events_per_base, read_stat_flag, n_event_alignment)
+        = what scaling_single leaves in db_t (f5c.c:736-807)."""
         n = len(seqs)
         seq_bufs = [C.create_string_buffer(s, len(s) + 1) for s in seqs]
         evs = [np.ascontiguousarray(e, dtype=EVENT_DT) for e in events_list]
-        outs = [np.zeros(len(e) + len(s), dtype=PAIR_DT) for e, s in zip(evs, seqs)]
+        outs = [np.zeros(len(e) + len(s), dtype=PAIR_DT) for e, s in zip(evs, seqs)] if want_pairs else None
         read_pp = (C.c_void_p * n)(*[C.addressof(b) for b in seq_bufs])
         ev_pp = (C.c_void_p * n)(*[e.ctypes.data if len(e) else None for e in evs])
-        out_pp = (C.c_void_p * n)(*[o.ctypes.data if len(o) else None for o in outs])
+        out_pp = (C.c_void_p * n)(*[o.ctypes.data if len(o) else None for o in outs]) if want_pairs else None
         read_len = np.array([len(s) for s in seqs], dtype=np.int32)
         n_events = np.array([len(e) for e in evs], dtype=np.uint64)
         sc = np.ascontiguousarray(scalings, dtype=SCAL_DT)
         n_pairs = np.zeros(n, dtype=np.int32)
         diag = np.zeros(n, dtype=DIAG_DT) if want_diag else None
         ns = np.ascontiguousarray(n_samples, dtype=np.int64) if n_samples is not None else None
+        extra = [None] * 5 + [0, 0]
+        if scaling:
+            K = np.maximum(read_len.astype(np.int64) - self.kmer_size + 1, 0)
+            maps = [np.full((int(kk), 2), -1, dtype=np.int32) for kk in K]
+            map_pp = (C.c_void_p * n)(*[m.ctypes.data if len(m) else None for m in maps])
+            sc_out = sc.copy()
+            epb = np.zeros(n, dtype=np.float64)
+            flag = (np.zeros(n, dtype=np.int32) if read_stat_flag is None
+                    else np.ascontiguousarray(read_stat_flag, dtype=np.int32).copy())
+            nal = np.zeros(n, dtype=np.int32)
+            extra = [C.cast(map_pp, C.c_void_p), _p(sc_out), _p(epb), _p(flag), _p(nal), 0, 0]
         hb = _HostBatch(n, C.cast(read_pp, C.c_void_p), _p(read_len), C.cast(ev_pp, C.c_void_p), _p(n_events),
-                        _p(sc), _p(ns) if ns is not None else None, C.cast(out_pp, C.c_void_p), _p(n_pairs),
-                        _p(diag) if want_diag else None)
+                        _p(sc), _p(ns) if ns is not None else None,
+                        C.cast(out_pp, C.c_void_p) if want_pairs else None, _p(n_pairs),
+                        _p(diag) if want_diag else None, *extra)
         self._chk(self._lib.abea_align_batch_host(self._h, C.byref(hb)), "abea_align_batch_host")
-        return [o[:k] for o, k in zip(outs, n_pairs)], n_pairs, diag
+        plist = [o[:k] for o, k in zip(outs, n_pairs)] if want_pairs else None
+        if scaling:
+            return plist, n_pairs, diag, dict(base_to_event_map=maps, scalings=sc_out, events_per_base=epb,
+                                              read_stat_flag=flag, n_event_alignment=nal)
+        return plist, n_pairs, diag
 
-    def align_flat_host(self, batch, want_diag=True):
+    def align_flat_host(self, batch, want_diag=True, **kw):
         """Convenience: run a flattened numpy batch (f5c_amd.synth layout) through the host entry point."""
         n = len(batch["read_len"])
         seqs, evs = [], []
@@ -209,7 +255,48 @@ class AbeaContext:
             seqs.append(batch["reads"][s:s + L].tobytes())
             s = int(batch["event_ptr"][i]); E = int(batch["n_events"][i])
             evs.append(batch["events"][s:s + E])
-        return self.align_db_host(seqs, evs, batch["scalings"], want_diag=want_diag)
+        return self.align_db_host(seqs, evs, batch["scalings"], want_diag=want_diag, **kw)
+
+    def host_view(self, batch, want_diag=False, scaling=False, want_pairs=True):
+        """Per-read pointer arrays over a flattened numpy batch (what a db_t holds), built once so that repeated
+        align_view() calls time only the library (bench.py).  Outputs live in the returned view: pairs
+        PAIR_DT[pair_cap] (read i at pair_ptr[i]), n_pairs, diag, and with scaling=True b2e int32[sum K, 2]
+        (read i at kmer_ptr[i]), scalings_out, events_per_base, read_stat_flag, n_event_alignment."""
+        n = len(batch["read_len"])
+        v = dict(n=n, batch=batch)
+        v["reads"] = np.ascontiguousarray(batch["reads"])
+        v["events"] = np.ascontiguousarray(batch["events"])
+        v["read_len"] = np.ascontiguousarray(batch["read_len"], dtype=np.int32)
+        v["n_events"] = np.ascontiguousarray(batch["n_events"]).astype(np.uint64)
+        v["scalings"] = np.ascontiguousarray(batch["scalings"], dtype=SCAL_DT)
+        v["read_pp"] = (v["reads"].ctypes.data + batch["read_ptr"].astype(np.int64)).astype(np.uint64)
+        v["ev_pp"] = (v["events"].ctypes.data + batch["event_ptr"].astype(np.int64) * EVENT_DT.itemsize).astype(np.uint64)
+        v["n_pairs"] = np.zeros(n, dtype=np.int32)
+        v["diag"] = np.zeros(n, dtype=DIAG_DT) if want_diag else None
+        extra = [None] * 5 + [0, 0]
+        out_pp = None
+        if want_pairs:
+            v["pairs"] = np.zeros(max(1, int(batch["pair_cap"])), dtype=PAIR_DT)
+            v["out_pp"] = (v["pairs"].ctypes.data + batch["pair_ptr"].astype(np.int64) * PAIR_DT.itemsize).astype(np.uint64)
+            out_pp = _p(v["out_pp"])
+        if scaling:
+            K = np.maximum(v["read_len"].astype(np.int64) - self.kmer_size + 1, 0)
+            v["kmer_ptr"] = np.concatenate([[0], np.cumsum(K)[:-1]]).astype(np.int64) if n else np.zeros(0, np.int64)
+            v["b2e"] = np.full((max(1, int(K.sum())), 2), -1, dtype=np.int32)
+            v["map_pp"] = (v["b2e"].ctypes.data + v["kmer_ptr"] * 8).astype(np.uint64)
+            v["scalings_out"] = v["scalings"].copy()
+            v["events_per_base"] = np.zeros(n, dtype=np.float64)
+            v["read_stat_flag"] = np.zeros(n, dtype=np.int32)
+            v["n_event_alignment"] = np.zeros(n, dtype=np.int32)
+            extra = [_p(v["map_pp"]), _p(v["scalings_out"]), _p(v["events_per_base"]), _p(v["read_stat_flag"]),
+                     _p(v["n_event_alignment"]), 0, 0]
+        v["hb"] = _HostBatch(n, _p(v["read_pp"]), _p(v["read_len"]), _p(v["ev_pp"]), _p(v["n_events"]),
+                             _p(v["scalings"]), None, out_pp, _p(v["n_pairs"]),
+                             _p(v["diag"]) if want_diag else None, *extra)
+        return v
+
+    def align_view(self, view):
+        self._chk(self._lib.abea_align_batch_host(self._h, C.byref(view["hb"])), "abea_align_batch_host")
 
     # ---- device-resident flattened batch ----
     @staticmethod

@@ -9,18 +9,8 @@
  * batch into chunks that rotate through three slot streams so that host copies, PCIe and kernels overlap; the raw-signal
  * entry runs event detection (row N2).  No CPU alignment fallback exists in this library.
  */
-#include <hip/hip_runtime.h>
-#include <algorithm>
-#include <chrono>
-#include <cmath>
-#include <cstdarg>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
 #include <numeric>
-#include <thread>
-#include <vector>
-#include "abea_device.h"
+#include "abea_internal.h"
 
 static_assert(sizeof(abea_event_t) == 24, "event_t layout (f5c.h:129)");
 static_assert(sizeof(abea_model_t) == 12, "model_t layout (f5c.h:147)");
@@ -32,12 +22,6 @@ static_assert(sizeof(abea_kpar_t) == 16, "kpar layout");
 static_assert(sizeof(abea_read_desc) % 16 == 0, "desc alignment");
 
 extern "C" {
-__global__ void abea_selftest_kernel(int* out);
-__global__ void abea_pre_kernel(const abea_read_desc*, const char*, const abea_event_t*, const abea_model_t*, int,
-                                abea_kpar_t*, float*);
-__global__ void abea_scaling_kernel(const abea_read_desc*, const char*, const abea_model_t*, int, const float*,
-                                    const abea_pair_t*, const int32_t*, abea_index_pair_t*, abea_scalings_t*, double*,
-                                    int32_t*, int32_t*, int);
 __global__ void abea_ev_sums_kernel(int, const int32_t*, const int16_t*, const int64_t*, const int32_t*, const float*,
                                     const int64_t*, double*, double*, const int32_t*);
 __global__ void abea_ev_psum_kernel(int, const int32_t*, const int16_t*, const int64_t*, const int32_t*, const float*,
@@ -66,75 +50,35 @@ __global__ void abea_ev_kmer_kernel(int, const int32_t*, const char*, const int6
 __global__ void abea_ev_scalings_kernel(int, const int32_t*, const int64_t*, const float*, const int32_t*,
                                         const int32_t*, const int32_t*, const int64_t*, const float*, int,
                                         abea_scalings_t*);
-__global__ void abea_align_kernel(const abea_read_desc*, const float*, const abea_kpar_t*, uint4*, uint32_t*,
-                                  abea_pair_t*, int32_t*, abea_read_diag*);
 }
 
 /* ------------------------------------------------------------------ errors */
 static thread_local char g_err[512] = "";
-static int fail(int code, const char* fmt, ...) {
+int abea_fail(int code, const char* fmt, ...) {
     va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof g_err, fmt, ap); va_end(ap);
     return code;
 }
-#define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) \
-    return fail(ABEA_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
-
 extern "C" const char* abea_last_error(void) { return g_err; }
 
-static double now_ms() {
-    using namespace std::chrono;
-    return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
-}
-
 /* ------------------------------------------------------------------ context */
-struct abea_ctx {
-    int device = 0;
-    int n_cu = 0;
-    char arch[64] = {0};
-    uint32_t k = 0;
-    int verbosity = 0;
-    hipStream_t stream = nullptr;
-    abea_model_t* d_model = nullptr;
-    uint8_t* arena = nullptr;      size_t arena_bytes = 0;
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-    /* pinned staging for descriptors */
-    abea_read_desc* h_desc = nullptr; size_t h_desc_cap = 0;
-    /* host-batch pipeline (abea_align_batch_host): chunks of reads rotate through these slots, each with its own
-     * stream, pinned staging block and share of the arena */
-    struct host_slot {
-        hipStream_t stream = nullptr;
-        hipEvent_t k0 = nullptr, k1 = nullptr, done = nullptr;
-        static const int N_PIECES = 4;         /* the copies of a chunk go in pieces so that they overlap the host loops */
-        hipEvent_t piece_done[N_PIECES] = {nullptr, nullptr, nullptr, nullptr};
-        int32_t piece_end[N_PIECES] = {0, 0, 0, 0};                   /* chunk-local read index ends (caller order) */
-        std::vector<int64_t> pair_off;                                /* chunk-local read index -> offset in pairs */
-        uint8_t* pinned = nullptr;  size_t pinned_cap = 0;
-        /* the chunk in flight */
-        bool busy = false;
-        int32_t first = 0, count = 0;
-        size_t o_desc = 0, o_npairs = 0, o_pairs = 0, o_diag = 0;      /* offsets into `pinned` */
-    };
-    static const int N_SLOTS = 3;
-    host_slot slot[N_SLOTS];
-    abea_stats stats;
-};
-
-static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+/* every failure after `new abea_ctx` goes through abea_free, which releases whatever was created so far */
+#define INIT_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { abea_free(c); \
+    return abea_fail(ABEA_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); } } while (0)
 
 extern "C" int abea_init(abea_ctx** out, const abea_cfg* cfg) {
-    if (!out || !cfg || !cfg->model) return fail(ABEA_EINVAL, "abea_init: null argument");
+    if (!out || !cfg || !cfg->model) return abea_fail(ABEA_EINVAL, "abea_init: null argument");
     if (cfg->kmer_size < 1 || cfg->kmer_size > ABEA_MAX_KMER_SIZE)
-        return fail(ABEA_EINVAL, "abea_init: kmer_size %u outside [1,%d]", cfg->kmer_size, ABEA_MAX_KMER_SIZE);
+        return abea_fail(ABEA_EINVAL, "abea_init: kmer_size %u outside [1,%d]", cfg->kmer_size, ABEA_MAX_KMER_SIZE);
     int n_dev = 0;
     if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0)
-        return fail(ABEA_ENODEV, "abea_init: no HIP device visible (this library has no CPU fallback)");
+        return abea_fail(ABEA_ENODEV, "abea_init: no HIP device visible (this library has no CPU fallback)");
     if (cfg->device_id < 0 || cfg->device_id >= n_dev)
-        return fail(ABEA_EINVAL, "abea_init: device_id %d but %d device(s)", cfg->device_id, n_dev);
+        return abea_fail(ABEA_EINVAL, "abea_init: device_id %d but %d device(s)", cfg->device_id, n_dev);
     HIP_TRY(hipSetDevice(cfg->device_id));
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, cfg->device_id));
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
-        return fail(ABEA_ENODEV, "abea_init: device %d is %s; the kernels are built for gfx950 only",
+        return abea_fail(ABEA_ENODEV, "abea_init: device %d is %s; the kernels are built for gfx950 only",
                     cfg->device_id, prop.gcnArchName);
     abea_ctx* c = new abea_ctx();
     memset(&c->stats, 0, sizeof c->stats);
@@ -143,54 +87,84 @@ extern "C" int abea_init(abea_ctx** out, const abea_cfg* cfg) {
     snprintf(c->arch, sizeof c->arch, "%s", prop.gcnArchName);
     c->k = cfg->kmer_size;
     c->verbosity = cfg->verbosity;
-    HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    for (auto& e : c->ev) HIP_TRY(hipEventCreate(&e));
-    for (auto& sl : c->slot) {
-        HIP_TRY(hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking));
-        HIP_TRY(hipEventCreate(&sl.k0)); HIP_TRY(hipEventCreate(&sl.k1)); HIP_TRY(hipEventCreate(&sl.done));
-        for (auto& e : sl.piece_done) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    }
+    INIT_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    for (auto& e : c->ev) INIT_TRY(hipEventCreate(&e));
     const size_t n_model = (size_t)1 << (2 * cfg->kmer_size);
-    HIP_TRY(hipMalloc(&c->d_model, n_model * sizeof(abea_model_t)));
-    HIP_TRY(hipMemcpy(c->d_model, cfg->model, n_model * sizeof(abea_model_t), hipMemcpyHostToDevice));
+    INIT_TRY(hipMalloc(&c->d_model, n_model * sizeof(abea_model_t)));
+    INIT_TRY(hipMemcpy(c->d_model, cfg->model, n_model * sizeof(abea_model_t), hipMemcpyHostToDevice));
     /* one-shot arena (f5c.cu:110-199 sizes its arrays once from free memory x MEM_FACTOR) */
     size_t free_b = 0, total_b = 0;
-    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+    INIT_TRY(hipMemGetInfo(&free_b, &total_b));
     double frac = (cfg->mem_frac > 0.f && cfg->mem_frac <= 1.f) ? cfg->mem_frac : 0.9;
     size_t want = (size_t)((double)free_b * frac);
     if (cfg->max_arena_bytes && want > cfg->max_arena_bytes) want = (size_t)cfg->max_arena_bytes;
     want = want / 4096 * 4096;
-    if (want < ((size_t)16 << 20)) { delete c; return fail(ABEA_ENOMEM, "abea_init: only %zu bytes free on device", free_b); }
-    HIP_TRY(hipMalloc(&c->arena, want));
+    if (want < ((size_t)16 << 20)) { abea_free(c); return abea_fail(ABEA_ENOMEM, "abea_init: only %zu bytes free on device", free_b); }
+    INIT_TRY(hipMalloc(&c->arena, want));
     c->arena_bytes = want;
     if (c->verbosity > 0)
-        fprintf(stderr, "[abea_init] %s, %d CUs, arena %.2f GiB of %.2f GiB free\n", c->arch, c->n_cu,
+        fprintf(stderr, "[abea_init] device %d: %s, %d CUs, arena %.2f GiB of %.2f GiB free\n", c->device, c->arch, c->n_cu,
                 want / 1073741824.0, free_b / 1073741824.0);
     *out = c;
     return ABEA_OK;
 }
 
+/* One f5c process driving several GPUs (north_star: batches shard across the GPUs of a node behind align_db): a parent
+ * context owning one child context per listed device.  The host entry splits each batch over the children
+ * (abea_host.cpp); the device-resident entries need a single-device context.  A device may be listed more than once
+ * (two contexts on one GPU: how the dispatch is tested on a 1-GPU box). */
+extern "C" int abea_init_multi(abea_ctx** out, const abea_cfg* cfg, const int32_t* device_ids, int32_t n_devices) {
+    if (!out || !cfg || !device_ids || n_devices < 1) return abea_fail(ABEA_EINVAL, "abea_init_multi: bad argument");
+    if (n_devices == 1) { abea_cfg one = *cfg; one.device_id = device_ids[0]; return abea_init(out, &one); }
+    abea_ctx* parent = new abea_ctx();
+    memset(&parent->stats, 0, sizeof parent->stats);
+    parent->device = -1;
+    parent->k = cfg->kmer_size;
+    parent->verbosity = cfg->verbosity;
+    for (int32_t i = 0; i < n_devices; ++i) {
+        abea_cfg one = *cfg;
+        one.device_id = device_ids[i];
+        /* contexts sharing a device share its free memory: split the arena fraction between them */
+        int32_t share = 0;
+        for (int32_t j = 0; j < n_devices; ++j) share += device_ids[j] == device_ids[i];
+        const float frac = (cfg->mem_frac > 0.f && cfg->mem_frac <= 1.f) ? cfg->mem_frac : 0.9f;
+        int32_t left = 0;                       /* contexts on this device still to be created, this one included */
+        for (int32_t j = i; j < n_devices; ++j) left += device_ids[j] == device_ids[i];
+        one.mem_frac = share > 1 ? frac / (float)left : frac;     /* each takes 1/left of what is still free */
+        abea_ctx* child = nullptr;
+        const int rc = abea_init(&child, &one);
+        if (rc != ABEA_OK) { abea_free(parent); return rc; }
+        parent->children.push_back(child);
+    }
+    snprintf(parent->arch, sizeof parent->arch, "%s", parent->children[0]->arch);
+    parent->n_cu = parent->children[0]->n_cu;
+    for (abea_ctx* ch : parent->children) parent->arena_bytes += ch->arena_bytes;
+    *out = parent;
+    return ABEA_OK;
+}
+
+extern "C" int32_t abea_device_count(abea_ctx* c) { return !c ? 0 : c->children.empty() ? 1 : (int32_t)c->children.size(); }
+
 extern "C" void abea_free(abea_ctx* c) {
     if (!c) return;
-    hipSetDevice(c->device);
-    if (c->stream) hipStreamSynchronize(c->stream);
-    hipFree(c->d_model); hipFree(c->arena);
-    hipHostFree(c->h_desc);
-    for (auto& sl : c->slot) {
-        if (sl.stream) { hipStreamSynchronize(sl.stream); hipStreamDestroy(sl.stream); }
-        if (sl.k0) hipEventDestroy(sl.k0);
-        if (sl.k1) hipEventDestroy(sl.k1);
-        if (sl.done) hipEventDestroy(sl.done);
-        for (auto& e : sl.piece_done) if (e) hipEventDestroy(e);
-        hipHostFree(sl.pinned);
+    for (abea_ctx* ch : c->children) abea_free(ch);
+    c->children.clear();
+    if (c->device >= 0) {
+        hipSetDevice(c->device);
+        if (c->stream) hipStreamSynchronize(c->stream);
+        abea_host_release(c);
+        hipFree(c->d_model); hipFree(c->arena);
+        hipHostFree(c->h_desc);
+        for (auto& e : c->ev) if (e) hipEventDestroy(e);
+        if (c->stream) hipStreamDestroy(c->stream);
+    } else {
+        abea_host_release(c);
     }
-    for (auto& e : c->ev) if (e) hipEventDestroy(e);
-    if (c->stream) hipStreamDestroy(c->stream);
     delete c;
 }
 
 extern "C" int abea_device_info(abea_ctx* c, char* arch, size_t arch_len, int32_t* n_cu, uint64_t* arena_bytes) {
-    if (!c) return fail(ABEA_EINVAL, "null ctx");
+    if (!c) return abea_fail(ABEA_EINVAL, "null ctx");
     if (arch && arch_len) snprintf(arch, arch_len, "%s", c->arch);
     if (n_cu) *n_cu = c->n_cu;
     if (arena_bytes) *arena_bytes = c->arena_bytes;
@@ -198,13 +172,14 @@ extern "C" int abea_device_info(abea_ctx* c, char* arch, size_t arch_len, int32_
 }
 
 extern "C" int abea_get_stats(abea_ctx* c, abea_stats* out) {
-    if (!c || !out) return fail(ABEA_EINVAL, "null argument");
+    if (!c || !out) return abea_fail(ABEA_EINVAL, "null argument");
     *out = c->stats;
     return ABEA_OK;
 }
 
 extern "C" int abea_selftest(abea_ctx* c) {
-    if (!c) return fail(ABEA_EINVAL, "null ctx");
+    if (!c) return abea_fail(ABEA_EINVAL, "null ctx");
+    if (!c->children.empty()) { for (abea_ctx* ch : c->children) { int rc = abea_selftest(ch); if (rc) return rc; } return ABEA_OK; }
     HIP_TRY(hipSetDevice(c->device));
     int* d = (int*)c->arena;
     int h[320];
@@ -213,38 +188,17 @@ extern "C" int abea_selftest(abea_ctx* c) {
     HIP_TRY(hipMemcpyAsync(h, d, sizeof h, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     for (int l = 0; l < 64; ++l) {
-        if (h[l] != l - 1) return fail(ABEA_EHIP, "selftest: wave_shr:1 lane %d got %d", l, h[l]);
-        if (h[64 + l] != (l == 63 ? -1 : l + 1)) return fail(ABEA_EHIP, "selftest: wave_shl:1 lane %d got %d", l, h[64 + l]);
-        if (h[128 + l] != 147) return fail(ABEA_EHIP, "selftest: readlane lane %d got %d", l, h[128 + l]);
-        if (h[192 + l] != (l == 49 ? 777 : l)) return fail(ABEA_EHIP, "selftest: writelane lane %d got %d", l, h[192 + l]);
-        if (h[256 + l] != 1) return fail(ABEA_EHIP, "selftest: fp64-reciprocal quotient differs from a/b at lane %d", l);
+        if (h[l] != l - 1) return abea_fail(ABEA_EHIP, "selftest: wave_shr:1 lane %d got %d", l, h[l]);
+        if (h[64 + l] != (l == 63 ? -1 : l + 1)) return abea_fail(ABEA_EHIP, "selftest: wave_shl:1 lane %d got %d", l, h[64 + l]);
+        if (h[128 + l] != 147) return abea_fail(ABEA_EHIP, "selftest: readlane lane %d got %d", l, h[128 + l]);
+        if (h[192 + l] != (l == 49 ? 777 : l)) return abea_fail(ABEA_EHIP, "selftest: writelane lane %d got %d", l, h[192 + l]);
+        if (h[256 + l] != 1) return abea_fail(ABEA_EHIP, "selftest: fp64-reciprocal quotient differs from a/b at lane %d", l);
     }
     return ABEA_OK;
 }
 
 /* ------------------------------------------------------------------ batch planning */
-struct plan_read {
-    int32_t idx;          /* index in the caller's batch */
-    int32_t L, E, K;
-    int64_t n_bands;
-    bool run;
-};
-
-/* per-read scratch bytes (kpar, evm, codes, trace, desc) */
-static size_t scratch_bytes(const plan_read& r) {
-    const size_t n_groups = (size_t)(r.n_bands + ABEA_GROUP - 1) / ABEA_GROUP;
-    return align_up((size_t)r.K * sizeof(abea_kpar_t), 16) + align_up((size_t)r.E * 4 + 256, 16) +
-           align_up(((size_t)(r.E + r.K) / 16 + 2) * 4, 16) + n_groups * 64 * sizeof(uint4) +
-           sizeof(abea_read_desc);
-}
-
-/* element counts of one launch's scratch arrays */
-struct sub_layout { size_t n_kpar = 0, n_evm = 0, n_code = 0, n_trace = 0; };
-
-/* Descriptor of one read and its place in the launch's scratch; the caller sets read_off/event_off/pair_off/kmer_off. */
-static void plan_desc(abea_read_desc& d, const plan_read& r, int k, const abea_scalings_t& sc, sub_layout& lay,
-                      abea_stats& st) {
-    (void)k;
+void plan_desc(abea_read_desc& d, const plan_read& r, const abea_scalings_t& sc, sub_layout& lay, abea_stats& st) {
     memset(&d, 0, sizeof d);
     d.out_idx = r.idx;
     d.read_len = r.L; d.n_events = r.E; d.n_kmers = r.K;
@@ -274,53 +228,31 @@ static void plan_desc(abea_read_desc& d, const plan_read& r, int k, const abea_s
                       16ull * r.K + 4ull * r.E;
 }
 
-/* the align_single guard (f5c.c:813-814, E/L < 15.0f in float); reads shorter than k are UB in the reference
- * (size_t underflow, align.c:191) and rejected here */
-/* the kernels address the trace with 32-bit byte offsets (32 B per band): 2^27 bands = a read of ~40 Mbases */
-static const int64_t ABEA_MAX_BANDS = (int64_t)1 << 27;
-
-static plan_read make_plan(int32_t idx, int32_t L, int32_t E, uint32_t k) {
-    plan_read r;
-    r.idx = idx; r.L = L; r.E = E;
-    r.K = L - (int32_t)k + 1;
-    r.run = E > 0 && r.K >= 1 && ((float)E / (float)L) < 15.0f;
-    r.n_bands = (int64_t)E + r.K + 2;
-    return r;
-}
-
-static int ensure_pinned(void** p, size_t* cap, size_t need) {
+int ensure_pinned(void** p, size_t* cap, size_t need) {
     if (*cap >= need) return ABEA_OK;
     if (*p) hipHostFree(*p);
     *p = nullptr; *cap = 0;
     size_t n = align_up(need + need / 4, 4096);
-    if (hipHostMalloc(p, n, hipHostMallocDefault) != hipSuccess) return fail(ABEA_EHIP, "hipHostMalloc(%zu) failed", n);
-    *cap = n;
-    return ABEA_OK;
-}
-static int ensure_dev(void** p, size_t* cap, size_t need) {
-    if (*cap >= need) return ABEA_OK;
-    if (*p) hipFree(*p);
-    *p = nullptr; *cap = 0;
-    size_t n = align_up(need + need / 4, 4096);
-    if (hipMalloc(p, n) != hipSuccess) return fail(ABEA_EHIP, "hipMalloc(%zu) failed", n);
+    if (hipHostMalloc(p, n, hipHostMallocDefault) != hipSuccess) return abea_fail(ABEA_EHIP, "hipHostMalloc(%zu) failed", n);
     *cap = n;
     return ABEA_OK;
 }
 
 extern "C" int abea_align_batch_device(abea_ctx* c, const abea_device_batch* B) {
-    if (!c || !B) return fail(ABEA_EINVAL, "null argument");
+    if (!c || !B) return abea_fail(ABEA_EINVAL, "null argument");
+    if (!c->children.empty()) return abea_fail(ABEA_EINVAL, "abea_align_batch_device needs a single-device context");
     const int32_t n = B->n_reads;
-    if (n < 0) return fail(ABEA_EINVAL, "n_reads < 0");
-    const double t_start = now_ms();
+    if (n < 0) return abea_fail(ABEA_EINVAL, "n_reads < 0");
+    const double t_start = abea_now_ms();
     abea_stats st; memset(&st, 0, sizeof st);
     st.arena_bytes = c->arena_bytes;
     if (n == 0) { st.total_ms = 0; c->stats = st; return ABEA_OK; }
     if (!B->read_ptr || !B->read_len || !B->event_ptr || !B->n_events || !B->pair_ptr || !B->scalings ||
         !B->reads || !B->events || !B->pairs || !B->n_pairs)
-        return fail(ABEA_EINVAL, "abea_align_batch_device: null array");
+        return abea_fail(ABEA_EINVAL, "abea_align_batch_device: null array");
     if (B->base_to_event_map && (!B->kmer_ptr || !B->scalings_io || !B->events_per_base || !B->read_stat_flag ||
                                  !B->n_event_alignment))
-        return fail(ABEA_EINVAL, "abea_align_batch_device: scaling outputs requested but some are null");
+        return abea_fail(ABEA_EINVAL, "abea_align_batch_device: scaling outputs requested but some are null");
     HIP_TRY(hipSetDevice(c->device));      /* the caller's thread changes per batch (f5c.cu:692-694) */
 
     /* ---- guards + ordering ---- */
@@ -331,7 +263,7 @@ extern "C" int abea_align_batch_device(abea_ctx* c, const abea_device_batch* B) 
         plan_read& r = reads[(size_t)i];
         r = make_plan(i, B->read_len[i], B->n_events[i], c->k);
         if (r.run && r.n_bands > ABEA_MAX_BANDS)
-            return fail(ABEA_EINVAL, "read %d has %lld bands; the limit is %lld", i, (long long)r.n_bands, (long long)ABEA_MAX_BANDS);
+            return abea_fail(ABEA_EINVAL, "read %d has %lld bands; the limit is %lld", i, (long long)r.n_bands, (long long)ABEA_MAX_BANDS);
         if (r.run) order.push_back(i); else skipped.push_back(i);
     }
     std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) {
@@ -339,7 +271,7 @@ extern "C" int abea_align_batch_device(abea_ctx* c, const abea_device_batch* B) 
     st.n_reads_skipped = (int64_t)skipped.size();
     st.n_reads_gpu = (int64_t)order.size();
 
-    /* skipped reads ride along in the first launch as n_groups == 0 descriptors */
+    /* skipped reads are appended last: they ride along in the last sub-batch as n_groups == 0 descriptors */
     std::vector<int32_t> seq; seq.reserve((size_t)n);
     seq.insert(seq.end(), order.begin(), order.end());
     seq.insert(seq.end(), skipped.begin(), skipped.end());
@@ -355,7 +287,7 @@ extern "C" int abea_align_batch_device(abea_ctx* c, const abea_device_batch* B) 
             bytes += need; ++end;
         }
         if (end == pos)
-            return fail(ABEA_ENOMEM, "read %d (L=%d, E=%d) needs more scratch than the %zu-byte arena",
+            return abea_fail(ABEA_ENOMEM, "read %d (L=%d, E=%d) needs more scratch than the %zu-byte arena",
                         seq[pos], reads[(size_t)seq[pos]].L, reads[(size_t)seq[pos]].E, c->arena_bytes);
         const size_t m = end - pos;
         int rc = ensure_pinned((void**)&c->h_desc, &c->h_desc_cap, m * sizeof(abea_read_desc));
@@ -366,7 +298,7 @@ extern "C" int abea_align_batch_device(abea_ctx* c, const abea_device_batch* B) 
         for (size_t j = 0; j < m; ++j) {
             const plan_read& r = reads[(size_t)seq[pos + j]];
             abea_read_desc& d = c->h_desc[j];
-            plan_desc(d, r, (int)c->k, B->scalings[r.idx], lay, st);
+            plan_desc(d, r, B->scalings[r.idx], lay, st);
             d.read_off = B->read_ptr[r.idx]; d.event_off = B->event_ptr[r.idx]; d.pair_off = B->pair_ptr[r.idx];
             d.kmer_off = B->kmer_ptr ? B->kmer_ptr[r.idx] : 0;
         }
@@ -378,7 +310,7 @@ extern "C" int abea_align_batch_device(abea_ctx* c, const abea_device_batch* B) 
         uint32_t* d_codes = (uint32_t*)p;                   p += align_up(n_code * 4, 256);
         uint4* d_trace = (uint4*)p;                         p += n_trace * sizeof(uint4);
         if ((size_t)(p - c->arena) > c->arena_bytes)
-            return fail(ABEA_ENOMEM, "internal: sub-batch layout %zu exceeds arena %zu", (size_t)(p - c->arena), c->arena_bytes);
+            return abea_fail(ABEA_ENOMEM, "internal: sub-batch layout %zu exceeds arena %zu", (size_t)(p - c->arena), c->arena_bytes);
 
         HIP_TRY(hipMemcpyAsync(d_desc, c->h_desc, m * sizeof(abea_read_desc), hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipEventRecord(c->ev[0], c->stream));
@@ -386,7 +318,8 @@ extern "C" int abea_align_batch_device(abea_ctx* c, const abea_device_batch* B) 
                            d_desc, B->reads, B->events, c->d_model, (int)c->k, d_kpar, d_evm);
         HIP_TRY(hipEventRecord(c->ev[1], c->stream));
         hipLaunchKernelGGL(abea_align_kernel, dim3((unsigned)m), dim3(64), 0, c->stream,
-                           d_desc, d_evm, d_kpar, d_trace, d_codes, B->pairs, B->n_pairs, B->diag);
+                           d_desc, d_evm, d_kpar, d_trace, d_codes, B->pairs, B->n_pairs, B->diag,
+                           (unsigned long long*)nullptr, (int64_t*)nullptr);
         HIP_TRY(hipEventRecord(c->ev[2], c->stream));
         if (B->base_to_event_map) {                          /* row N1: scaling_single on the device */
             hipLaunchKernelGGL(abea_scaling_kernel, dim3((unsigned)m), dim3(64), 0, c->stream,
@@ -405,7 +338,7 @@ extern "C" int abea_align_batch_device(abea_ctx* c, const abea_device_batch* B) 
         st.n_sub_batches += 1; st.fill_launches += 1;
         pos = end;
     }
-    st.total_ms = now_ms() - t_start;
+    st.total_ms = abea_now_ms() - t_start;
     c->stats = st;
     if (c->verbosity > 1)
         fprintf(stderr, "[abea] %lld reads on GPU, %lld skipped, %lld sub-batch(es): pre %.3f ms fill %.3f ms post %.3f ms\n",
@@ -416,15 +349,16 @@ extern "C" int abea_align_batch_device(abea_ctx* c, const abea_device_batch* B) 
 
 /* ------------------------------------------------------------------ raw signal -> events (row N2) */
 extern "C" int abea_detect_events_device(abea_ctx* c, const abea_signal_batch* B) {
-    if (!c || !B) return fail(ABEA_EINVAL, "null argument");
+    if (!c || !B) return abea_fail(ABEA_EINVAL, "null argument");
+    if (!c->children.empty()) return abea_fail(ABEA_EINVAL, "abea_detect_events_device needs a single-device context");
     const int32_t n = B->n_reads;
-    if (n < 0) return fail(ABEA_EINVAL, "n_reads < 0");
+    if (n < 0) return abea_fail(ABEA_EINVAL, "n_reads < 0");
     if (n == 0) return ABEA_OK;
     if (!B->sig_ptr || !B->n_samples || !B->scaling || !B->event_ptr || !B->event_cap || !B->signal || !B->events ||
         !B->n_events)
-        return fail(ABEA_EINVAL, "abea_detect_events_device: null array");
+        return abea_fail(ABEA_EINVAL, "abea_detect_events_device: null array");
     if (B->scalings && (!B->reads || !B->read_ptr || !B->read_len))
-        return fail(ABEA_EINVAL, "abea_detect_events_device: scalings need the read sequences");
+        return abea_fail(ABEA_EINVAL, "abea_detect_events_device: scalings need the read sequences");
     HIP_TRY(hipSetDevice(c->device));
     /* lane-per-read passes: order reads by length so that the 64 reads of a wavefront finish together */
     std::vector<int32_t> order((size_t)n);
@@ -438,7 +372,7 @@ extern "C" int abea_detect_events_device(abea_ctx* c, const abea_signal_batch* B
         /* ---- carve waves whose interleaved scratch fits the arena: per sample S,Q fp64 + two float t-statistics
          *      (24 B), per event slot a peak position + a mean (8 B) ---- */
         const size_t idx_bytes = N * (4 + 8 + 4 + 12 + 8 + 4 + 8 + 4 + 4 + 4) + (size_t)n_waves_all * 56 + 8192;
-        if (idx_bytes + (1u << 20) > c->arena_bytes) return fail(ABEA_ENOMEM, "arena too small for %d index records", n);
+        if (idx_bytes + (1u << 20) > c->arena_bytes) return abea_fail(ABEA_ENOMEM, "arena too small for %d index records", n);
         const size_t budget = c->arena_bytes - idx_bytes - 4096;
         std::vector<int64_t> wave_base, peak_base, kmer_base, seg_base; std::vector<int32_t> wave_len, wave_cap, wave_k, wave_nseg;
         size_t entries = 0, pentries = 0, kentries = 0, segs = 0;
@@ -460,7 +394,7 @@ extern "C" int abea_detect_events_device(abea_ctx* c, const abea_signal_batch* B
             kmer_base.push_back((int64_t)kentries); wave_k.push_back(wk);
             entries += need; pentries += pneed; kentries += kneed; ++w1;
         }
-        if (w1 == w0) return fail(ABEA_ENOMEM, "a read of %d samples does not fit the %zu-byte arena",
+        if (w1 == w0) return abea_fail(ABEA_ENOMEM, "a read of %d samples does not fit the %zu-byte arena",
                                   B->n_samples[order[(size_t)w0 * 64]], c->arena_bytes);
         const int nw = w1 - w0;
         const int r0 = w0 * 64, nr = std::min(n - r0, nw * 64);
@@ -565,251 +499,5 @@ extern "C" int abea_detect_events_device(abea_ctx* c, const abea_signal_batch* B
         c->stats.event_ms += ms;
         w0 = w1;
     }
-    return ABEA_OK;
-}
-
-/* run fn(i) for i in [0,n) on up to `threads` host threads, contiguous blocks (reads are independent) */
-template <class F> static void parallel_for(int32_t n, int threads, F fn) {
-    threads = std::max(1, std::min(threads, n / 64 + 1));
-    if (threads == 1) { for (int32_t i = 0; i < n; ++i) fn(i); return; }
-    std::vector<std::thread> pool;
-    const int32_t step = (n + threads - 1) / threads;
-    for (int t = 0; t < threads; ++t) {
-        const int32_t lo = t * step, hi = std::min(n, lo + step);
-        if (lo >= hi) break;
-        pool.emplace_back([=]() { for (int32_t i = lo; i < hi; ++i) fn(i); });
-    }
-    for (auto& th : pool) th.join();
-}
-
-/* ------------------------------------------------------------------ host batch (db_t view) */
-/* Finish the chunk in flight in `sl`: wait for its D2H, then un-flatten into the caller-owned per-read buffers
- * (the role of f5c.cu:1003-1030; pairs arrive already ascending). */
-static int host_retire(abea_ctx* c, abea_ctx::host_slot& sl, const abea_host_batch* H, int host_threads, abea_stats& st,
-                       double& host_ms) {
-    if (!sl.busy) return ABEA_OK;
-    const int32_t* npairs = (const int32_t*)(sl.pinned + sl.o_npairs);
-    const abea_pair_t* pairs = (const abea_pair_t*)(sl.pinned + sl.o_pairs);
-    const abea_read_diag* diag = (const abea_read_diag*)(sl.pinned + sl.o_diag);
-    const int32_t first = sl.first;
-    int32_t lo = 0;
-    for (int q = 0; q < abea_ctx::host_slot::N_PIECES; ++q) {           /* piece q un-flattens while piece q+1 is still copying */
-        HIP_TRY(hipEventSynchronize(sl.piece_done[q]));
-        const int32_t hi = sl.piece_end[q];
-        const double t0 = now_ms();
-        parallel_for(hi - lo, host_threads, [&](int32_t t) {
-            const int32_t j = lo + t, i = first + j;
-            const int32_t np = npairs[j];
-            H->n_pairs[i] = np;
-            if (np > 0) memcpy(H->pairs[i], pairs + sl.pair_off[(size_t)j], (size_t)np * sizeof(abea_pair_t));
-            if (H->diag) H->diag[i] = diag[j];
-        });
-        host_ms += now_ms() - t0;
-        lo = hi;
-    }
-    HIP_TRY(hipEventSynchronize(sl.done));
-    float ms = 0;
-    HIP_TRY(hipEventElapsedTime(&ms, sl.k0, sl.k1));
-    st.fill_ms += ms;
-    for (int32_t j = 0; j < sl.count; ++j) st.sum_pairs += npairs[j];
-    sl.busy = false;
-    (void)c;
-    return ABEA_OK;
-}
-
-/* Replaces align_cuda (f5c.cu:647-1061).  The batch is cut into chunks of reads; each chunk is flattened into pinned
- * memory (sequence + event means only: ABEA reads nothing else of event_t, align.c:131), copied, aligned and copied
- * back on its slot's stream, so that the host copies, both PCIe directions and the kernels of neighbouring chunks
- * overlap.  Results do not depend on the chunking (reads are independent). */
-extern "C" int abea_align_batch_host(abea_ctx* c, const abea_host_batch* H) {
-    if (!c || !H) return fail(ABEA_EINVAL, "null argument");
-    const int32_t n = H->n_reads;
-    if (n < 0) return fail(ABEA_EINVAL, "n_reads < 0");
-    if (n == 0) { memset(&c->stats, 0, sizeof c->stats); return ABEA_OK; }
-    if (!H->read || !H->read_len || !H->events || !H->n_events || !H->scalings || !H->pairs || !H->n_pairs)
-        return fail(ABEA_EINVAL, "abea_align_batch_host: null array");
-    const double t_start = now_ms();
-    HIP_TRY(hipSetDevice(c->device));
-    abea_stats st; memset(&st, 0, sizeof st);
-    st.arena_bytes = c->arena_bytes;
-    double host_ms = 0;
-
-    std::vector<plan_read> reads((size_t)n);
-    for (int32_t i = 0; i < n; ++i) {
-        const bool good = (!H->n_samples || H->n_samples[i] > 0) && H->read[i] && H->events[i] && H->pairs[i] &&
-                          H->read_len[i] > 0 && H->n_events[i] > 0 && H->n_events[i] < (uint64_t)INT32_MAX;
-        /* bad read (nsample == 0): n_pairs = 0 (f5c.c:826-828) */
-        reads[(size_t)i] = make_plan(i, good ? H->read_len[i] : 0, good ? (int32_t)H->n_events[i] : 0, c->k);
-        if (reads[(size_t)i].run && reads[(size_t)i].n_bands > ABEA_MAX_BANDS)
-            return fail(ABEA_EINVAL, "read %d has %lld bands; the limit is %lld", i, (long long)reads[(size_t)i].n_bands,
-                        (long long)ABEA_MAX_BANDS);
-        if (reads[(size_t)i].run) ++st.n_reads_gpu; else ++st.n_reads_skipped;
-    }
-    const int host_threads = (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
-    size_t target_events = (size_t)64 << 20;   /* a launch lasts as long as its longest read: keep chunks big */
-    if (const char* e = getenv("ABEA_HOST_CHUNK_EVENTS")) target_events = std::max<size_t>(1, strtoull(e, nullptr, 10));
-    const size_t slot_arena = c->arena_bytes / abea_ctx::N_SLOTS / 4096 * 4096;
-
-    /* device + pinned bytes one read adds to a chunk besides scratch_bytes(): sequence, pair capacity, n_pairs, diag */
-    auto io_bytes = [](const plan_read& r) {
-        return align_up((size_t)r.L + 1, 16) + ((size_t)r.E + (size_t)r.L) * sizeof(abea_pair_t) + 4 + sizeof(abea_read_diag);
-    };
-    int32_t pos = 0, turn = 0;
-    std::vector<int32_t> order;
-    while (pos < n) {
-        /* ---- carve a chunk ---- */
-        size_t bytes = 65536, ev = 0;
-        int32_t end = pos;
-        bool whole_arena = false;
-        while (end < n) {
-            const plan_read& r = reads[(size_t)end];
-            const size_t need = (r.run ? scratch_bytes(r) : sizeof(abea_read_desc)) + io_bytes(r) + 1024;
-            if (bytes + need > slot_arena) {
-                if (end > pos) break;
-                if (bytes + need > c->arena_bytes)
-                    return fail(ABEA_ENOMEM, "read %d (L=%d, E=%d) needs more scratch than the %zu-byte arena", end, r.L, r.E,
-                                c->arena_bytes);
-                whole_arena = true;                      /* an over-long read: give it the whole arena, alone */
-            }
-            bytes += need; ev += (size_t)r.E; ++end;
-            if (ev >= target_events || whole_arena) break;
-        }
-        const int32_t m = end - pos;
-        abea_ctx::host_slot& sl = c->slot[whole_arena ? 0 : turn % abea_ctx::N_SLOTS];
-        int rc;
-        if (whole_arena) { for (auto& o : c->slot) if ((rc = host_retire(c, o, H, host_threads, st, host_ms))) return rc; }
-        else if ((rc = host_retire(c, sl, H, host_threads, st, host_ms))) return rc;
-        uint8_t* arena = whole_arena ? c->arena : c->arena + (size_t)(turn % abea_ctx::N_SLOTS) * slot_arena;
-
-        /* ---- plan: longest first, skipped reads last (n_groups == 0 descriptors) ---- */
-        const double t0 = now_ms();
-        order.clear();
-        for (int32_t i = pos; i < end; ++i) if (reads[(size_t)i].run) order.push_back(i);
-        std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) {
-            return reads[(size_t)a].n_bands > reads[(size_t)b].n_bands; });
-        for (int32_t i = pos; i < end; ++i) if (!reads[(size_t)i].run) order.push_back(i);
-        size_t n_read = 0, n_pair = 0;
-        for (int32_t i = pos; i < end; ++i) {
-            n_read += align_up((size_t)reads[(size_t)i].L + 1, 16);
-            n_pair += (size_t)reads[(size_t)i].E + (size_t)reads[(size_t)i].L;
-        }
-        /* pinned block: [desc][reads][evm] go up, [npairs][pairs][diag] come down */
-        std::vector<abea_read_desc> descs((size_t)m);
-        sub_layout lay;
-        {
-            size_t ro = 0, po = 0;
-            std::vector<int64_t> roff((size_t)m);
-            std::vector<int64_t>& poff = sl.pair_off;
-            poff.resize((size_t)m + 1);
-            for (int32_t i = pos; i < end; ++i) {         /* sequences and pair lists keep the caller's order */
-                roff[(size_t)(i - pos)] = (int64_t)ro; ro += align_up((size_t)reads[(size_t)i].L + 1, 16);
-                poff[(size_t)(i - pos)] = (int64_t)po; po += (size_t)reads[(size_t)i].E + (size_t)reads[(size_t)i].L;
-            }
-            poff[(size_t)m] = (int64_t)po;
-            for (int32_t j = 0; j < m; ++j) {
-                plan_read r = reads[(size_t)order[(size_t)j]];
-                r.idx = order[(size_t)j] - pos;           /* out_idx is chunk-local */
-                plan_desc(descs[(size_t)j], r, (int)c->k, H->scalings[order[(size_t)j]], lay, st);
-                descs[(size_t)j].read_off = roff[(size_t)r.idx];
-                descs[(size_t)j].pair_off = poff[(size_t)r.idx];
-            }
-        }
-        size_t o = 0;
-        sl.o_desc = o;                 o = align_up(o + (size_t)m * sizeof(abea_read_desc), 256);
-        const size_t o_reads = o;      o = align_up(o + n_read, 256);
-        const size_t o_evm = o;        o = align_up(o + lay.n_evm * 4 + 512, 256);
-        sl.o_npairs = o;               o = align_up(o + (size_t)m * 4, 256);
-        sl.o_pairs = o;                o = align_up(o + n_pair * sizeof(abea_pair_t), 256);
-        sl.o_diag = o;                 o = align_up(o + (size_t)m * sizeof(abea_read_diag), 256);
-        if ((rc = ensure_pinned((void**)&sl.pinned, &sl.pinned_cap, o))) return rc;
-        memcpy(sl.pinned + sl.o_desc, descs.data(), (size_t)m * sizeof(abea_read_desc));
-
-        /* ---- arena layout: [desc][kpar][evm][codes][trace][reads][npairs][pairs][diag] ---- */
-        uint8_t* p = arena;
-        abea_read_desc* d_desc = (abea_read_desc*)p;        p += align_up((size_t)m * sizeof(abea_read_desc), 256);
-        abea_kpar_t* d_kpar = (abea_kpar_t*)p;              p += align_up(lay.n_kpar * sizeof(abea_kpar_t), 256);
-        float* d_evm = (float*)p;                           p += align_up(lay.n_evm * 4 + 512, 256);
-        uint32_t* d_codes = (uint32_t*)p;                   p += align_up(lay.n_code * 4, 256);
-        uint4* d_trace = (uint4*)p;                         p += align_up(lay.n_trace * sizeof(uint4), 256);
-        char* d_reads = (char*)p;                           p += align_up(n_read, 256);
-        int32_t* d_npairs = (int32_t*)p;                    p += align_up((size_t)m * 4, 256);
-        abea_pair_t* d_pairs = (abea_pair_t*)p;             p += align_up(n_pair * sizeof(abea_pair_t), 256);
-        abea_read_diag* d_diag = (abea_read_diag*)p;        p += align_up((size_t)m * sizeof(abea_read_diag), 256);
-        if ((size_t)(p - arena) > (whole_arena ? c->arena_bytes : slot_arena))
-            return fail(ABEA_ENOMEM, "internal: chunk layout %zu exceeds its arena share %zu", (size_t)(p - arena),
-                        whole_arena ? c->arena_bytes : slot_arena);
-
-        /* ---- flatten (the role of f5c.cu:744-802, which runs on one thread) and copy up, piece by piece ---- */
-        const int NP = abea_ctx::host_slot::N_PIECES;
-        char* h_reads = (char*)(sl.pinned + o_reads);
-        float* h_evm = (float*)(sl.pinned + o_evm);
-        parallel_for(m, host_threads, [&](int32_t j) {
-            const abea_read_desc& d = descs[(size_t)j];
-            const size_t L = (size_t)d.read_len;
-            if (L) memcpy(h_reads + d.read_off, H->read[pos + d.out_idx], L);
-            h_reads[d.read_off + (int64_t)L] = '\0';
-        });
-        HIP_TRY(hipMemcpyAsync(d_desc, sl.pinned + sl.o_desc, (size_t)m * sizeof(abea_read_desc), hipMemcpyHostToDevice, sl.stream));
-        HIP_TRY(hipMemcpyAsync(d_reads, h_reads, n_read, hipMemcpyHostToDevice, sl.stream));
-        int32_t j0 = 0;
-        for (int q = 0; q < NP; ++q) {                     /* descriptors are in evm order: a j-range is one contiguous span */
-            const size_t want = lay.n_evm * (size_t)(q + 1) / NP;
-            int32_t j1 = j0;
-            while (j1 < m && (q == NP - 1 || descs[(size_t)j1].n_groups == 0 || (size_t)descs[(size_t)j1].evm_off < want)) ++j1;
-            parallel_for(j1 - j0, host_threads, [&](int32_t t) {
-                const abea_read_desc& d = descs[(size_t)(j0 + t)];
-                if (d.n_groups == 0) return;
-                const abea_event_t* ev = H->events[pos + d.out_idx];
-                float* dst = h_evm + d.evm_off;
-                for (int32_t e = 0; e < d.n_events; ++e) dst[e] = ev[e].mean;
-            });
-            size_t e0 = lay.n_evm, e1 = lay.n_evm;         /* span of this piece in evm (skipped reads own none) */
-            for (int32_t j = j0; j < j1; ++j) if (descs[(size_t)j].n_groups) { e0 = (size_t)descs[(size_t)j].evm_off; break; }
-            for (int32_t j = j1; j < m; ++j) if (descs[(size_t)j].n_groups) { e1 = (size_t)descs[(size_t)j].evm_off; break; }
-            if (e1 > e0)
-                HIP_TRY(hipMemcpyAsync(d_evm + e0, h_evm + e0, (e1 - e0) * 4, hipMemcpyHostToDevice, sl.stream));
-            j0 = j1;
-        }
-        host_ms += now_ms() - t0;
-
-        /* ---- kernels, then copy down in pieces of the caller's order ---- */
-        HIP_TRY(hipEventRecord(sl.k0, sl.stream));
-        hipLaunchKernelGGL(abea_pre_kernel, dim3((unsigned)m), dim3(256), 0, sl.stream,
-                           d_desc, d_reads, (const abea_event_t*)nullptr, c->d_model, (int)c->k, d_kpar, d_evm);
-        hipLaunchKernelGGL(abea_align_kernel, dim3((unsigned)m), dim3(64), 0, sl.stream,
-                           d_desc, d_evm, d_kpar, d_trace, d_codes, d_pairs, d_npairs, H->diag ? d_diag : nullptr);
-        HIP_TRY(hipEventRecord(sl.k1, sl.stream));
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(sl.pinned + sl.o_npairs, d_npairs, (size_t)m * 4, hipMemcpyDeviceToHost, sl.stream));
-        if (H->diag)
-            HIP_TRY(hipMemcpyAsync(sl.pinned + sl.o_diag, d_diag, (size_t)m * sizeof(abea_read_diag), hipMemcpyDeviceToHost, sl.stream));
-        int32_t i0 = 0;
-        for (int q = 0; q < NP; ++q) {
-            const int64_t want = sl.pair_off[(size_t)m] * (q + 1) / NP;
-            int32_t i1 = i0;
-            while (i1 < m && (q == NP - 1 || sl.pair_off[(size_t)i1 + 1] <= want)) ++i1;
-            const int64_t p0 = sl.pair_off[(size_t)i0], p1 = sl.pair_off[(size_t)i1];
-            if (p1 > p0)
-                HIP_TRY(hipMemcpyAsync(sl.pinned + sl.o_pairs + (size_t)p0 * sizeof(abea_pair_t), d_pairs + p0,
-                                       (size_t)(p1 - p0) * sizeof(abea_pair_t), hipMemcpyDeviceToHost, sl.stream));
-            HIP_TRY(hipEventRecord(sl.piece_done[q], sl.stream));
-            sl.piece_end[q] = i1;
-            i0 = i1;
-        }
-        HIP_TRY(hipEventRecord(sl.done, sl.stream));
-        sl.busy = true; sl.first = pos; sl.count = m;
-        st.n_sub_batches += 1; st.fill_launches += 1;
-        if (whole_arena) { if ((rc = host_retire(c, sl, H, host_threads, st, host_ms))) return rc; }
-        else ++turn;
-        pos = end;
-    }
-    /* ---- drain, oldest chunk first ---- */
-    for (int q = 0; q < abea_ctx::N_SLOTS; ++q) {
-        int rc = host_retire(c, c->slot[(turn + q) % abea_ctx::N_SLOTS], H, host_threads, st, host_ms);
-        if (rc) return rc;
-    }
-    st.host_ms = host_ms;              /* flatten + un-flatten wall time; the copies overlap it, so h2d/d2h stay 0 */
-    st.total_ms = now_ms() - t_start;
-    c->stats = st;
     return ABEA_OK;
 }

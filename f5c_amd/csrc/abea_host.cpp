@@ -1,0 +1,654 @@
+/* abea_host.cpp — the host-buffer entry of libabea_hip.so: abea_align_batch_host (include/abea.h), the replacement
+ * of the reference's align_cuda (src/f5c.cu:647-1061) as align_db sees it, plus the multi-device dispatch.
+ *
+ * The reference flattens the whole batch on one thread into pageable memory (f5c.cu:744-802), copies, runs three
+ * kernels, copies back and un-flattens with a reversal loop (f5c.cu:1003-1030), all serialised.  Here:
+ *   - reads are ordered longest first (band count E+K) and cut into chunks; a chunk is the unit of flatten -> H2D ->
+ *     align-pre + fused align kernel (+ scaling_single) -> D2H -> un-flatten;
+ *   - chunks rotate through N slots, each with its own HIP stream, pinned staging and share of the device arena;
+ *     kernels of different slots run concurrently on the GPU (the tail of one chunk overlaps the head of the next, so
+ *     chunking does not cost the longest-read latency per chunk), copies of both directions overlap kernels;
+ *   - the host loops run on a persistent pool of worker threads (the caller's thread takes part): flatten gathers the
+ *     event means (4 of event_t's 24 bytes: align.c:131 reads nothing else) and the sequences; un-flatten writes the
+ *     caller's per-read buffers;
+ *   - what comes down over PCIe is the traceback walk, 2 bits per step (0.4 B per event instead of 8.3): the pairs are
+ *     expanded from it on the host while they are written into db->event_align_pairs[i].  ABEA_HOST_PAIRS=device keeps
+ *     the expansion on the GPU and copies compacted pair lists instead;
+ *   - optional scaling_single on the device right behind the alignment (row N1): base_to_event_map + recalibrated
+ *     scalings come back, the pair lists need not.
+ * With a multi-device context (abea_init_multi) the batch is first split over the devices, longest-processing-time-
+ * first on the band count, and each device runs the pipeline above on its share from its own host thread.
+ * No CPU alignment fallback exists in this library.
+ */
+#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <queue>
+#include <string>
+#include <thread>
+#include <sched.h>
+#include <immintrin.h>
+#include "abea_internal.h"
+
+/* ------------------------------------------------------------------ host worker pool */
+/* CPUs this process may actually use: min(affinity mask, cgroup CPU quota) */
+static int effective_cpus() {
+    int n = (int)std::thread::hardware_concurrency();
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) n = std::min(n > 0 ? n : 1 << 20, CPU_COUNT(&set));
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {                       /* cgroup v2 */
+        char q[64]; long long p = 0;
+        if (fscanf(f, "%63s %lld", q, &p) == 2 && strcmp(q, "max") != 0 && p > 0)
+            n = std::min<long long>(n, std::max<long long>(1, (atoll(q) + p / 2) / p));
+        fclose(f);
+    } else {                                                                     /* cgroup v1 */
+        long long q = -1, p = 0;
+        if (FILE* g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(g, "%lld", &q) != 1) q = -1; fclose(g); }
+        if (FILE* g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(g, "%lld", &p) != 1) p = 0; fclose(g); }
+        if (q > 0 && p > 0) n = std::min<long long>(n, std::max<long long>(1, (q + p / 2) / p));
+    }
+    return std::max(1, n);
+}
+
+struct abea_host_pool {
+    typedef std::function<void(int64_t, int64_t)> fn_t;       /* fn(lo, hi): items [lo, hi) */
+    std::vector<std::thread> th;
+    std::mutex mu;
+    std::condition_variable cv_go, cv_done;
+    const fn_t* fn = nullptr;
+    std::atomic<int64_t> next{0};
+    int64_t n = 0, grain = 1;
+    int running = 0;
+    uint64_t gen = 0;
+    bool stop = false;
+
+    explicit abea_host_pool(int threads) {
+        for (int t = 1; t < threads; ++t) th.emplace_back([this]() { worker(); });
+    }
+    ~abea_host_pool() {
+        { std::lock_guard<std::mutex> lk(mu); stop = true; }
+        cv_go.notify_all();
+        for (auto& t : th) t.join();
+    }
+    int threads() const { return (int)th.size() + 1; }
+    void drain() {
+        for (;;) {
+            const int64_t lo = next.fetch_add(grain);
+            if (lo >= n) break;
+            (*fn)(lo, std::min(n, lo + grain));
+        }
+    }
+    void worker() {
+        uint64_t seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_go.wait(lk, [&]() { return stop || gen != seen; });
+                if (stop) return;
+                seen = gen;
+            }
+            drain();
+            { std::lock_guard<std::mutex> lk(mu); if (--running == 0) cv_done.notify_all(); }
+        }
+    }
+    /* run f over [0, n_items) in pieces of `g` items, dynamically scheduled; the caller's thread takes part */
+    void run(int64_t n_items, int64_t g, const fn_t& f) {
+        if (n_items <= 0) return;
+        if (th.empty() || n_items <= g) { f(0, n_items); return; }
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            fn = &f; n = n_items; grain = std::max<int64_t>(1, g); next.store(0);
+            running = (int)th.size(); ++gen;
+        }
+        cv_go.notify_all();
+        drain();
+        std::unique_lock<std::mutex> lk(mu);
+        cv_done.wait(lk, [&]() { return running == 0; });
+        fn = nullptr;
+    }
+};
+
+/* ------------------------------------------------------------------ one chunk in flight */
+struct abea_host_slot {
+    hipStream_t stream = nullptr;
+    hipEvent_t k0 = nullptr, k1 = nullptr, k2 = nullptr, k3 = nullptr, kdone = nullptr, done = nullptr;
+    uint8_t* up = nullptr;  size_t up_cap = 0;          /* pinned, host -> device: [desc][reads][evm] */
+    uint8_t* dn = nullptr;  size_t dn_cap = 0;          /* pinned, device -> host */
+    bool busy = false;
+    /* ---- the chunk in flight ---- */
+    int32_t m = 0, chunk_no = 0;
+    std::vector<int32_t> rd;                            /* caller index of descriptor j */
+    bool scaling = false, device_pairs = false, staged = false;
+    size_t o_np = 0, o_diag = 0, o_codes = 0, o_poff = 0, o_cursor = 0, o_pairs = 0;      /* offsets in `dn` */
+    size_t o_b2e = 0, o_sc = 0, o_epb = 0, o_flag = 0, o_nal = 0;
+    abea_pair_t* d_pairs = nullptr;                     /* device-pairs mode: compacted lists to copy at stage A */
+    size_t pair_cap = 0;
+};
+
+static int slot_create(abea_host_slot** out) {
+    abea_host_slot* s = new abea_host_slot();
+    *out = s;
+    HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreate(&s->k0)); HIP_TRY(hipEventCreate(&s->k1)); HIP_TRY(hipEventCreate(&s->k2)); HIP_TRY(hipEventCreate(&s->k3));
+    HIP_TRY(hipEventCreateWithFlags(&s->kdone, hipEventDisableTiming | (getenv("ABEA_HOST_SPIN") ? 0 : hipEventBlockingSync)));
+    HIP_TRY(hipEventCreateWithFlags(&s->done, hipEventDisableTiming | (getenv("ABEA_HOST_SPIN") ? 0 : hipEventBlockingSync)));
+    return ABEA_OK;
+}
+
+void abea_host_release(abea_ctx* c) {
+    for (abea_host_slot* s : c->slots) {
+        if (!s) continue;
+        if (s->stream) { hipStreamSynchronize(s->stream); hipStreamDestroy(s->stream); }
+        for (hipEvent_t e : {s->k0, s->k1, s->k2, s->k3, s->kdone, s->done}) if (e) hipEventDestroy(e);
+        hipHostFree(s->up); hipHostFree(s->dn);
+        delete s;
+    }
+    c->slots.clear();
+    delete c->pool;
+    c->pool = nullptr;
+}
+
+/* ------------------------------------------------------------------ un-flatten helpers */
+/* The walk's 2-bit codes -> (k-mer, event) pairs in ascending order (align.c:452-513: the reference collects the
+ * pairs backwards, then reverses).  Step j of the walk (j = 0 at the end cell (K-1, best_event)) is pair n-1-j;
+ * code 0 = diagonal (k-mer and event step), 1 = up (event only), 2 = left (k-mer only) — the same expansion as
+ * phase 3 of abea_align_kernel. */
+static void expand_codes(const uint32_t* codes, int32_t n, int32_t k, int32_t e, abea_pair_t* out) {
+    abea_pair_t* o = out + n;
+    for (int32_t j = 0; j < n; j += 16) {
+        uint32_t w = codes[j >> 4];
+        const int32_t lim = std::min(16, n - j);
+        for (int32_t t = 0; t < lim; ++t) {
+            --o;
+            o->ref_pos = k; o->read_pos = e;
+            const uint32_t cd = w & 3u;
+            w >>= 2;
+            k -= (cd != 1u); e -= (cd != 2u);
+        }
+    }
+}
+
+struct host_opts {
+    size_t chunk_events;
+    int32_t chunk_reads_min, chunk_reads_max;
+    int n_slots;
+    bool device_pairs;
+    bool sdma_d2h;             /* experiment: return the result block with hipMemcpyAsync instead of the copy-out kernel */
+};
+
+static host_opts read_opts() {
+    host_opts o;
+    o.chunk_events = (size_t)48 << 20; o.chunk_reads_min = 2048; o.chunk_reads_max = 16384; o.n_slots = 8; o.device_pairs = false;
+    if (const char* e = getenv("ABEA_HOST_CHUNK_EVENTS")) o.chunk_events = std::max<size_t>(1, strtoull(e, nullptr, 10));
+    if (const char* e = getenv("ABEA_HOST_CHUNK_READS")) o.chunk_reads_min = std::max(1, atoi(e));
+    if (const char* e = getenv("ABEA_HOST_CHUNK_READS_MAX")) o.chunk_reads_max = std::max(1, atoi(e));
+    if (const char* e = getenv("ABEA_HOST_SLOTS")) o.n_slots = std::min(8, std::max(1, atoi(e)));
+    if (const char* e = getenv("ABEA_HOST_PAIRS")) o.device_pairs = strcmp(e, "device") == 0;
+    o.sdma_d2h = getenv("ABEA_HOST_SDMA_D2H") != nullptr;
+    o.chunk_reads_max = std::max(o.chunk_reads_max, o.chunk_reads_min);
+    return o;
+}
+
+/* ------------------------------------------------------------------ the pipeline on one device */
+struct host_run_state {
+    double t_origin = 0; bool trace = false;
+    void log(const char* what, int chunk, int m = 0, size_t ev = 0) const {
+        if (trace) fprintf(stderr, "[abea host dev %d] %8.2f ms  chunk %2d  %-14s reads %d events %zu\n", c->device, abea_now_ms() - t_origin, chunk, what, m, ev);
+    }
+    abea_ctx* c;
+    const abea_host_batch* H;
+    host_opts opt;
+    bool want_pairs, scaling, device_pairs;
+    abea_stats st;
+    std::vector<plan_read> reads;         /* indexed by position in `mine` */
+};
+
+/* stage A of a device-pairs chunk: the kernels are done, the total pair count is known -> copy the compacted lists */
+static int slot_stage(host_run_state& S, abea_host_slot& sl, bool block) {
+    if (!sl.busy || !sl.device_pairs || sl.staged) return ABEA_OK;
+    if (!block && hipEventQuery(sl.kdone) != hipSuccess) return ABEA_OK;
+    const double t0 = abea_now_ms();
+    HIP_TRY(hipEventSynchronize(sl.kdone));
+    S.st.wait_ms += abea_now_ms() - t0;
+    const unsigned long long total = *(const unsigned long long*)(sl.dn + sl.o_cursor);
+    if (total > sl.pair_cap) return abea_fail(ABEA_EHIP, "internal: %llu compacted pairs exceed the capacity %zu", total, sl.pair_cap);
+    if (total)
+        HIP_TRY(hipMemcpyAsync(sl.dn + sl.o_pairs, sl.d_pairs, (size_t)total * sizeof(abea_pair_t), hipMemcpyDeviceToHost, sl.stream));
+    HIP_TRY(hipEventRecord(sl.done, sl.stream));
+    S.st.d2h_bytes += total * sizeof(abea_pair_t);
+    sl.staged = true;
+    return ABEA_OK;
+}
+
+/* Finish the chunk in flight in `sl`: wait for its results, then un-flatten into the caller-owned per-read buffers
+ * (the role of f5c.cu:1003-1030). */
+static int slot_retire(host_run_state& S, abea_host_slot& sl) {
+    if (!sl.busy) return ABEA_OK;
+    int rc = slot_stage(S, sl, true);
+    if (rc) return rc;
+    double t0 = abea_now_ms();
+    S.log("wait", sl.chunk_no);
+    HIP_TRY(hipEventSynchronize(sl.done));
+    S.st.wait_ms += abea_now_ms() - t0;
+    S.log("unflatten", sl.chunk_no);
+    const abea_host_batch* H = S.H;
+    const abea_read_desc* descs = (const abea_read_desc*)sl.up;
+    const int32_t* npairs = (const int32_t*)(sl.dn + sl.o_np);
+    const abea_read_diag* diag = (const abea_read_diag*)(sl.dn + sl.o_diag);
+    const uint32_t* codes = (const uint32_t*)(sl.dn + sl.o_codes);
+    const int64_t* poff = (const int64_t*)(sl.dn + sl.o_poff);
+    const abea_pair_t* pairs = (const abea_pair_t*)(sl.dn + sl.o_pairs);
+    const abea_index_pair_t* b2e = (const abea_index_pair_t*)(sl.dn + sl.o_b2e);
+    const abea_scalings_t* sc = (const abea_scalings_t*)(sl.dn + sl.o_sc);
+    const double* epb = (const double*)(sl.dn + sl.o_epb);
+    const int32_t* flag = (const int32_t*)(sl.dn + sl.o_flag);
+    const int32_t* nal = (const int32_t*)(sl.dn + sl.o_nal);
+    t0 = abea_now_ms();
+    const bool want_pairs = S.want_pairs, dev_pairs = sl.device_pairs, scaling = sl.scaling;
+    S.c->pool->run(sl.m, 1, [&](int64_t lo, int64_t hi) {
+        for (int64_t j = lo; j < hi; ++j) {
+            const int32_t i = sl.rd[(size_t)j];
+            const int32_t np = npairs[j];
+            H->n_pairs[i] = np;
+            if (H->diag) H->diag[i] = diag[j];
+            if (want_pairs && np > 0) {
+                if (dev_pairs) memcpy(H->pairs[i], pairs + poff[j], (size_t)np * sizeof(abea_pair_t));
+                else expand_codes(codes + descs[j].code_off, np, descs[j].n_kmers - 1, diag[j].best_event, H->pairs[i]);
+            }
+            if (scaling) {
+                if (np > 0 && H->base_to_event_map[i])
+                    memcpy(H->base_to_event_map[i], b2e + descs[j].kmer_off, (size_t)descs[j].n_kmers * sizeof(abea_index_pair_t));
+                if (H->scalings_out) H->scalings_out[i] = sc[j];
+                if (H->events_per_base) H->events_per_base[i] = epb[j];
+                if (H->read_stat_flag) H->read_stat_flag[i] = flag[j];
+                if (H->n_event_alignment) H->n_event_alignment[i] = nal[j];
+            }
+        }
+    });
+    S.st.unflatten_ms += abea_now_ms() - t0;
+    S.log("retired", sl.chunk_no);
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, sl.k0, sl.k1)); S.st.pre_ms += ms;
+    HIP_TRY(hipEventElapsedTime(&ms, sl.k1, sl.k2)); S.st.fill_ms += ms;
+    if (scaling) { HIP_TRY(hipEventElapsedTime(&ms, sl.k2, sl.k3)); S.st.trace_ms += ms; }
+    for (int32_t j = 0; j < sl.m; ++j) S.st.sum_pairs += npairs[j];
+    sl.busy = false;
+    return ABEA_OK;
+}
+
+/* on every exit, error or not, nothing of this call may stay in flight: the slots' bookkeeping and the pinned /
+ * caller buffers they point at belong to this batch only */
+struct slot_guard {
+    abea_ctx* c;
+    ~slot_guard() {
+        for (abea_host_slot* s : c->slots)
+            if (s && s->busy) { hipStreamSynchronize(s->stream); s->busy = false; }
+    }
+};
+
+static int host_run(abea_ctx* c, const abea_host_batch* H, const int32_t* mine, int32_t n_mine, int host_threads,
+                    abea_stats* st_out) {
+    const double t_start = abea_now_ms();
+    HIP_TRY(hipSetDevice(c->device));          /* the caller's thread changes per batch (f5c.cu:692-694) */
+    host_run_state S;
+    S.c = c; S.H = H; S.opt = read_opts();
+    S.t_origin = t_start; S.trace = getenv("ABEA_HOST_TRACE") != nullptr;
+    memset(&S.st, 0, sizeof S.st);
+    S.st.arena_bytes = c->arena_bytes;
+    S.st.n_devices = 1;
+    S.scaling = H->base_to_event_map != nullptr;
+    S.want_pairs = H->pairs != nullptr;
+    S.device_pairs = S.want_pairs && S.opt.device_pairs && !S.scaling;
+    const bool scaling = S.scaling;
+    const bool pairs_on_device = S.device_pairs || scaling;       /* the scaling kernel reads the pair lists in HBM */
+
+    /* ---- worker pool and slots (persistent across calls) ---- */
+    if (!c->pool || c->pool->threads() != host_threads) { delete c->pool; c->pool = new abea_host_pool(host_threads); }
+    S.st.host_threads = c->pool->threads();
+    while ((int)c->slots.size() < S.opt.n_slots) {
+        abea_host_slot* s = nullptr;
+        const int rc = slot_create(&s);
+        c->slots.push_back(s);
+        if (rc) return rc;
+    }
+    const int n_slots = S.opt.n_slots;
+    for (abea_host_slot* s : c->slots) s->busy = false;          /* nothing survives a call (slot_guard) */
+    slot_guard guard{c};
+
+    /* ---- guards (align_single, f5c.c:811-830) and ordering ---- */
+    S.reads.resize((size_t)n_mine);
+    std::vector<int32_t> order; order.reserve((size_t)n_mine);
+    for (int32_t q = 0; q < n_mine; ++q) {
+        const int32_t i = mine ? mine[q] : q;
+        const bool good = (!H->n_samples || H->n_samples[i] > 0) && H->read[i] && H->events[i] &&
+                          (!S.want_pairs || H->pairs[i]) && H->read_len[i] > 0 && H->n_events[i] > 0 &&
+                          H->n_events[i] < (uint64_t)INT32_MAX;
+        /* bad read (nsample == 0): n_pairs = 0 (f5c.c:826-828) */
+        plan_read r = make_plan(i, good ? H->read_len[i] : 0, good ? (int32_t)H->n_events[i] : 0, c->k);
+        if (r.run && r.n_bands > ABEA_MAX_BANDS)
+            return abea_fail(ABEA_EINVAL, "read %d has %lld bands; the limit is %lld", i, (long long)r.n_bands, (long long)ABEA_MAX_BANDS);
+        S.reads[(size_t)q] = r;
+        if (r.run) { order.push_back(q); ++S.st.n_reads_gpu; }
+        else {
+            ++S.st.n_reads_skipped;
+            H->n_pairs[i] = 0;
+            if (H->diag) {
+                abea_read_diag dg; memset(&dg, 0, sizeof dg);
+                dg.max_score = -__builtin_inff(); dg.flags = ABEA_RF_SKIPPED;
+                H->diag[i] = dg;
+            }
+            if (scaling) {                                        /* f5c.c:786-794: could not align */
+                if (H->scalings_out) H->scalings_out[i] = H->scalings[i];
+                if (H->events_per_base) H->events_per_base[i] = 0.0;
+                if (H->read_stat_flag) H->read_stat_flag[i] |= ABEA_FAILED_ALIGNMENT;
+                if (H->n_event_alignment) H->n_event_alignment[i] = 0;
+            }
+        }
+    }
+    std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) {
+        return S.reads[(size_t)a].n_bands > S.reads[(size_t)b].n_bands; });
+
+    /* device + pinned bytes one read adds to a chunk besides scratch_bytes() */
+    auto io_bytes = [&](const plan_read& r) {
+        size_t b = align_up((size_t)r.L + 1, 16) + 4 + sizeof(abea_read_diag) + 8;
+        if (pairs_on_device) b += ((size_t)r.E + (size_t)r.L) * sizeof(abea_pair_t);
+        if (scaling) b += (size_t)r.K * sizeof(abea_index_pair_t) + sizeof(abea_scalings_t) + 8 + 4 + 4;
+        return b + 64;
+    };
+    /* check every read against the arena before anything is launched */
+    for (int32_t q : order) {
+        const plan_read& r = S.reads[(size_t)q];
+        if (scratch_bytes(r) + io_bytes(r) + 65536 > c->arena_bytes)
+            return abea_fail(ABEA_ENOMEM, "read %d (L=%d, E=%d) needs more scratch than the %zu-byte arena", r.idx, r.L, r.E,
+                             c->arena_bytes);
+    }
+    const size_t slot_arena = c->arena_bytes / (size_t)n_slots / 4096 * 4096;
+    const int min_rescale = H->min_num_events_to_rescale > 0 ? H->min_num_events_to_rescale : 200;
+
+    size_t pos = 0;
+    int turn = 0, chunk_no = 0;
+    while (pos < order.size()) {
+        /* ---- carve a chunk: the first chunks are small so that the longest reads start early ---- */
+        const int ramp = chunk_no == 0 ? 4 : chunk_no == 1 ? 2 : 1;
+        const size_t want_ev = S.opt.chunk_events / ramp;
+        const int32_t want_reads = std::max(1, S.opt.chunk_reads_min / ramp);
+        size_t bytes = 65536, ev = 0, end = pos;
+        bool whole_arena = false;
+        while (end < order.size()) {
+            const plan_read& r = S.reads[(size_t)order[end]];
+            const size_t need = scratch_bytes(r) + io_bytes(r);
+            if (bytes + need > slot_arena) {
+                if (end > pos) break;
+                whole_arena = true;                      /* an over-long read: give it the whole arena, alone */
+            }
+            bytes += need; ev += (size_t)r.E; ++end;
+            const int32_t cnt = (int32_t)(end - pos);
+            if (whole_arena || (cnt >= want_reads && ev >= want_ev) || cnt >= S.opt.chunk_reads_max) break;
+        }
+        const int32_t m = (int32_t)(end - pos);
+        abea_host_slot& sl = *c->slots[(size_t)(whole_arena ? 0 : turn % n_slots)];
+        int rc;
+        if (whole_arena) { for (abea_host_slot* o : c->slots) if ((rc = slot_retire(S, *o))) return rc; }
+        else if ((rc = slot_retire(S, sl))) return rc;
+        uint8_t* arena = whole_arena ? c->arena : c->arena + (size_t)(turn % n_slots) * slot_arena;
+
+        /* ---- plan the chunk ---- */
+        double t0 = abea_now_ms();
+        S.log("plan", chunk_no, m, ev);
+        sl.chunk_no = chunk_no;
+        sl.m = m; sl.scaling = scaling; sl.device_pairs = S.device_pairs; sl.staged = false;
+        sl.rd.resize((size_t)m);
+        size_t n_read = 0, n_pair = 0, n_kmer = 0;
+        for (int32_t j = 0; j < m; ++j) {
+            const plan_read& r = S.reads[(size_t)order[pos + (size_t)j]];
+            n_read += align_up((size_t)r.L + 1, 16);
+            n_pair += (size_t)r.E + (size_t)r.L;
+            n_kmer += (size_t)r.K;
+        }
+        size_t n_evm_max = 0;
+        for (int32_t j = 0; j < m; ++j) n_evm_max += align_up((size_t)S.reads[(size_t)order[pos + (size_t)j]].E + 64, 4);
+        /* `up` = [desc][reads][evm], mirrored at the start of the chunk's arena share: one H2D copy */
+        const size_t u_desc = 0;
+        const size_t u_reads = align_up(u_desc + (size_t)m * sizeof(abea_read_desc), 256);
+        const size_t u_evm = align_up(u_reads + n_read, 256);
+        const size_t u_end = align_up(u_evm + n_evm_max * 4 + 512, 256);
+        if ((rc = ensure_pinned((void**)&sl.up, &sl.up_cap, u_end))) return rc;
+        abea_read_desc* descs = (abea_read_desc*)(sl.up + u_desc);
+        sub_layout lay;
+        {
+            size_t ro = 0, po = 0, ko = 0;
+            for (int32_t j = 0; j < m; ++j) {
+                plan_read r = S.reads[(size_t)order[pos + (size_t)j]];
+                sl.rd[(size_t)j] = r.idx;
+                const int32_t caller = r.idx;
+                r.idx = j;                                 /* out_idx = position in the chunk */
+                plan_desc(descs[j], r, H->scalings[caller], lay, S.st);
+                descs[j].read_off = (int64_t)ro; ro += align_up((size_t)r.L + 1, 16);
+                descs[j].pair_off = (int64_t)po; po += (size_t)r.E + (size_t)r.L;
+                descs[j].kmer_off = (int64_t)ko; ko += (size_t)r.K;
+            }
+        }
+        /* `dn` = [npairs][diag][codes | poff, cursor][scaling outputs] mirrors the arena block behind the scratch */
+        size_t o = 0;
+        sl.o_np = o;      o = align_up(o + (size_t)m * 4, 256);
+        sl.o_diag = o;    o = align_up(o + (size_t)m * sizeof(abea_read_diag), 256);
+        sl.o_codes = o;   if (!S.device_pairs && S.want_pairs) o = align_up(o + lay.n_code * 4, 256);
+        sl.o_poff = o;    if (S.device_pairs) o = align_up(o + (size_t)m * 8, 256);
+        sl.o_cursor = o;  if (S.device_pairs) o = align_up(o + 8, 256);
+        sl.o_b2e = o;     if (scaling) o = align_up(o + n_kmer * sizeof(abea_index_pair_t), 256);
+        sl.o_sc = o;      if (scaling) o = align_up(o + (size_t)m * sizeof(abea_scalings_t), 256);
+        sl.o_epb = o;     if (scaling) o = align_up(o + (size_t)m * 8, 256);
+        sl.o_flag = o;    if (scaling) o = align_up(o + (size_t)m * 4, 256);
+        sl.o_nal = o;     if (scaling) o = align_up(o + (size_t)m * 4, 256);
+        const size_t dn_copy = o;                         /* one D2H copy of [0, dn_copy) */
+        sl.o_pairs = o;   if (S.device_pairs) o = align_up(o + n_pair * sizeof(abea_pair_t), 256);
+        if ((rc = ensure_pinned((void**)&sl.dn, &sl.dn_cap, o))) return rc;
+
+        /* ---- arena: [up block][kpar][trace][codes* ...] ; the dn block is contiguous on the device too ---- */
+        uint8_t* p = arena;
+        uint8_t* d_up = p;                                  p += u_end;
+        abea_kpar_t* d_kpar = (abea_kpar_t*)p;              p += align_up(lay.n_kpar * sizeof(abea_kpar_t), 256);
+        uint4* d_trace = (uint4*)p;                         p += align_up(lay.n_trace * sizeof(uint4), 256);
+        uint8_t* d_dn = p;                                  p += dn_copy;
+        uint32_t* d_codes_scratch = nullptr;                /* codes stay on the device when nobody wants them */
+        if (S.device_pairs || !S.want_pairs) { d_codes_scratch = (uint32_t*)p; p += align_up(lay.n_code * 4, 256); }
+        abea_pair_t* d_pairs = nullptr;
+        if (pairs_on_device) { d_pairs = (abea_pair_t*)p; p += align_up(n_pair * sizeof(abea_pair_t), 256); }
+        if ((size_t)(p - arena) > (whole_arena ? c->arena_bytes : slot_arena))
+            return abea_fail(ABEA_ENOMEM, "internal: chunk layout %zu exceeds its arena share %zu", (size_t)(p - arena),
+                             whole_arena ? c->arena_bytes : slot_arena);
+        const abea_read_desc* d_desc = (const abea_read_desc*)(d_up + u_desc);
+        const char* d_reads = (const char*)(d_up + u_reads);
+        float* d_evm = (float*)(d_up + u_evm);
+        int32_t* d_np = (int32_t*)(d_dn + sl.o_np);
+        abea_read_diag* d_diag = (abea_read_diag*)(d_dn + sl.o_diag);
+        uint32_t* d_codes = d_codes_scratch ? d_codes_scratch : (uint32_t*)(d_dn + sl.o_codes);
+        int64_t* d_poff = (int64_t*)(d_dn + sl.o_poff);
+        unsigned long long* d_cursor = (unsigned long long*)(d_dn + sl.o_cursor);
+        sl.d_pairs = d_pairs; sl.pair_cap = n_pair;
+
+        /* ---- flatten (the role of f5c.cu:744-802, which runs on one thread) ---- */
+        char* h_reads = (char*)(sl.up + u_reads);
+        float* h_evm = (float*)(sl.up + u_evm);
+        S.log("flatten", chunk_no);
+        c->pool->run(m, 1, [&](int64_t lo, int64_t hi) {
+            for (int64_t j = lo; j < hi; ++j) {
+                const abea_read_desc& d = descs[j];
+                const int32_t i = sl.rd[(size_t)j];
+                const size_t L = (size_t)d.read_len;
+                memcpy(h_reads + d.read_off, H->read[i], L);
+                h_reads[d.read_off + (int64_t)L] = '\0';
+                /* event means: 4 of event_t's 24 bytes; non-temporal stores (the staging block is written once and
+                 * read by the DMA engine only; dst is 16-byte aligned: evm_off is a multiple of 4 floats) */
+                const abea_event_t* evs = H->events[i];
+                float* dst = h_evm + d.evm_off;
+                const int32_t E = d.n_events;
+                int32_t e = 0;
+                for (; e + 4 <= E; e += 4)
+                    _mm_stream_ps(dst + e, _mm_set_ps(evs[e + 3].mean, evs[e + 2].mean, evs[e + 1].mean, evs[e].mean));
+                for (; e < E; ++e) dst[e] = evs[e].mean;
+            }
+            _mm_sfence();
+        });
+        S.st.flatten_ms += abea_now_ms() - t0;
+        S.log("enqueue", chunk_no);
+
+        /* ---- copy up, run, copy down ---- */
+        HIP_TRY(hipMemcpyAsync(d_up, sl.up, u_evm + lay.n_evm * 4, hipMemcpyHostToDevice, sl.stream));
+        S.st.h2d_bytes += u_evm + lay.n_evm * 4;
+        if (S.device_pairs) HIP_TRY(hipMemsetAsync(d_cursor, 0, 8, sl.stream));
+        if (scaling) {
+            abea_scalings_t* h_sc = (abea_scalings_t*)(sl.dn + sl.o_sc);
+            int32_t* h_flag = (int32_t*)(sl.dn + sl.o_flag);
+            for (int32_t j = 0; j < m; ++j) {
+                h_sc[j] = H->scalings[sl.rd[(size_t)j]];
+                h_flag[j] = H->read_stat_flag ? H->read_stat_flag[sl.rd[(size_t)j]] : 0;
+            }
+            HIP_TRY(hipMemcpyAsync(d_dn + sl.o_sc, h_sc, (size_t)m * sizeof(abea_scalings_t), hipMemcpyHostToDevice, sl.stream));
+            HIP_TRY(hipMemcpyAsync(d_dn + sl.o_flag, h_flag, (size_t)m * 4, hipMemcpyHostToDevice, sl.stream));
+            HIP_TRY(hipMemsetAsync(d_dn + sl.o_b2e, 0xFF, n_kmer * sizeof(abea_index_pair_t), sl.stream));   /* {-1,-1}: align.c:566-569 */
+        }
+        HIP_TRY(hipEventRecord(sl.k0, sl.stream));
+        hipLaunchKernelGGL(abea_pre_kernel, dim3((unsigned)m), dim3(256), 0, sl.stream,
+                           d_desc, d_reads, (const abea_event_t*)nullptr, c->d_model, (int)c->k, d_kpar, d_evm);
+        HIP_TRY(hipEventRecord(sl.k1, sl.stream));
+        hipLaunchKernelGGL(abea_align_kernel, dim3((unsigned)m), dim3(64), 0, sl.stream,
+                           d_desc, d_evm, d_kpar, d_trace, d_codes, d_pairs, d_np, d_diag,
+                           S.device_pairs ? d_cursor : (unsigned long long*)nullptr, S.device_pairs ? d_poff : (int64_t*)nullptr);
+        HIP_TRY(hipEventRecord(sl.k2, sl.stream));
+        if (scaling) {
+            hipLaunchKernelGGL(abea_scaling_kernel, dim3((unsigned)m), dim3(64), 0, sl.stream,
+                               d_desc, d_reads, c->d_model, (int)c->k, d_evm, d_pairs, d_np,
+                               (abea_index_pair_t*)(d_dn + sl.o_b2e), (abea_scalings_t*)(d_dn + sl.o_sc),
+                               (double*)(d_dn + sl.o_epb), (int32_t*)(d_dn + sl.o_flag), (int32_t*)(d_dn + sl.o_nal), min_rescale);
+            HIP_TRY(hipEventRecord(sl.k3, sl.stream));
+        }
+        /* the result block goes down by a kernel, not by an SDMA copy: a copy queued behind the alignment kernel would
+         * hold its SDMA ring until that kernel ends and stall the next chunks' H2D copies (abea_copy_out_kernel) */
+        if (S.opt.sdma_d2h) HIP_TRY(hipMemcpyAsync(sl.dn, d_dn, dn_copy, hipMemcpyDeviceToHost, sl.stream));
+        else hipLaunchKernelGGL(abea_copy_out_kernel, dim3((unsigned)std::min<size_t>(512, (dn_copy / 16 + 255) / 256)), dim3(256), 0,
+                                sl.stream, (const uint4*)d_dn, (uint4*)sl.dn, dn_copy / 16);
+        HIP_TRY(hipGetLastError());
+        S.st.d2h_bytes += dn_copy;
+        if (S.device_pairs) HIP_TRY(hipEventRecord(sl.kdone, sl.stream));       /* the pair copy follows at stage A */
+        else HIP_TRY(hipEventRecord(sl.done, sl.stream));
+        sl.busy = true;
+        S.log("enqueued", chunk_no);
+        S.st.n_sub_batches += 1; S.st.fill_launches += 1;
+        if (whole_arena) { if ((rc = slot_retire(S, sl))) return rc; }
+        else ++turn;
+        pos = end; ++chunk_no;
+        for (abea_host_slot* o2 : c->slots) if ((rc = slot_stage(S, *o2, false))) return rc;
+    }
+    /* ---- drain, oldest chunk first ---- */
+    for (int q = 0; q < n_slots; ++q) {
+        int rc = slot_retire(S, *c->slots[(size_t)((turn + q) % n_slots)]);
+        if (rc) return rc;
+    }
+    S.st.host_ms = S.st.flatten_ms + S.st.unflatten_ms;
+    S.st.total_ms = abea_now_ms() - t_start;
+    *st_out = S.st;
+    return ABEA_OK;
+}
+
+/* ------------------------------------------------------------------ multi-device split */
+/* Longest-processing-time-first on the band count E + K (f5c_amd/synth.py shard_batch is the same rule):
+ * reads in descending weight go to the currently lightest device; ties by lowest device index.  `weight[i] <= 0`
+ * reads (guard failures) are dealt round-robin: they cost nothing. */
+extern "C" int abea_lpt_split(const int64_t* weight, int32_t n, int32_t n_bins, int32_t* bin_of) {
+    if (!weight || !bin_of || n < 0 || n_bins < 1) return abea_fail(ABEA_EINVAL, "abea_lpt_split: bad argument");
+    std::vector<int32_t> order((size_t)n);
+    for (int32_t i = 0; i < n; ++i) order[(size_t)i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return weight[a] > weight[b]; });
+    typedef std::pair<int64_t, int32_t> item;                 /* (load, bin): smallest load first, then lowest bin */
+    std::priority_queue<item, std::vector<item>, std::greater<item>> heap;
+    for (int32_t b = 0; b < n_bins; ++b) heap.push(item(0, b));
+    for (int32_t i : order) {
+        item t = heap.top(); heap.pop();
+        bin_of[i] = t.second;
+        heap.push(item(t.first + std::max<int64_t>(weight[i], 0), t.second));
+    }
+    return ABEA_OK;
+}
+
+static void stats_add(abea_stats& a, const abea_stats& b) {
+    /* kernel / host times: the devices work at the same time, the batch waits for the slowest */
+    a.pre_ms = std::max(a.pre_ms, b.pre_ms); a.fill_ms = std::max(a.fill_ms, b.fill_ms); a.trace_ms = std::max(a.trace_ms, b.trace_ms);
+    a.host_ms = std::max(a.host_ms, b.host_ms); a.flatten_ms = std::max(a.flatten_ms, b.flatten_ms);
+    a.unflatten_ms = std::max(a.unflatten_ms, b.unflatten_ms); a.wait_ms = std::max(a.wait_ms, b.wait_ms);
+    a.n_reads_gpu += b.n_reads_gpu; a.n_reads_skipped += b.n_reads_skipped; a.n_sub_batches += b.n_sub_batches;
+    a.sum_events += b.sum_events; a.sum_bands += b.sum_bands; a.sum_pairs += b.sum_pairs; a.fill_launches += b.fill_launches;
+    a.arena_bytes += b.arena_bytes; a.bytes_ref += b.bytes_ref; a.bytes_min += b.bytes_min; a.bytes_moved += b.bytes_moved;
+    a.h2d_bytes += b.h2d_bytes; a.d2h_bytes += b.d2h_bytes; a.host_threads += b.host_threads;
+}
+
+extern "C" int abea_align_batch_host(abea_ctx* c, const abea_host_batch* H) {
+    if (!c || !H) return abea_fail(ABEA_EINVAL, "null argument");
+    const int32_t n = H->n_reads;
+    if (n < 0) return abea_fail(ABEA_EINVAL, "n_reads < 0");
+    if (n == 0) { memset(&c->stats, 0, sizeof c->stats); return ABEA_OK; }
+    if (!H->read || !H->read_len || !H->events || !H->n_events || !H->scalings || !H->n_pairs)
+        return abea_fail(ABEA_EINVAL, "abea_align_batch_host: null array");
+    if (!H->pairs && !H->base_to_event_map)
+        return abea_fail(ABEA_EINVAL, "abea_align_batch_host: neither pairs nor base_to_event_map requested");
+    const double t_start = abea_now_ms();
+    /* leave two of the CPUs this process may use to the HIP runtime's own threads: under a cgroup CPU quota a pool as
+     * wide as the quota gets the whole process throttled (measured on the GPU box) */
+    const int cpus = effective_cpus();
+    int threads = std::min(16, cpus > 4 ? cpus - 2 : cpus);
+    if (const char* e = getenv("ABEA_HOST_THREADS")) threads = std::max(1, atoi(e));
+    if (c->children.empty()) {
+        abea_stats st;
+        const int rc = host_run(c, H, nullptr, n, threads, &st);
+        if (rc) return rc;
+        c->stats = st;
+        return ABEA_OK;
+    }
+    /* ---- several devices: LPT split, one host thread (and its share of the workers) per device ---- */
+    const int32_t nd = (int32_t)c->children.size();
+    std::vector<int64_t> weight((size_t)n);
+    for (int32_t i = 0; i < n; ++i) {
+        const bool good = (!H->n_samples || H->n_samples[i] > 0) && H->read_len[i] > 0 && H->n_events[i] > 0 &&
+                          H->n_events[i] < (uint64_t)INT32_MAX;
+        const plan_read r = make_plan(i, good ? H->read_len[i] : 0, good ? (int32_t)H->n_events[i] : 0, c->k);
+        weight[(size_t)i] = r.run ? r.n_bands : 0;
+    }
+    std::vector<int32_t> bin_of((size_t)n);
+    int rc = abea_lpt_split(weight.data(), n, nd, bin_of.data());
+    if (rc) return rc;
+    std::vector<std::vector<int32_t>> share((size_t)nd);
+    for (int32_t i = 0; i < n; ++i) share[(size_t)bin_of[(size_t)i]].push_back(i);
+    std::vector<int> rcs((size_t)nd, ABEA_OK);
+    std::vector<abea_stats> sts((size_t)nd);
+    std::vector<std::string> errs((size_t)nd);
+    const int per_dev = std::max(1, threads / nd);
+    std::vector<std::thread> th;
+    for (int32_t d = 0; d < nd; ++d)
+        th.emplace_back([&, d]() {
+            memset(&sts[(size_t)d], 0, sizeof(abea_stats));
+            rcs[(size_t)d] = host_run(c->children[(size_t)d], H, share[(size_t)d].data(), (int32_t)share[(size_t)d].size(),
+                                      per_dev, &sts[(size_t)d]);
+            if (rcs[(size_t)d]) errs[(size_t)d] = abea_last_error();       /* the message is thread-local */
+        });
+    for (auto& t : th) t.join();
+    abea_stats st; memset(&st, 0, sizeof st);
+    for (int32_t d = 0; d < nd; ++d) {
+        if (rcs[(size_t)d]) return abea_fail(rcs[(size_t)d], "device %d: %s", c->children[(size_t)d]->device, errs[(size_t)d].c_str());
+        c->children[(size_t)d]->stats = sts[(size_t)d];
+        stats_add(st, sts[(size_t)d]);
+    }
+    st.n_devices = nd;
+    st.total_ms = abea_now_ms() - t_start;
+    c->stats = st;
+    return ABEA_OK;
+}
+
+/* per-device statistics of the last host batch of a multi-device context (device = index into device_ids) */
+extern "C" int abea_get_device_stats(abea_ctx* c, int32_t device, abea_stats* out) {
+    if (!c || !out) return abea_fail(ABEA_EINVAL, "null argument");
+    if (c->children.empty()) { if (device != 0) return abea_fail(ABEA_EINVAL, "device %d of 1", device); *out = c->stats; return ABEA_OK; }
+    if (device < 0 || device >= (int32_t)c->children.size()) return abea_fail(ABEA_EINVAL, "device %d of %zu", device, c->children.size());
+    *out = c->children[(size_t)device]->stats;
+    return ABEA_OK;
+}

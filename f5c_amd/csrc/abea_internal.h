@@ -1,0 +1,103 @@
+/* abea_internal.h — shared between the host translation units of libabea_hip.so (abea_capi.cpp: context, device
+ * entry, event detection; abea_host.cpp: the host-buffer pipeline and the multi-device dispatch).  Internal. */
+#ifndef ABEA_INTERNAL_H
+#define ABEA_INTERNAL_H
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include "abea_device.h"
+
+extern "C" {
+__global__ void abea_selftest_kernel(int* out);
+__global__ void abea_pre_kernel(const abea_read_desc*, const char*, const abea_event_t*, const abea_model_t*, int,
+                                abea_kpar_t*, float*);
+__global__ void abea_scaling_kernel(const abea_read_desc*, const char*, const abea_model_t*, int, const float*,
+                                    const abea_pair_t*, const int32_t*, abea_index_pair_t*, abea_scalings_t*, double*,
+                                    int32_t*, int32_t*, int);
+__global__ void abea_align_kernel(const abea_read_desc*, const float*, const abea_kpar_t*, uint4*, uint32_t*,
+                                  abea_pair_t*, int32_t*, abea_read_diag*, unsigned long long*, int64_t*);
+__global__ void abea_copy_out_kernel(const uint4*, uint4*, size_t);
+}
+
+/* ------------------------------------------------------------------ errors */
+int abea_fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+#define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) \
+    return abea_fail(ABEA_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
+
+static inline double abea_now_ms() {
+    using namespace std::chrono;
+    return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+/* ------------------------------------------------------------------ context */
+struct abea_host_pool;      /* abea_host.cpp: persistent host worker threads */
+struct abea_host_slot;      /* abea_host.cpp: one chunk in flight (stream, pinned staging, arena share) */
+
+struct abea_ctx {
+    int device = 0;
+    int n_cu = 0;
+    char arch[64] = {0};
+    uint32_t k = 0;
+    int verbosity = 0;
+    hipStream_t stream = nullptr;
+    abea_model_t* d_model = nullptr;
+    uint8_t* arena = nullptr;      size_t arena_bytes = 0;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    /* pinned staging for descriptors (device entry, event detection) */
+    abea_read_desc* h_desc = nullptr; size_t h_desc_cap = 0;
+    /* host-buffer entry (abea_host.cpp), created on first use */
+    abea_host_pool* pool = nullptr;
+    std::vector<abea_host_slot*> slots;
+    /* abea_init_multi: a parent context owns one child per device and no device state of its own */
+    std::vector<abea_ctx*> children;
+    abea_stats stats;
+};
+
+void abea_host_release(abea_ctx* c);       /* frees pool + slots (abea_host.cpp); called by abea_free */
+
+/* ------------------------------------------------------------------ batch planning */
+struct plan_read {
+    int32_t idx;          /* index in the caller's batch */
+    int32_t L, E, K;
+    int64_t n_bands;
+    bool run;
+};
+
+/* the kernels address the trace with 32-bit byte offsets (32 B per band): 2^27 bands = a read of ~40 Mbases */
+static const int64_t ABEA_MAX_BANDS = (int64_t)1 << 27;
+
+/* the align_single guard (f5c.c:813-814, E/L < 15.0f in float); reads shorter than k are UB in the reference
+ * (size_t underflow, align.c:191) and rejected here */
+static inline plan_read make_plan(int32_t idx, int32_t L, int32_t E, uint32_t k) {
+    plan_read r;
+    r.idx = idx; r.L = L; r.E = E;
+    r.K = L - (int32_t)k + 1;
+    r.run = E > 0 && r.K >= 1 && ((float)E / (float)L) < 15.0f;
+    r.n_bands = (int64_t)E + r.K + 2;
+    return r;
+}
+
+/* per-read scratch bytes (kpar, evm, codes, trace, desc) */
+static inline size_t scratch_bytes(const plan_read& r) {
+    const size_t n_groups = (size_t)(r.n_bands + ABEA_GROUP - 1) / ABEA_GROUP;
+    return align_up((size_t)r.K * sizeof(abea_kpar_t), 16) + align_up((size_t)r.E * 4 + 256, 16) +
+           align_up(((size_t)(r.E + r.K) / 16 + 2) * 4, 16) + n_groups * 64 * sizeof(uint4) +
+           sizeof(abea_read_desc);
+}
+
+/* element counts of one launch's scratch arrays */
+struct sub_layout { size_t n_kpar = 0, n_evm = 0, n_code = 0, n_trace = 0; };
+
+/* Descriptor of one read and its place in the launch's scratch; the caller sets read_off/event_off/pair_off/kmer_off. */
+void plan_desc(abea_read_desc& d, const plan_read& r, const abea_scalings_t& sc, sub_layout& lay, abea_stats& st);
+
+int ensure_pinned(void** p, size_t* cap, size_t need);
+
+#endif

@@ -184,7 +184,11 @@ void abea_align_kernel(const abea_read_desc* __restrict__ descs,
                        const float* __restrict__ evm_all, const abea_kpar_t* __restrict__ kpar_all,
                        uint4* __restrict__ trace_all, uint32_t* __restrict__ codes_all,
                        abea_pair_t* __restrict__ pairs_all, int32_t* __restrict__ n_pairs,
-                       abea_read_diag* __restrict__ diag) {
+                       abea_read_diag* __restrict__ diag,
+                       unsigned long long* __restrict__ pair_cursor, int64_t* __restrict__ pair_off_out) {
+    /* pairs_all == nullptr: the pair lists are not materialised on the device (the host entry expands them from the
+     * walk codes).  pair_cursor != nullptr: pair lists are packed back to back in completion order (atomic bump
+     * allocation of n entries per read, offset reported in pair_off_out[]) instead of at desc.pair_off. */
     __shared__ uint4 smem[256];                        /* 4 KiB: phase 1 rings, phase 3 emission buffer */
     abea_kpar_t* const k_ring = reinterpret_cast<abea_kpar_t*>(smem);        /* 128 x 16 B */
     float* const e_ring = reinterpret_cast<float*>(smem + 128);              /* 128 x 4 B  */
@@ -458,7 +462,6 @@ void abea_align_kernel(const abea_read_desc* __restrict__ descs,
         return;
     }
     uint32_t* codes = codes_all + d->code_off;
-    abea_pair_t* pairs = pairs_all + d->pair_off;
 
     /* align.c:452-499, wave-uniform, on the scalar unit.  The trace of the current 32-band group sits
      * in 4 VGPRs (one uint4 per lane); the 128 bits of the lane pair the path is in are held in SGPRs,
@@ -539,6 +542,17 @@ void abea_align_kernel(const abea_read_desc* __restrict__ descs,
     /* ============================================================ phase 3: expansion + QC
      * prefix sums turn codes into (k,e) pairs written in forward order; log-emissions are summed in
      * walk order, in double (align.c:473-476) */
+    abea_pair_t* pairs = nullptr;
+    if (pairs_all) {
+        long long off = d->pair_off;
+        if (pair_cursor) {
+            unsigned long long o = 0;
+            if (lane == 0) o = atomicAdd(pair_cursor, (unsigned long long)n);
+            off = (long long)(((unsigned long long)(unsigned)uni((int)(o >> 32)) << 32) | (unsigned)uni((int)o));
+            if (lane == 0) pair_off_out[out_idx] = off;
+        }
+        pairs = pairs_all + off;
+    }
     double sum = 0.0;
     int base_k = K - 1, base_e = best_e;
     for (int c0 = 0; c0 < n; c0 += 1024) {
@@ -559,7 +573,7 @@ void abea_align_kernel(const abea_read_desc* __restrict__ descs,
             float lp = 0.f;
             if (j < cnt) {
                 abea_pair_t p; p.ref_pos = kk; p.read_pos = ee;
-                pairs[n - 1 - (i0 + j)] = p;
+                if (pairs) pairs[n - 1 - (i0 + j)] = p;
                 const abea_kpar_t kp = kpar[kk];
                 const float dx = __fsub_rn(evm[ee], kp.gpm);
                 const float a = (float)((double)dx * kp.istd);
@@ -595,6 +609,21 @@ void abea_align_kernel(const abea_read_desc* __restrict__ descs,
             diag[out_idx] = dg;
         }
     }
+}
+
+
+/* ================================================================ results -> pinned host memory
+ * The host pipeline's chunks return their (small) result block with this kernel instead of a hipMemcpyAsync: an SDMA
+ * copy queued behind a 20 ms alignment kernel blocks its SDMA ring for that long, and the H2D copies of the following
+ * chunks that land on the same ring start only when that kernel has finished (measured: profiles/r02_*).
+ * A kernel on the chunk's own stream has no such side effect.  16 bytes per lane, coalesced, straight over PCIe. */
+extern "C" __global__ __launch_bounds__(256)
+void abea_copy_out_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16) {
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4* s = reinterpret_cast<const u32x4*>(src);
+    u32x4* d = reinterpret_cast<u32x4*>(dst);
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x)
+        __builtin_nontemporal_store(s[i], d + i);
 }
 
 

@@ -2,6 +2,7 @@
  * Pure C++ (no HIP): everything device-side stays behind abea_*.  */
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 #include "../../include/abea_f5c_shim.h"
 
@@ -19,19 +20,22 @@ extern "C" void abea_f5c_init(abea_f5c_core* core) {
     cfg.verbosity = core->verbosity;
     cfg.reserved = 0;
     abea_ctx* ctx = nullptr;
-    if (abea_init(&ctx, &cfg) != ABEA_OK) SHIM_DIE("abea_init");
+    if (core->n_cuda_devs > 1 && core->cuda_dev_ids) {
+        if (abea_init_multi(&ctx, &cfg, core->cuda_dev_ids, core->n_cuda_devs) != ABEA_OK) SHIM_DIE("abea_init_multi");
+    } else if (abea_init(&ctx, &cfg) != ABEA_OK) SHIM_DIE("abea_init");
     core->cuda = ctx;
     core->align_kernel_time = core->align_pre_kernel_time = core->align_core_kernel_time = 0;
     core->align_post_kernel_time = core->align_cuda_memcpy = core->align_cuda_preprocess = 0;
     core->align_cuda_postprocess = core->align_cuda_total_kernel = 0;
 }
 
-extern "C" void abea_f5c_align(abea_f5c_core* core, abea_f5c_db* db) {
+static void shim_run(abea_f5c_core* core, abea_f5c_db* db, bool scale, const char* who) {
     const int32_t n = db->n_bam_rec;
     std::vector<const abea_event_t*> ev((size_t)n);
     std::vector<uint64_t> n_ev((size_t)n);
     for (int32_t i = 0; i < n; ++i) { ev[(size_t)i] = db->et[i].event; n_ev[(size_t)i] = db->et[i].n; }
     abea_host_batch hb;
+    memset(&hb, 0, sizeof hb);
     hb.n_reads = n;
     hb.read = db->read;
     hb.read_len = db->read_len;
@@ -42,22 +46,54 @@ extern "C" void abea_f5c_align(abea_f5c_core* core, abea_f5c_db* db) {
     hb.pairs = db->event_align_pairs;
     hb.n_pairs = db->n_event_align_pairs;
     hb.diag = nullptr;
-    if (abea_align_batch_host((abea_ctx*)core->cuda, &hb) != ABEA_OK) SHIM_DIE("abea_align_batch_host");
+    if (scale) {
+        /* scaling_single malloc()s base_to_event_map[i] for aligned reads (f5c.c:746); which reads align is known only
+         * afterwards, so every read that passes the guards gets one and the failed ones are released below */
+        for (int32_t i = 0; i < n; ++i) {
+            const int32_t nk = db->read_len[i] - (int32_t)core->kmer_size + 1;
+            const bool good = (!db->nsample || db->nsample[i] > 0) && nk > 0 && db->et[i].n > 0;
+            db->base_to_event_map[i] = good ? (abea_index_pair_t*)malloc(sizeof(abea_index_pair_t) * (size_t)nk) : nullptr;
+            if (good && !db->base_to_event_map[i]) { fprintf(stderr, "[%s::ERROR] malloc failed\n", who); exit(EXIT_FAILURE); }
+        }
+        hb.base_to_event_map = db->base_to_event_map;
+        hb.scalings_out = db->scalings;              /* recalibrated in place, like recalibrate_model(&db->scalings[i]) */
+        hb.events_per_base = db->events_per_base;
+        hb.read_stat_flag = db->read_stat_flag;
+        hb.n_event_alignment = db->n_event_alignment;
+        hb.min_num_events_to_rescale = core->min_num_events_to_rescale;
+    }
+    if (abea_align_batch_host((abea_ctx*)core->cuda, &hb) != ABEA_OK) {
+        fprintf(stderr, "[%s::ERROR]\033[1;31m abea_align_batch_host: %s\033[0m\n", who, abea_last_error());
+        exit(EXIT_FAILURE);
+    }
+    if (scale)
+        for (int32_t i = 0; i < n; ++i)
+            if (db->n_event_align_pairs[i] <= 0 && db->base_to_event_map[i]) { free(db->base_to_event_map[i]); db->base_to_event_map[i] = nullptr; }
     abea_stats st;
     abea_get_stats((abea_ctx*)core->cuda, &st);
-    /* the host entry pipelines chunks: align-pre is timed together with the fused kernel (fill_ms), and the copies
-     * overlap the kernels and the host loops, so pre / memcpy are reported as 0 and host_ms is split evenly */
+    /* the copies overlap the kernels and the host loops (h2d_ms / d2h_ms stay 0); flatten = the reference's
+     * "cpu preprocess", un-flatten = its "cpu postprocess" (meth_main.c:769,784) */
     core->align_pre_kernel_time += st.pre_ms * 1e-3;
     core->align_core_kernel_time += st.fill_ms * 1e-3;      /* fused fill + traceback */
-    core->align_post_kernel_time += st.trace_ms * 1e-3;
+    core->align_post_kernel_time += st.trace_ms * 1e-3;     /* scaling_single kernel, when fused */
     core->align_kernel_time += (st.pre_ms + st.fill_ms + st.trace_ms) * 1e-3;
     core->align_cuda_total_kernel += (st.pre_ms + st.fill_ms + st.trace_ms) * 1e-3;
     core->align_cuda_memcpy += (st.h2d_ms + st.d2h_ms) * 1e-3;
-    core->align_cuda_preprocess += st.host_ms * 0.5e-3;
-    core->align_cuda_postprocess += st.host_ms * 0.5e-3;
+    core->align_cuda_preprocess += st.flatten_ms * 1e-3;
+    core->align_cuda_postprocess += st.unflatten_ms * 1e-3;
     if (core->verbosity > 1)                                  /* f5c.cu:1052 "Load : CPU x entries, GPU y entries" */
-        fprintf(stderr, "[%s] Load : CPU 0 entries (0.0M bases), GPU %lld entries (%.1fM bases), %lld skipped by guards\n",
-                __func__, (long long)st.n_reads_gpu, (double)db->sum_bases / 1e6, (long long)st.n_reads_skipped);
+        fprintf(stderr, "[%s] Load : CPU 0 entries (0.0M bases), GPU %lld entries (%.1fM bases) on %d device(s), %lld skipped by guards\n",
+                who, (long long)st.n_reads_gpu, (double)db->sum_bases / 1e6, st.n_devices, (long long)st.n_reads_skipped);
+}
+
+extern "C" void abea_f5c_align(abea_f5c_core* core, abea_f5c_db* db) { shim_run(core, db, false, __func__); }
+
+extern "C" void abea_f5c_align_scale(abea_f5c_core* core, abea_f5c_db* db) {
+    if (!db->base_to_event_map || !db->events_per_base || !db->read_stat_flag || !db->n_event_alignment) {
+        fprintf(stderr, "[%s::ERROR] the db view lacks the scaling_single outputs\n", __func__);
+        exit(EXIT_FAILURE);
+    }
+    shim_run(core, db, true, __func__);
 }
 
 extern "C" void abea_f5c_free(abea_f5c_core* core) {

@@ -65,6 +65,15 @@ typedef struct {
 
 /* Replaces init_cuda(core_t*)   src/f5c.cu:23-202  (device select, model H2D, one-shot arena). */
 int  abea_init(abea_ctx** ctx, const abea_cfg* cfg);
+/* The same over several GPUs of one node (BASELINE north_star: "batches of reads shard embarrassingly across the 8
+ * GPUs of one node (per-GPU hipStreams ...)"; the reference has only --cuda-dev-id, one device per process,
+ * docs/f5c.1:271): a context that owns one device context per entry of device_ids.  abea_align_batch_host() then
+ * splits every batch over the devices (longest-processing-time-first on the band count E+K), one host
+ * thread and one set of streams per device, each writing straight into the caller's per-read buffers; no data crosses
+ * between devices.  cfg->device_id is ignored; a device may be listed twice (two contexts on one GPU).  The
+ * device-resident entries (abea_align_batch_device, abea_detect_events_device) need a single-device context. */
+int  abea_init_multi(abea_ctx** ctx, const abea_cfg* cfg, const int32_t* device_ids, int32_t n_devices);
+int32_t abea_device_count(abea_ctx* ctx);
 /* Replaces free_cuda(core_t*)   src/f5c.cu:204-234. */
 void abea_free(abea_ctx* ctx);
 /* Message of the last failure on the calling thread. */
@@ -79,12 +88,33 @@ typedef struct {
     const uint64_t* n_events;              /* db->et[i].n */
     const abea_scalings_t* scalings;       /* db->scalings[i] (scale, shift used) */
     const int64_t* n_samples;              /* db->sig[i]->nsample ; NULL = all reads good */
-    abea_pair_t* const* pairs;             /* db->event_align_pairs[i], caller-allocated, capacity n_events+read_len (f5c.c:724) */
+    abea_pair_t* const* pairs;             /* db->event_align_pairs[i], caller-allocated, capacity n_events+read_len (f5c.c:724);
+                                              may be NULL when base_to_event_map is given (pair lists stay on the device) */
     int32_t* n_pairs;                      /* db->n_event_align_pairs[i] */
     abea_read_diag* diag;                  /* optional [n_reads], may be NULL */
+    /* ---- optional: scaling_db() fused behind the alignment (src/f5c.c:736-807 scaling_single = postalign +
+     *      recalibrate_model, src/align.c:561-773; row N1).  The pair lists have no other consumer in process_db
+     *      (src/f5c.c:907-960: align_db, then pthread_db(scaling_single), then meth_single reads only base_to_event_map / scalings / events_per_base), so with pairs == NULL only 8 B per k-mer come back instead of 8 B per pair.
+     *      All NULL = alignment only. ---- */
+    abea_index_pair_t* const* base_to_event_map;   /* db->base_to_event_map[i]: caller-allocated, read_len-k+1 entries;
+                                                      written only for reads with n_pairs > 0 (the reference leaves NULL otherwise) */
+    abea_scalings_t* scalings_out;         /* [n_reads] db->scalings[i] after recalibration (input copied when not recalibrated;
+                                              log_var untouched) ; may alias `scalings` */
+    double*  events_per_base;              /* [n_reads] db->events_per_base[i] */
+    int32_t* read_stat_flag;               /* [n_reads] in/out: ABEA_FAILED_* bits OR-ed in (src/f5c.h:66-68) */
+    int32_t* n_event_alignment;            /* [n_reads] db->n_event_alignment[i] */
+    int32_t  min_num_events_to_rescale;    /* opt.min_num_events_to_rescale; 0 -> 200 */
+    int32_t  reserved;
 } abea_host_batch;
 
-/* Replaces align_cuda(core_t*, db_t*)  src/f5c.cu:647-1061 : flatten + H2D + kernels + D2H. */
+/* Replaces align_cuda(core_t*, db_t*)  src/f5c.cu:647-1061 : flatten + H2D + kernels + D2H.
+ * The batch is cut into chunks of reads, longest reads first; chunks rotate through a few stream slots so that the host
+ * loops (flatten: event means + sequences into pinned memory; un-flatten: results into the caller's per-read buffers),
+ * both PCIe directions and the kernels of neighbouring chunks overlap.  What crosses PCIe downwards is the traceback
+ * walk itself, 2 bits per step; the (k-mer, event) pairs are expanded from it on the host straight into
+ * db->event_align_pairs[i] (the role of the reversal loop at f5c.cu:1003-1030).  ABEA_HOST_PAIRS=device in the
+ * environment moves the expansion back to the GPU (pair lists compacted on the device, then copied down).
+ * Results do not depend on the chunking, the mode or the number of devices. */
 int abea_align_batch_host(abea_ctx* ctx, const abea_host_batch* batch);
 
 /* ---- device-resident flattened batch: the layout of the reference's device arrays (src/f5c.cu:672-690) ---- */
@@ -170,8 +200,20 @@ typedef struct {
     uint64_t bytes_ref;                   /* algorithmic bytes A_ref of the reads run */
     uint64_t bytes_min;                   /* strict floor A_min */
     uint64_t bytes_moved;                 /* bytes this implementation reads+writes in HBM by construction */
+    /* host batch only */
+    double flatten_ms, unflatten_ms;      /* wall time of the two host loops (they overlap the copies and kernels) */
+    double wait_ms;                       /* time the calling thread spent waiting for the GPU */
+    uint64_t h2d_bytes, d2h_bytes;        /* PCIe traffic of the call */
+    int32_t n_devices, host_threads;
 } abea_stats;
 int abea_get_stats(abea_ctx* ctx, abea_stats* out);
+/* Multi-device context: the share of the last host batch that ran on device_ids[device]; abea_get_stats() gives the
+ * whole batch (counts summed, times = the slowest device). */
+int abea_get_device_stats(abea_ctx* ctx, int32_t device, abea_stats* out);
+/* The split abea_align_batch_host() applies on a multi-device context, exposed for callers that shard themselves
+ * (one process per GPU): reads in descending weight (band count n_events + n_kmers + 2; <= 0 for reads the guards skip)
+ * go to the currently lightest of n_bins bins, ties to the lowest bin.  Host-only, needs no context. */
+int abea_lpt_split(const int64_t* weight, int32_t n, int32_t n_bins, int32_t* bin_of);
 
 /* Library / device introspection: "gfx950", CU count; used by tests to assert the native path ran. */
 int abea_device_info(abea_ctx* ctx, char* arch, size_t arch_len, int32_t* n_cu, uint64_t* arena_bytes);

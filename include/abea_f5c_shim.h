@@ -31,6 +31,12 @@ typedef struct {                       /* the slice of core_t used by init_cuda/
     /* timing accumulators, seconds, same meaning as core_t's (f5c.h:457-466) */
     double align_kernel_time, align_pre_kernel_time, align_core_kernel_time, align_post_kernel_time;
     double align_cuda_memcpy, align_cuda_preprocess, align_cuda_postprocess, align_cuda_total_kernel;
+    /* one process, several GPUs (the reference has only --cuda-dev-id, one device per process, docs/f5c.1:271):
+     * n_cuda_devs > 1 makes abea_f5c_init build a multi-device context over cuda_dev_ids[] and every batch is
+     * split over them inside abea_f5c_align; 0 = the single device cuda_dev_id */
+    const int32_t* cuda_dev_ids;
+    int32_t n_cuda_devs;
+    int32_t min_num_events_to_rescale; /* core->opt.min_num_events_to_rescale (abea_f5c_align_scale only) */
 } abea_f5c_core;
 
 typedef struct {                       /* the slice of db_t align_cuda reads/writes, src/f5c.h:290-352 */
@@ -43,10 +49,19 @@ typedef struct {                       /* the slice of db_t align_cuda reads/wri
     abea_pair_t** event_align_pairs;   /* db->event_align_pairs (caller-allocated, f5c.c:724) */
     int32_t* n_event_align_pairs;      /* db->n_event_align_pairs */
     int64_t sum_bases;                 /* db->sum_bases (statistics only) */
+    /* abea_f5c_align_scale only: what scaling_single writes (f5c.c:736-807) */
+    abea_index_pair_t** base_to_event_map; /* db->base_to_event_map: entry i is malloc()ed here when read i aligned, NULL otherwise */
+    double* events_per_base;           /* db->events_per_base */
+    int32_t* read_stat_flag;           /* db->read_stat_flag (FAILED_* bits are OR-ed in) */
+    int32_t* n_event_alignment;        /* db->n_event_alignment */
 } abea_f5c_db;
 
 void abea_f5c_init(abea_f5c_core* core);
 void abea_f5c_align(abea_f5c_core* core, abea_f5c_db* db);
+/* align_db() + pthread_db(scaling_single) in one call (process_db, f5c.c:924-936): the pair lists stay on the device,
+ * base_to_event_map / recalibrated db->scalings / events_per_base / read_stat_flag come back.  db->event_align_pairs
+ * may be NULL (or given, then it is filled as well, e.g. for --print-banded-aln). */
+void abea_f5c_align_scale(abea_f5c_core* core, abea_f5c_db* db);
 void abea_f5c_free(abea_f5c_core* core);
 
 #ifdef __cplusplus

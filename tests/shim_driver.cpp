@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <vector>
+#include <chrono>
 #include "../include/abea_f5c_shim.h"
 
 static std::vector<char> slurp(const char* path) {
@@ -48,12 +49,42 @@ int main(int argc, char** argv) {
     }
     db.read = read.data(); db.read_len = read_len.data(); db.nsample = nullptr; db.et = et.data();
     db.scalings = sc.data(); db.event_align_pairs = pairs.data(); db.n_event_align_pairs = n_pairs.data();
+    /* test knobs: SHIM_NSAMPLE0 = reads whose db->sig[i]->nsample is 0 (bad reads, f5c.c:826-828); SHIM_DEVS = device
+     * list for one multi-GPU context; SHIM_FUSED = align_db + scaling_db in one call */
+    std::vector<int64_t> nsample(n, 4000);
+    if (const char* e = getenv("SHIM_NSAMPLE0")) {
+        for (const char* q = e; *q;) { nsample[(size_t)strtol(q, (char**)&q, 10)] = 0; if (*q == ',') ++q; }
+        db.nsample = nsample.data();
+    }
+    std::vector<int32_t> devs;
+    if (const char* e = getenv("SHIM_DEVS"))
+        for (const char* q = e; *q;) { devs.push_back((int32_t)strtol(q, (char**)&q, 10)); if (*q == ',') ++q; }
+    const bool fused = getenv("SHIM_FUSED") != nullptr;
+    std::vector<abea_index_pair_t*> b2e(n, nullptr); std::vector<double> epb(n, 0.0);
+    std::vector<int32_t> flag(n, 0), nal(n, 0);
+    std::vector<abea_scalings_t> sc0 = sc;
+    db.base_to_event_map = b2e.data(); db.events_per_base = epb.data(); db.read_stat_flag = flag.data();
+    db.n_event_alignment = nal.data();
 
     abea_f5c_core core; memset(&core, 0, sizeof core);
     core.model = model; core.kmer_size = k; core.cuda_dev_id = 0; core.cuda_mem_frac = 0.2f; core.verbosity = 2;
+    core.cuda_dev_ids = devs.data(); core.n_cuda_devs = (int32_t)devs.size();
     abea_f5c_init(&core);
-    abea_f5c_align(&core, &db);
-    abea_f5c_align(&core, &db);                              /* a second batch through the same context */
+    if (fused) {
+        abea_f5c_align_scale(&core, &db);
+        for (int32_t i = 0; i < n; ++i) { free(b2e[i]); b2e[i] = nullptr; flag[i] = 0; }
+        sc = sc0; db.scalings = sc.data();
+        abea_f5c_align_scale(&core, &db);                    /* a second batch through the same context */
+    } else {
+        abea_f5c_align(&core, &db);
+        const int reps = getenv("SHIM_REPS") ? atoi(getenv("SHIM_REPS")) : 1;   /* more batches through the same context */
+        for (int r = 0; r < reps; ++r) {
+            const auto t0 = std::chrono::steady_clock::now();
+            abea_f5c_align(&core, &db);
+            if (getenv("SHIM_REPS"))
+                fprintf(stderr, "abea_f5c_align wall %.2f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+        }
+    }
     FILE* out = fopen(argv[2], "w");
     for (int32_t i = 0; i < n; ++i) {
         fprintf(out, "%d\t", i);
@@ -61,8 +92,19 @@ int main(int argc, char** argv) {
         fprintf(out, "\n");
     }
     fclose(out);
+    if (fused) {                                             /* "<i> flag n_alignment events_per_base shift scale var | start,stop ..." */
+        char path[4096]; snprintf(path, sizeof path, "%s.scale", argv[2]);
+        FILE* f = fopen(path, "w");
+        for (int32_t i = 0; i < n; ++i) {
+            fprintf(f, "%d\t%d\t%d\t%a\t%a\t%a\t%a\t", i, flag[i], nal[i], epb[i], (double)sc[i].shift, (double)sc[i].scale, (double)sc[i].var);
+            if (b2e[i]) for (int32_t j = 0; j < read_len[i] - (int32_t)k + 1; ++j) fprintf(f, "%d,%d ", b2e[i][j].start, b2e[i][j].stop);
+            else fprintf(f, "NULL");
+            fprintf(f, "\n");
+        }
+        fclose(f);
+    }
     fprintf(stderr, "kernel time %.3f ms, memcpy %.3f ms\n", core.align_kernel_time * 1e3 / 2, core.align_cuda_memcpy * 1e3 / 2);
     abea_f5c_free(&core);
-    for (int32_t i = 0; i < n; ++i) { free(read[i]); free(et[i].event); free(pairs[i]); }
+    for (int32_t i = 0; i < n; ++i) { free(read[i]); free(et[i].event); free(pairs[i]); free(b2e[i]); }
     return 0;
 }

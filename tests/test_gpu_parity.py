@@ -144,24 +144,26 @@ def _check_host(batch, plist, n_pairs, ora):
 
 
 def test_host_api_chunk_pipeline(ctx, orc, r9, monkeypatch):
-    """abea_align_batch_host cuts the batch into chunks that rotate through three slot streams; the chunking must not
-    show in the results.  Forced here to ~10 chunks (bad reads included, so some chunks carry skipped descriptors)."""
+    """abea_align_batch_host cuts the batch into chunks that rotate through the slot streams; the chunking must not
+    show in the results.  Forced here to >= 8 chunks (bad reads included)."""
     from f5c_amd import synth
     k, model = r9
     batch = synth.make_batch(60, model, k, seed=52, law=1800, bad_frac=0.15)
     ora = orc.align_batch(batch, model, k, n_threads=8)
     monkeypatch.setenv("ABEA_HOST_CHUNK_EVENTS", "20000")
+    monkeypatch.setenv("ABEA_HOST_CHUNK_READS", "4")
     plist, n_pairs, diag = ctx.align_flat_host(batch)
     assert ctx.stats()["n_sub_batches"] >= 8
     _check_host(batch, plist, n_pairs, ora)
     monkeypatch.delenv("ABEA_HOST_CHUNK_EVENTS")
+    monkeypatch.delenv("ABEA_HOST_CHUNK_READS")
     plist1, n_pairs1, _ = ctx.align_flat_host(batch)                 # one chunk
     assert ctx.stats()["n_sub_batches"] == 1
     _check_host(batch, plist1, n_pairs1, ora)
 
 
 def test_host_api_read_larger_than_a_slot(orc, r9):
-    """A read whose scratch exceeds a slot's third of the arena drains the pipeline and runs alone in the whole arena;
+    """A read whose scratch exceeds a slot's share of the arena drains the pipeline and runs alone in the whole arena;
     a read that does not fit the arena at all is an error, not a CPU fallback."""
     from f5c_amd import abea, synth
     k, model = r9
@@ -169,7 +171,7 @@ def test_host_api_read_larger_than_a_slot(orc, r9):
     ora = orc.align_batch(batch, model, k, n_threads=6)
     with abea.AbeaContext(model, k, max_arena_bytes=16 << 20) as small:
         plist, n_pairs, _ = small.align_flat_host(batch)
-        assert small.stats()["n_sub_batches"] >= 4
+        assert small.stats()["n_sub_batches"] >= 3
         _check_host(batch, plist, n_pairs, ora)
         huge = synth.make_batch(1, model, k, seed=54, lengths=[200000], bad_frac=0.0)
         with pytest.raises(RuntimeError, match="arena"):

@@ -1,0 +1,259 @@
+"""The host-buffer entry (abea_align_batch_host = what align_db costs its caller, src/f5c.cu:647-1061): chunk pipeline,
+both pair-return modes, fused scaling_single, the nsample guard, error exits, and the in-library multi-device dispatch.
+GPU results are compared with the CPU oracle bit for bit."""
+import os
+import subprocess
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _check_host(batch, plist, n_pairs, ora):
+    o_pairs, o_n, _ = ora
+    assert (n_pairs == o_n).all(), np.nonzero(n_pairs != o_n)[0][:10]
+    for i in range(len(o_n)):
+        s = int(batch["pair_ptr"][i])
+        assert (plist[i] == o_pairs[s:s + o_n[i]]).all(), f"read {i}"
+
+
+# ---------------------------------------------------------------- CPU: the splitter is host-only code
+def test_lpt_split_is_the_sharding_rule(r9):
+    """abea_lpt_split (the in-library multi-GPU split) = f5c_amd.synth.shard_batch (the bench's per-rank split):
+    same bins, every read exactly once, bins balanced on the band count."""
+    from f5c_amd import abea, synth
+    k, model = r9
+    lib = abea.load_library()
+    rng = np.random.default_rng(3)
+    L = np.exp(rng.uniform(np.log(1000.0), np.log(50000.0), 5000)).astype(np.int64)
+    E = (2 * L + rng.integers(-50, 50, len(L))).astype(np.int64)
+    w = np.ascontiguousarray(E + (L - k + 1) + 2)
+    w[::97] = 0                                              # guard failures cost nothing
+    for nb in (1, 2, 3, 8):
+        bins = np.full(len(w), -1, dtype=np.int32)
+        assert lib.abea_lpt_split(w.ctypes.data, len(w), nb, bins.ctypes.data) == 0
+        assert bins.min() == 0 and bins.max() == nb - 1
+        loads = np.bincount(bins, weights=w, minlength=nb)
+        assert loads.max() - loads.min() <= w.max()          # LPT bound
+        if nb > 1:
+            assert loads.max() / loads.mean() < 1.01
+    # same rule as the Python splitter the bench uses per rank
+    fake = dict(read_len=L.astype(np.int32), n_events=(w - L).astype(np.int32))
+    import heapq
+    order = np.argsort(-w, kind="stable")
+    heap = [(0, r) for r in range(4)]
+    ref = np.zeros(len(w), dtype=np.int32)
+    for i in order:
+        load, r = heapq.heappop(heap)
+        ref[i] = r
+        heapq.heappush(heap, (load + int(w[i]), r))
+    bins = np.zeros(len(w), dtype=np.int32)
+    lib.abea_lpt_split(w.ctypes.data, len(w), 4, bins.ctypes.data)
+    assert (bins == ref).all()
+    assert lib.abea_lpt_split(None, 3, 2, bins.ctypes.data) != 0
+
+
+# ---------------------------------------------------------------- GPU
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["codes", "device"])
+def test_both_pair_return_modes_many_chunks(ctx, orc, r9, monkeypatch, mode):
+    """Pairs expanded on the host from the 2-bit walk (default) and pairs expanded + compacted on the device
+    (ABEA_HOST_PAIRS=device) give the oracle's lists, over many small chunks and over one chunk."""
+    from f5c_amd import synth
+    k, model = r9
+    batch = synth.make_batch(150, model, k, seed=91, law="loguniform", bad_frac=0.1,
+                             lengths=np.exp(np.random.default_rng(1).uniform(np.log(300), np.log(9000), 150)).astype(int))
+    ora = orc.align_batch(batch, model, k, n_threads=8)
+    monkeypatch.setenv("ABEA_HOST_PAIRS", "device" if mode == "device" else "host")
+    for chunk_reads, chunk_events in ((7, 30000), (2048, 48 << 20)):
+        monkeypatch.setenv("ABEA_HOST_CHUNK_READS", str(chunk_reads))
+        monkeypatch.setenv("ABEA_HOST_CHUNK_EVENTS", str(chunk_events))
+        plist, n_pairs, diag = ctx.align_flat_host(batch)
+        st = ctx.stats()
+        assert st["n_sub_batches"] >= (10 if chunk_reads == 7 else 1)
+        _check_host(batch, plist, n_pairs, ora)
+        ran = (diag["flags"] & 3) == 0
+        assert (diag["n_aligned"][ran] == ora[2]["n_aligned"][ran]).all()
+        assert np.allclose(diag["sum_emission"][ran], ora[2]["sum_emission"][ran], rtol=0, atol=1e-4)
+        assert st["sum_pairs"] == int(ora[1].sum())
+        if mode == "codes":                                  # the walk is ~0.4 B per event on the wire, the pairs ~8
+            assert st["d2h_bytes"] < 2 * int(batch["n_events"].sum()) + 200 * len(n_pairs) + (1 << 16) * st["n_sub_batches"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("want_pairs", [True, False])
+def test_fused_scaling_single_through_the_host_entry(ctx, orc, r9, monkeypatch, want_pairs):
+    """align_db + scaling_db in one call (f5c.c:924-936): base_to_event_map, recalibrated scalings, events_per_base, flags
+    and counts equal the oracle's scaling_single on the oracle's pairs; with pairs=NULL nothing but those comes back."""
+    from f5c_amd import synth
+    k, model = r9
+    batch = synth.make_batch(60, model, k, seed=83, law="gamma8k", bad_frac=0.1)
+    monkeypatch.setenv("ABEA_HOST_CHUNK_READS", "16")
+    monkeypatch.setenv("ABEA_HOST_CHUNK_EVENTS", "200000")
+    o_pairs, o_n, _ = orc.align_batch(batch, model, k, n_threads=8)
+    flag_in = np.zeros(60, dtype=np.int32); flag_in[5] = 0x100          # unrelated bits survive
+    plist, n_pairs, _, sc = ctx.align_flat_host(batch, scaling=True, want_pairs=want_pairs, read_stat_flag=flag_in)
+    assert ctx.stats()["n_sub_batches"] >= 3
+    assert (n_pairs == o_n).all()
+    assert (plist is None) == (not want_pairs)
+    n_cal = 0
+    for i in range(60):
+        s, L = int(batch["read_ptr"][i]), int(batch["read_len"][i])
+        es, E = int(batch["event_ptr"][i]), int(batch["n_events"][i])
+        ps = int(batch["pair_ptr"][i])
+        r = orc.scaling_single(o_pairs[ps:ps + o_n[i]], batch["reads"][s:s + L].tobytes(), batch["events"][es:es + E],
+                               model, k, batch["scalings"]["scale"][i], batch["scalings"]["shift"][i])
+        assert sc["read_stat_flag"][i] == (r["flag"] | flag_in[i]), i
+        assert sc["n_event_alignment"][i] == r["n_alignment"] and sc["events_per_base"][i] == r["events_per_base"]
+        m = sc["base_to_event_map"][i]
+        if o_n[i] > 0:
+            assert (m[:, 0] == r["base_to_event_map"]["start"]).all() and (m[:, 1] == r["base_to_event_map"]["stop"]).all()
+            if not (r["flag"] & 1) or r["scalings"]["var"] != 0:
+                assert sc["scalings"]["shift"][i] == r["scalings"]["shift"]
+                assert sc["scalings"]["scale"][i] == r["scalings"]["scale"]
+                assert sc["scalings"]["var"][i] == r["scalings"]["var"]
+                n_cal += 1
+        else:
+            assert (m == -1).all()                            # untouched: the reference leaves NULL there
+            assert sc["scalings"]["scale"][i] == batch["scalings"]["scale"][i]
+    assert n_cal >= 40
+
+
+@pytest.mark.gpu
+def test_nsample_zero_reads_are_skipped(ctx, orc, r9):
+    """align_single's first guard (f5c.c:812,826-828): db->sig[i]->nsample == 0 -> n_event_align_pairs = 0, nothing
+    written; the other reads are unaffected."""
+    from f5c_amd import synth
+    k, model = r9
+    batch = synth.make_batch(30, model, k, seed=93, law=1500, bad_frac=0.0)
+    ora = orc.align_batch(batch, model, k, n_threads=4)
+    ns = np.full(30, 6000, dtype=np.int64); ns[[0, 7, 29]] = 0
+    seqs, evs = [], []
+    for i in range(30):
+        s, L = int(batch["read_ptr"][i]), int(batch["read_len"][i])
+        es, E = int(batch["event_ptr"][i]), int(batch["n_events"][i])
+        seqs.append(batch["reads"][s:s + L].tobytes()); evs.append(batch["events"][es:es + E])
+    plist, n_pairs, diag = ctx.align_db_host(seqs, evs, batch["scalings"], n_samples=ns)
+    assert (n_pairs[[0, 7, 29]] == 0).all() and (diag["flags"][[0, 7, 29]] & 1).all()
+    keep = np.setdiff1d(np.arange(30), [0, 7, 29])
+    assert (n_pairs[keep] == ora[1][keep]).all() and (ora[1][keep] > 0).all()
+    for i in keep:
+        s = int(batch["pair_ptr"][i])
+        assert (plist[i] == ora[0][s:s + ora[1][i]]).all()
+
+
+@pytest.mark.gpu
+def test_error_exit_leaves_nothing_in_flight(orc, r9, monkeypatch):
+    """A read that cannot fit the arena fails the call before anything is launched, and the same context then runs
+    the next batch correctly (regression: stale chunk bookkeeping used to be un-flattened into the next batch)."""
+    from f5c_amd import abea, synth
+    k, model = r9
+    monkeypatch.setenv("ABEA_HOST_CHUNK_READS", "4")
+    monkeypatch.setenv("ABEA_HOST_CHUNK_EVENTS", "10000")
+    good = synth.make_batch(40, model, k, seed=95, law=1200, bad_frac=0.05)
+    ora = orc.align_batch(good, model, k, n_threads=4)
+    bad = synth.make_batch(13, model, k, seed=96, lengths=[1200] * 12 + [250000], bad_frac=0.0)
+    with abea.AbeaContext(model, k, max_arena_bytes=20 << 20) as c:
+        for _ in range(2):
+            with pytest.raises(abea.AbeaError, match="arena"):
+                c.align_flat_host(bad)
+            plist, n_pairs, _ = c.align_flat_host(good)
+            _check_host(good, plist, n_pairs, ora)
+
+
+@pytest.mark.gpu
+def test_multi_device_context_two_contexts_on_one_gpu(orc, r9, monkeypatch):
+    """abea_init_multi: one process, several device contexts; every batch is LPT-split inside the library and each
+    share runs its own pipeline from its own host thread.  On a 1-GPU box the device is listed twice."""
+    from f5c_amd import abea, synth
+    k, model = r9
+    batch = synth.make_batch(120, model, k, seed=97, bad_frac=0.08,
+                             lengths=np.exp(np.random.default_rng(2).uniform(np.log(400), np.log(12000), 120)).astype(int))
+    ora = orc.align_batch(batch, model, k, n_threads=8)
+    monkeypatch.setenv("ABEA_HOST_CHUNK_READS", "8")
+    monkeypatch.setenv("ABEA_HOST_CHUNK_EVENTS", "50000")
+    with abea.AbeaContext(model, k, device_ids=[0, 0], max_arena_bytes=1 << 30) as c:
+        assert c.device_count() == 2
+        c.selftest()
+        for scaling in (False, True):
+            res = c.align_flat_host(batch, scaling=scaling)
+            _check_host(batch, res[0], res[1], ora)
+            st = c.stats()
+            assert st["n_devices"] == 2 and st["n_reads_gpu"] + st["n_reads_skipped"] == 120
+            per = [c.device_stats(d) for d in range(2)]
+            assert all(p["n_reads_gpu"] > 0 for p in per)
+            assert sum(p["sum_events"] for p in per) == st["sum_events"]
+            bands = [p["sum_bands"] for p in per]
+            assert max(bands) / (sum(bands) / 2) < 1.05       # LPT balance on the band count
+        with pytest.raises(abea.AbeaError, match="single-device"):
+            c.align_db_device(abea.AbeaContext.upload(batch))
+    # the single-device result is identical
+    with abea.AbeaContext(model, k, device_ids=[0], max_arena_bytes=1 << 30) as c1:
+        assert c1.device_count() == 1
+        plist, n_pairs, _ = c1.align_flat_host(batch)
+        _check_host(batch, plist, n_pairs, ora)
+
+
+def _run_shim(tmp_path, batch, model, k, env):
+    import struct
+    from f5c_amd import abea
+    exe = str(tmp_path / "shim_driver")
+    if not os.path.exists(exe):
+        subprocess.check_call(["g++", "-std=c++11", "-O2", os.path.join(ROOT, "tests", "shim_driver.cpp"), "-o", exe,
+                               "-L", os.path.dirname(abea.LIB_PATH), "-labea_hip",
+                               "-Wl,-rpath," + os.path.dirname(os.path.abspath(abea.LIB_PATH))])
+    n = len(batch["read_len"])
+    blob = struct.pack("<4i", n, k, len(model), 0) + model.tobytes() + batch["read_len"].tobytes() + \
+        batch["n_events"].tobytes() + batch["scalings"].tobytes()
+    for i in range(n):
+        s, L = int(batch["read_ptr"][i]), int(batch["read_len"][i])
+        blob += batch["reads"][s:s + L].tobytes()
+    blob += batch["events"].tobytes()
+    (tmp_path / "batch.bin").write_bytes(blob)
+    e = dict(os.environ); e.update(env)
+    subprocess.check_call([exe, str(tmp_path / "batch.bin"), str(tmp_path / "out.txt")], env=e)
+    lines = (tmp_path / "out.txt").read_text().splitlines()
+    got = []
+    for ln in lines:
+        f = ln.split("\t")
+        got.append([tuple(int(v) for v in t.strip("{}").split(",")) for t in f[1:] if t])
+    return got
+
+
+@pytest.mark.gpu
+def test_cpp_caller_nsample_multi_device_and_fused(orc, r9, tmp_path):
+    """The g++-built process_db-shaped caller through include/abea_f5c_shim.h with (a) bad reads (nsample == 0),
+    (b) a device LIST (two contexts on device 0), (c) align_db + scaling_db fused (abea_f5c_align_scale)."""
+    from f5c_amd import synth
+    k, model = r9
+    batch = synth.make_batch(24, model, k, seed=72, law=1600, bad_frac=0.1)
+    o_pairs, o_n, _ = orc.align_batch(batch, model, k, n_threads=4)
+
+    def expect(i):
+        s = int(batch["pair_ptr"][i])
+        return [tuple(int(v) for v in p) for p in o_pairs[s:s + o_n[i]]]
+
+    got = _run_shim(tmp_path, batch, model, k, {"SHIM_NSAMPLE0": "1,5", "SHIM_DEVS": "0,0"})
+    for i in range(24):
+        assert got[i] == ([] if i in (1, 5) else expect(i)), i
+    got = _run_shim(tmp_path, batch, model, k, {"SHIM_FUSED": "1"})
+    for i in range(24):
+        assert got[i] == expect(i), i
+    for ln in (tmp_path / "out.txt.scale").read_text().splitlines():
+        f = ln.split("\t")
+        i = int(f[0])
+        s, L = int(batch["read_ptr"][i]), int(batch["read_len"][i])
+        es, E = int(batch["event_ptr"][i]), int(batch["n_events"][i])
+        ps = int(batch["pair_ptr"][i])
+        r = orc.scaling_single(o_pairs[ps:ps + o_n[i]], batch["reads"][s:s + L].tobytes(), batch["events"][es:es + E],
+                               model, k, batch["scalings"]["scale"][i], batch["scalings"]["shift"][i])
+        assert int(f[1]) == r["flag"] and int(f[2]) == r["n_alignment"] and float.fromhex(f[3]) == r["events_per_base"]
+        if o_n[i] > 0:
+            m = np.array([[int(v) for v in t.split(",")] for t in f[7].split()], dtype=np.int32)
+            assert (m[:, 0] == r["base_to_event_map"]["start"]).all() and (m[:, 1] == r["base_to_event_map"]["stop"]).all()
+            if not (r["flag"] & 1) or r["scalings"]["var"] != 0:
+                assert np.float32(float.fromhex(f[4])) == r["scalings"]["shift"]
+                assert np.float32(float.fromhex(f[5])) == r["scalings"]["scale"]
+                assert np.float32(float.fromhex(f[6])) == r["scalings"]["var"]
+        else:
+            assert f[7].strip() == "NULL"                      # f5c.c:787 base_to_event_map[i] = NULL
