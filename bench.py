@@ -1,11 +1,18 @@
 #!/usr/bin/env python3
 """bench.py — ABEA throughput on MI355X (BASELINE.json metric: ABEA Mevents/s, + % HBM roofline).
 
-A "step" is one pass of the hot path (the align-pre kernel and the fused band fill + traceback + expansion kernel,
-through abea_align_batch_device) over one synthetic batch already resident in HBM.  Workload at N=1 is
-BASELINE.json configs[1]: synthetic R9.4.1 DNA, 10k reads, mean 8 kb, ~2 events/base, W=100.
-For N>1 every rank owns an independent batch of the same law (weak scaling, no data-path
-collective); RCCL carries only the final MAX-time / statistics gather.
+A "step" is one pass of the hot path over one synthetic batch THROUGH THE HOST ENTRY, abea_align_batch_host: what
+align_db() costs its caller ("wall-time of abea_align_batch, H2D of the packed batch through D2H of pairs";
+reference src/f5c.cu:647-1061).  Inputs are the per-read host buffers of a db_t (sequences, event_t tables, scalings),
+outputs the per-read pair lists in caller-owned host memory; the timed region holds flatten, both PCIe directions, the
+align-pre kernel, the fused band fill + traceback kernel and the un-flatten.  `value` is that PCIe-inclusive rate.
+Beside it, measured in the same run on the same batch: the device-resident rate (abea_align_batch_device, inputs
+already in HBM) and the kernel-only rate, which carries the roofline of the dominant kernel.
+
+Workload at N=1: BASELINE.json configs[2], the largest single-GPU configuration — 100k synthetic R9.4.1 reads, 1-50 kb.
+N>1 (config 4): the SAME batch strong-scaled; every rank builds and aligns only its LPT shard, no data-path collective;
+RCCL carries the final MAX-time / statistics gather.  `--single-process --gpus N` instead drives N GPUs from one
+process through the library's own multi-device context (abea_init_multi).
 
 Prints ONE JSON line on rank 0.
 """
@@ -24,29 +31,35 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (≈6.3 TB
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", default="r9_10k_8kb", help="r9_10k_8kb | r9_100k_mixed | r10_50k_10kb")
-    ap.add_argument("--reads", type=int, default=0, help="override the number of reads (per rank)")
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--steps", type=int, default=12)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", default="r9_100k_mixed", help="r9_100k_mixed | r9_10k_8kb | r10_50k_10kb")
+    ap.add_argument("--reads", type=int, default=0, help="override the number of reads of the whole batch")
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"])
+    ap.add_argument("--mode", default="all", choices=["all", "host", "device"],
+                    help="host: only the timed host-to-host steps; device: only the device-resident leg (the command "
+                         "the per-kernel rocprofv3 summaries under profiles/ are taken with)")
+    ap.add_argument("--device-steps", type=int, default=3, help="device-resident steps (roofline leg)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-small-batch", action="store_true", help="skip the f5c-default-batch (-K 512 -B 2M) measurement")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline sample duration")
-    ap.add_argument("--arena-gib", type=float, default=0.0, help="cap the scratch arena (0 = 90%% of free HBM)")
+    ap.add_argument("--arena-gib", type=float, default=150.0, help="cap the scratch arena (the resident batch needs the rest)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to exercise the N>1 path on one GPU)")
-    ap.add_argument("--one-device", action="store_true", help="testing aid: every rank uses cuda:0 (needs --backend gloo)")
-    ap.add_argument("--batch-cache", default="", help="np.savez cache of the generated batch (avoids the forked "
-                    "generator pool, e.g. under rocprofv3)")
+    ap.add_argument("--one-device", action="store_true", help="testing aid: every rank / context uses device 0")
+    ap.add_argument("--single-process", action="store_true", help="N GPUs from ONE process (abea_init_multi) instead of one rank per GPU")
     args = ap.parse_args()
 
     import numpy as np
     import torch
-    from f5c_amd import abea, synth, load_model_f32, synthetic_model
+    from f5c_amd import abea, synth, dist_util, load_model_f32, synthetic_model
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
+    if args.single_process:
+        assert world == 1, "--single-process is launched without torch.distributed.run"
+    elif world != args.gpus:
         assert world == 1 and args.gpus == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
     cfg = synth.CONFIGS[args.config]
     k = cfg["k"]
@@ -54,23 +67,24 @@ def main():
         _, model = load_model_f32(os.path.join(ROOT, "tests", "golden", "r9.4_450bps.6mer.f32"))
     else:
         model = synthetic_model(k, seed=9)
-    n_reads = args.reads or cfg["n_reads"]
+    n_total = args.reads or cfg["n_reads"]
+
+    # ---- the batch: every rank builds only the reads it aligns ----
     t0 = time.time()
-    workers = max(1, min(32, (os.cpu_count() or 1) // max(1, world)))
-    cache = f"{args.batch_cache}.{args.config}.{n_reads}.r{rank}.npz" if args.batch_cache else ""
-    if cache and os.path.exists(cache):
-        z = np.load(cache)
-        batch = {k_: z[k_] for k_ in z.files}
-        batch["pair_cap"] = int(batch["pair_cap"])
-    elif args.scaling == "weak":
-        batch = synth.make_batch(n_reads, model, k, seed=cfg["seed"] + 1000 * rank, law=cfg["law"], workers=workers)
+    workers = max(1, min(16, effective_cpus() // max(1, world)))
+    if world > 1 and args.scaling == "strong":
+        # config 4: ONE batch, LPT-split on the band count; the read lengths are known before generation
+        # (E is ~2.04 L for this generator, so 3L stands for E + K) and each rank generates just its shard
+        L_all = synth.batch_lengths(n_total, cfg["seed"], cfg["law"])
+        mine = np.nonzero(synth.lpt_bins(3 * L_all, world) == rank)[0]
+        batch = synth.make_batch(n_total, model, k, seed=cfg["seed"], law=cfg["law"], workers=workers, subset=mine)
+    elif world > 1:
+        batch = synth.make_batch(n_total, model, k, seed=cfg["seed"] + 1000 * rank, law=cfg["law"], workers=workers)
     else:
-        full = synth.make_batch(n_reads, model, k, seed=cfg["seed"], law=cfg["law"], workers=workers)
-        batch, _ = synth.shard_batch(full, rank, world)
-        del full
-    if cache and not os.path.exists(cache):
-        np.savez(cache, **batch)
+        batch = synth.make_batch(n_total, model, k, seed=cfg["seed"], law=cfg["law"], workers=workers)
     t_gen = time.time() - t0
+    sum_events = int(batch["n_events"].sum())
+    n_reads = len(batch["read_len"])
 
     # GPU / RCCL initialisation only after the forked generator pool is done
     if args.one_device:
@@ -84,87 +98,135 @@ def main():
         else:
             dist.init_process_group("gloo")
 
-    d = abea.AbeaContext.upload(batch)            # inputs resident in HBM before the arena is sized
-    ctx = abea.AbeaContext(model, k, device_id=local_rank, verbosity=0,
-                           max_arena_bytes=int(args.arena_gib * (1 << 30)))
+    n_dev = args.gpus if args.single_process else 1
+    dev_ids = ([0] * n_dev if args.one_device else list(range(n_dev))) if args.single_process else None
+    ctx = abea.AbeaContext(model, k, device_id=local_rank, verbosity=0, device_ids=dev_ids,
+                           max_arena_bytes=int(args.arena_gib * (1 << 30) / (n_dev if args.one_device else 1)))
     ctx.selftest()
-    sum_events = int(batch["n_events"].sum())
 
     def sync():
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
 
-    for _ in range(args.warmup):
+    out = {}
+    # ================================================================ host-to-host: the timed region
+    elapsed = 0.0
+    host_stats = None
+    if args.mode in ("all", "host"):
+        view = ctx.host_view(batch)            # per-read pointer arrays over the host batch + caller-owned pair buffers
+        for _ in range(args.warmup):
+            ctx.align_view(view)
+        sync()
+        t0 = time.perf_counter()
+        acc = dict(flatten_ms=0.0, unflatten_ms=0.0, wait_ms=0.0, pre_ms=0.0, fill_ms=0.0)
+        for _ in range(args.steps):
+            ctx.align_view(view)
+            st = ctx.stats()
+            for key in acc:
+                acc[key] += st[key]
+        sync()
+        elapsed = time.perf_counter() - t0
+        host_stats = ctx.stats()
+        host_n_pairs = view["n_pairs"].copy()
+    # ================================================================ device-resident leg (not in the timed region)
+    dev = None
+    if args.mode in ("all", "device") and not args.single_process:
+        d = abea.AbeaContext.upload(batch)
         ctx.align_db_device(d, want_diag=False)
-    sync()
-    t0 = time.perf_counter()
-    fill_ms = pre_ms = trace_ms = 0.0
-    launches = 0
-    for _ in range(args.steps):
-        ctx.align_db_device(d, want_diag=False)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        fill_ms = pre_ms = 0.0
+        launches = 0
+        for _ in range(args.device_steps):
+            ctx.align_db_device(d, want_diag=False)
+            st = ctx.stats()
+            fill_ms += st["fill_ms"]; pre_ms += st["pre_ms"]
+            launches += st["fill_launches"]
+        torch.cuda.synchronize()
+        dev_elapsed = time.perf_counter() - t1
         st = ctx.stats()
-        fill_ms += st["fill_ms"]; pre_ms += st["pre_ms"]; trace_ms += st["trace_ms"]
-        launches += st["fill_launches"]
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
+        n_pairs = d["n_pairs"].cpu().numpy()[:n_reads]
+        sum_pairs = int(n_pairs.sum())
+        # SURVEY §8d A_ref: stats.bytes_ref holds the P-independent part (24E + L+1 + 40 + 108B + 4); +17 B per returned pair
+        a_ref = int(st["bytes_ref"]) + 17 * sum_pairs
+        a_min = int(st["bytes_min"]) + 8 * sum_pairs
+        dev = dict(elapsed=dev_elapsed, fill_ms=fill_ms, pre_ms=pre_ms, launches=launches, a_ref=a_ref, a_min=a_min,
+                   launches_per_step=st["fill_launches"], n_pairs=n_pairs, d=d)
+        if host_stats is not None:
+            assert (n_pairs == host_n_pairs).all(), "host entry and device entry disagree on n_pairs"
+    if host_stats is None:
+        # --mode device: report the device-resident rate as the step (profiling runs only; value is flagged)
+        elapsed = dev["elapsed"] * args.steps / max(1, args.device_steps)
+    qc_pass = float(((host_n_pairs if host_stats is not None else dev["n_pairs"]) > 0).sum())
 
-    st = ctx.stats()
-    n_pairs = d["n_pairs"].cpu().numpy()[:len(batch["read_len"])]
-    sum_pairs = int(n_pairs.sum())
-    # SURVEY §8d A_ref: stats.bytes_ref holds the P-independent part (24E + L+1 + 40 + 108B + 4); +17 B per returned pair
-    a_ref = int(st["bytes_ref"]) + 17 * sum_pairs
-    a_min = int(st["bytes_min"]) + 8 * sum_pairs
-    stats_vec = torch.tensor([elapsed, float(sum_events), fill_ms, pre_ms, trace_ms, float(launches),
-                              float(a_ref), float(a_min), float(len(batch["read_len"])),
-                              float((n_pairs > 0).sum())], dtype=torch.float64,
-                             device="cuda" if args.backend == "nccl" else "cpu")
-    if dist is not None:
-        allv = [torch.zeros_like(stats_vec) for _ in range(world)]
-        dist.all_gather(allv, stats_vec)            # the "trivial final gather" over xGMI
-        allv = torch.stack(allv).cpu().numpy()
-    else:
-        allv = stats_vec.cpu().numpy()[None, :]
-    t_max = float(allv[:, 0].max())
-    total_events = float(allv[:, 1].sum())
-    total_reads = float(allv[:, 8].sum())
+    g = dist_util.gather_stats(dict(elapsed=elapsed, events=float(sum_events), reads=float(n_reads), pairs=qc_pass),
+                               device="cuda" if (dist is not None and args.backend == "nccl") else "cpu")
+    t_max, total_events, total_reads = g["t_max"], g["events"], g["reads"]
 
     if rank == 0:
         value = total_events * args.steps / t_max / 1e6
-        # roofline of the dominant kernel (abea_fill_kernel) on rank 0: algorithmic bytes of one launch
-        # over its HIP-event duration on the library's stream
-        fill_avg_ms = fill_ms / max(1, launches)
-        a_ref_launch = a_ref / max(1, st["fill_launches"])
-        achieved = a_ref_launch / (fill_avg_ms * 1e-3) / 1e9
+        name = {"r9_100k_mixed": "BASELINE configs[2]: 100k synthetic R9.4.1 DNA reads, 1-50 kb log-uniform, ~2 events/base, bandwidth 100",
+                "r9_10k_8kb": "BASELINE configs[1]: 10k synthetic R9.4.1 DNA reads, mean 8 kb, ~2 events/base, bandwidth 100",
+                "r10_50k_10kb": "BASELINE configs[4]: 50k reads mean 10 kb, synthetic 9-mer (R10-sized) model"}.get(args.config, args.config)
+        if world > 1 or args.single_process:
+            name += f"; the same batch split over {args.gpus} GPUs (configs[3])" if args.scaling == "strong" or args.single_process \
+                else f"; an independent batch per GPU x{args.gpus}"
         out = {
             "metric": "ABEA Mevents/s", "value": round(value, 3), "unit": "Mevents/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(t_max / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": args.scaling, "vs_baseline": None, "dtype": "f32 scores, f64 sums, 2-bit trace",
-            "data": "synthetic",
-            "config": {"workload": f"{args.config}: synthetic R9.4.1 DNA reads, ~2 events/base, bandwidth 100"
-                       if k == 6 else f"{args.config}: synthetic 9-mer model",
-                       "reads_per_gpu": int(len(batch["read_len"])), "events_per_gpu": sum_events,
-                       "kmer_size": k, "parallelism": f"reads sharded x{world}" if world > 1 else "1 GPU",
-                       "inputs": "resident in HBM (flattened event_t AoS + sequences)"},
+            "scaling": "strong" if (args.scaling == "strong" or args.single_process) else "weak", "vs_baseline": None,
+            "dtype": "f32 scores, f64 sums, 2-bit trace", "data": "synthetic",
+            "config": {"workload": name, "reads": int(total_reads), "events": int(total_events), "kmer_size": k,
+                       "reads_rank0": n_reads, "events_rank0": sum_events,
+                       "parallelism": (f"one process, {args.gpus} GPUs (abea_init_multi, LPT split in the library)" if args.single_process
+                                       else f"{world} ranks x 1 GPU, LPT shards, no data-path collective" if world > 1 else "1 GPU"),
+                       "boundary": ("host buffers in, host buffers out: abea_align_batch_host = align_db's GPU branch "
+                                    "(flatten + H2D + kernels + D2H + un-flatten inside the timed region)"
+                                    if host_stats is not None else "device-resident only (--mode device, profiling run)")},
             "reads_per_s": round(total_reads * args.steps / t_max, 1),
-            "qc_pass_frac": round(float(allv[:, 9].sum() / total_reads), 4),
-            "kernel_ms": {"pre": round(pre_ms / args.steps, 3), "fill": round(fill_ms / args.steps, 3),
-                          "post": round(trace_ms / args.steps, 3), "fill_launches_per_step": launches // args.steps},
-            "roofline": {"bound": "hbm", "kernel": "abea_align_kernel", "achieved": round(achieved, 2),
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                         "traffic": pmc_traffic(args.config, sum_events),
-                         "algorithmic_bytes_per_launch": int(a_ref_launch),
-                         "bytes_per_event_ref": round(a_ref / sum_events, 1),
-                         "frac_min_bytes": round(a_min / max(1, st["fill_launches"]) / (fill_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                         "avg_launch_ms": round(fill_avg_ms, 3),
-                         "limiter": valu_issue(args.config, sum_events, fill_avg_ms)},
+            "qc_pass_frac": round(g["pairs"] / total_reads, 4),
             "gen_s": round(t_gen, 1),
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(batch, model, k, args.cpu_seconds, d, ctx)
+        if host_stats is not None:
+            out["host_to_host"] = {
+                "mevents_per_s": round(sum_events * args.steps / elapsed / 1e6, 1),
+                "ms_per_step": round(elapsed / args.steps * 1e3, 2),
+                "host_ms_per_step": {"flatten": round(acc["flatten_ms"] / args.steps, 1),
+                                     "unflatten": round(acc["unflatten_ms"] / args.steps, 1),
+                                     "wait_for_gpu": round(acc["wait_ms"] / args.steps, 1)},
+                "chunks_per_step": int(host_stats["n_sub_batches"]), "host_threads": int(host_stats["host_threads"]),
+                "devices": int(host_stats["n_devices"]),
+                "pcie_bytes_per_step": {"h2d": int(host_stats["h2d_bytes"]), "d2h": int(host_stats["d2h_bytes"])},
+                "note": "pairs come down as the 2-bit traceback walk and are expanded on the host into the caller's buffers",
+            }
+        if dev is not None:
+            dsteps = args.device_steps
+            fill_avg_ms = dev["fill_ms"] / max(1, dev["launches"])
+            a_ref_launch = dev["a_ref"] / max(1, dev["launches_per_step"])
+            achieved = a_ref_launch / (fill_avg_ms * 1e-3) / 1e9
+            out["device_resident"] = {"mevents_per_s": round(sum_events * dsteps / dev["elapsed"] / 1e6, 1),
+                                      "ms_per_step": round(dev["elapsed"] / dsteps * 1e3, 2), "steps": dsteps,
+                                      "inputs": "flattened event_t AoS + sequences already in HBM, pairs stay in HBM"}
+            out["kernel_only"] = {"mevents_per_s": round(sum_events * dsteps / ((dev["fill_ms"] + dev["pre_ms"]) * 1e-3) / 1e6, 1),
+                                  "ms_per_step": {"pre": round(dev["pre_ms"] / dsteps, 3), "align": round(dev["fill_ms"] / dsteps, 3)},
+                                  "align_launches_per_step": int(dev["launches_per_step"])}
+            out["roofline"] = {"bound": "hbm", "kernel": "abea_align_kernel", "achieved": round(achieved, 2),
+                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+                               "traffic": pmc_traffic(args.config, sum_events, dev["launches_per_step"]),
+                               "algorithmic_bytes_per_launch": int(a_ref_launch),
+                               "bytes_per_event_ref": round(dev["a_ref"] / sum_events, 1),
+                               "frac_min_bytes": round(dev["a_min"] / max(1, dev["launches_per_step"]) / (fill_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                               "avg_launch_ms": round(fill_avg_ms, 3),
+                               "measured_on": "the device-resident leg of this run (one launch per step; HIP events on the "
+                                              "library's stream); the host-to-host steps launch the same kernel once per chunk",
+                               "limiter": valu_issue(args.config, sum_events, fill_avg_ms, dev["launches_per_step"])}
+        if world == 1 and not args.single_process and not args.no_small_batch and host_stats is not None:
+            out["f5c_default_batch"] = small_batch(ctx, batch)
+        if world == 1 and not args.single_process and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(batch, model, k, args.cpu_seconds, view if host_stats is not None else None,
+                                               dev, ctx)
         print(json.dumps(out), flush=True)
     ctx.close()
     if dist is not None:
@@ -172,24 +234,46 @@ def main():
         dist.destroy_process_group()
 
 
-def pmc_traffic(config, sum_events):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same
-    command (profiles/pmc_traffic.json: bytes per event, FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM)."""
+def small_batch(ctx, batch):
+    """What a drop-in does WITHOUT re-tuned flags: f5c's default batch is -K 512 reads / -B 2 Mbases (src/f5c.c:1178-1179).
+    One such batch fills 512 of the GPU's 4096 wave slots and lasts as long as its longest read."""
+    import numpy as np
+    from f5c_amd import synth
+    L = batch["read_len"].astype(np.int64)
+    n = int(min(512, len(L), max(1, np.searchsorted(np.cumsum(L), 2_000_000) + 1)))
+    sub = synth.take_reads(batch, np.arange(n))
+    v = ctx.host_view(sub)
+    ctx.align_view(v)
+    t0 = time.perf_counter()
+    reps = 5
+    for _ in range(reps):
+        ctx.align_view(v)
+    t = (time.perf_counter() - t0) / reps
+    ev = int(sub["n_events"].sum())
+    return {"reads": n, "bases": int(L[:n].sum()), "events": ev, "ms_per_batch": round(t * 1e3, 2),
+            "mevents_per_s": round(ev / t / 1e6, 1), "longest_read_bases": int(L[:n].max()),
+            "note": "host-to-host, one batch at a time as process_db issues them; INTEGRATION.md recommends -K 20000 -B 200M"}
+
+
+def pmc_traffic(config, sum_events, launches):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of `bench.py --mode device`
+    on the shipped kernel (profiles/pmc_traffic.json: bytes per event, FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM)."""
     try:
         t = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))[config]
-        return int(t["hbm_bytes_per_event"] * sum_events)
+        return int(t["hbm_bytes_per_event"] * sum_events / max(1, launches))
     except Exception:
         return None
 
 
-def valu_issue(config, sum_events, launch_ms):
+def valu_issue(config, sum_events, launch_ms, launches):
     """What actually bounds the kernel: VALU issue.  wave64 VALU instructions per launch (rocprofv3 SQ_INSTS_VALU of
     the same command, profiles/pmc_traffic.json) x measured issue cost per instruction per SIMD / (1024 SIMDs x time)."""
     try:
         t = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))[config]
-        busy_ms = t["valu_wave_instr_per_event"] * sum_events * t["valu_issue_ns_per_instr"] * 1e-6 / 1024.0
-        return {"unit": "valu-issue", "frac": round(busy_ms / launch_ms, 3),
-                "valu_wave_instr_per_launch": int(t["valu_wave_instr_per_event"] * sum_events)}
+        n_inst = t["valu_wave_instr_per_event"] * sum_events / max(1, launches)
+        busy_ms = n_inst * t["valu_issue_ns_per_instr"] * 1e-6 / 1024.0
+        return {"unit": "valu-issue", "frac": round(busy_ms / launch_ms, 3), "valu_wave_instr_per_launch": int(n_inst),
+                "source": t.get("source", "profiles/pmc_traffic.json")}
     except Exception:
         return None
 
@@ -212,63 +296,67 @@ def effective_cpus():
     return n
 
 
-def cpu_baseline(batch, model, k, target_s, dbatch, ctx):
+def cpu_baseline(batch, model, k, target_s, view, dev, ctx):
     """The CPU path timed beside the GPU: the oracle restatement ("port") of align() driven by a
-    pthread_db-shaped work-stealing pool on the host cores, on a bounded prefix of the same batch.
-    Thread counts {all, 1/2, 1/4 of the cores} are tried with glibc malloc tuned to recycle the per-read
-    buffers (the default allocator mmap()s every ~12 MB buffer and stops scaling past ~64 threads; that
-    figure is reported too).  The best throughput is `value`.  Also checks the GPU output bit-exact."""
+    pthread_db-shaped work-stealing pool on the host cores, on a bounded RANDOM sample of the same batch (the batch is
+    length-mixed; a prefix would not be representative).  Thread counts {all, 2x, 4x the usable cores} are tried with
+    glibc malloc tuned to recycle the per-read buffers; the best throughput is `value`.  Also checks the GPU output of
+    this run (host entry, else device entry) bit-exact on the sample."""
     import numpy as np
     from f5c_amd import synth
     from oracle import orc
     hw_threads = os.cpu_count() or 1
     cores = effective_cpus()                 # cgroup CPU quota if one is set (the GPU box: 16 of 256 hw threads)
     n = len(batch["read_len"])
-    cum = np.cumsum(batch["n_events"].astype(np.int64))
+    perm = np.random.default_rng(12345).permutation(n)
+    cum = np.cumsum(batch["n_events"].astype(np.int64)[perm])
 
     def run(n_reads, threads):
-        sub = synth.take_reads(batch, np.arange(n_reads))
+        idx = np.sort(perm[:n_reads])
+        sub = synth.take_reads(batch, idx)
         t0 = time.perf_counter()
         res = orc.align_batch(sub, model, k, n_threads=threads, want_diag=False)
-        return int(sub["n_events"].sum()) / (time.perf_counter() - t0), sub, res
+        return int(sub["n_events"].sum()) / (time.perf_counter() - t0), sub, res, idx
 
-    cands = sorted({cores, min(hw_threads, 2 * cores), min(hw_threads, 4 * cores)}, reverse=True)
-    budget = target_s / (len(cands) + 1)
+    cands = sorted({cores, min(hw_threads, 2 * cores)}, reverse=True)
+    budget = target_s / (len(cands) + 0.5)
     best = None
     tried = {}
     orc.malloc_tuning(True)
+    rate = 9e6
     for t in cands:
-        rate, _, _ = run(min(n, max(8, 2 * t)), t)                          # calibration / warm-up of the heaps
         m = int(min(n, max(2 * t, np.searchsorted(cum, rate * budget) + 1)))
-        rate, sub, res = run(m, t)
+        rate, sub, res, idx = run(m, t)
         tried[str(t)] = round(rate / 1e6, 3)
         if best is None or rate > best[0]:
-            best = (rate, t, m, sub, res)
+            best = (rate, t, m, sub, res, idx)
     orc.malloc_tuning(False)
-    m_def = int(min(n, max(128, np.searchsorted(cum, 8e6 * budget) + 1)))
-    rate_def, _, _ = run(m_def, min(hw_threads, 2 * cores))
-    one = synth.take_reads(batch, np.arange(min(n, 4)))
+    one_idx = perm[:4]
+    one = synth.take_reads(batch, np.sort(one_idx))
     t0 = time.perf_counter()
     orc.align_batch(one, model, k, n_threads=1, want_diag=False)
     t1 = time.perf_counter() - t0
-    rate, t, m, sub, (o_pairs, o_n, _) = best
-    pairs, n_pairs, _ = ctx.download(dbatch)
-    ok = bool((n_pairs[:m] == o_n).all())
+    rate, t, m, sub, (o_pairs, o_n, _), idx = best
+    if view is not None:
+        pairs, n_pairs, src = view["pairs"], view["n_pairs"], "host entry"
+    else:
+        pairs, n_pairs, _ = ctx.download(dev["d"])
+        src = "device entry"
+    ok = bool((n_pairs[idx] == o_n).all())
     if ok:
-        for i in range(m):
-            a = int(batch["pair_ptr"][i]); b = int(sub["pair_ptr"][i])
-            if not (pairs[a:a + o_n[i]] == o_pairs[b:b + o_n[i]]).all():
+        for j, i in enumerate(idx):
+            a = int(batch["pair_ptr"][i]); b = int(sub["pair_ptr"][j]); np_j = int(o_n[j])
+            if not (pairs[a:a + np_j] == o_pairs[b:b + np_j]).all():
                 ok = False
                 break
     return {"value": round(rate / 1e6, 4), "unit": "Mevents/s", "cores": min(t, cores), "kind": "port",
-            "sample": f"first {m} reads of the same batch ({int(sub['n_events'].sum())} events); work-stealing "
+            "sample": f"{m} random reads of the same batch ({int(sub['n_events'].sum())} events); work-stealing "
                       f"pthread pool, best of thread counts {tried}; the container's cgroup CPU quota is {cores} CPUs "
                       f"({hw_threads} hardware threads visible), so at most {cores} cores run at a time; glibc malloc "
                       f"tuned to recycle per-read buffers",
             "threads": t,
-            "default_malloc_mevents_s": round(rate_def / 1e6, 4), "default_malloc_threads": min(hw_threads, 2 * cores),
             "single_thread_mevents_s": round(int(one["n_events"].sum()) / t1 / 1e6, 4),
-            "gpu_bit_exact_on_sample": ok}
+            "gpu_bit_exact_on_sample": ok, "gpu_output_checked": src}
 
 
 if __name__ == "__main__":

@@ -12,8 +12,8 @@ arrays (src/f5c.cu:672-690): the workloads BASELINE.json names.
 
 Read synthesis: bases i.i.d. ACGT; each k-mer emits d events, d = 0 with p=0.04 else 1+Poisson(1.08)
 (≈2 events/base, a few skips); event.mean = scale_t*model.mean + shift_t + N(0,(1.3*model.stdv)^2);
-≈1 % of reads get pure-noise signal (exercise the QC-fail path).  Generation is chunked and seeded
-per chunk ([seed, chunk]) so any box regenerates the identical batch.
+≈1 % of reads get pure-noise signal (exercise the QC-fail path).  Every read draws from its own generator seeded
+[seed, read index], so any box regenerates the identical batch and any subset of it can be built on its own.
 """
 import numpy as np
 from .types import EVENT_DT, SCAL_DT
@@ -53,39 +53,52 @@ def _kmer_ranks(codes, k):
     return r
 
 
-def _chunk(lengths, model, k, rng, bad_frac):
+def _chunk(idx, lengths, model, k, seed, bad_frac):
+    """Reads `idx` (global read indices) of the batch; every read draws from its own generator seeded [seed, index],
+    so any subset of a batch can be generated on its own (bench.py: each rank builds only its shard)."""
     n = len(lengths)
-    tot = int(lengths.sum())
-    codes = rng.integers(0, 4, tot, dtype=np.int64)
-    starts = np.concatenate([[0], np.cumsum(lengths)[:-1]])
     K = lengths - k + 1
+    codes_l, d_l, noise_l, len_l, sd_l, bad_l, badmean_l = [], [], [], [], [], [], []
+    scale_t = np.zeros(n); shift_t = np.zeros(n)
+    for j in range(n):
+        rng = np.random.default_rng([seed, int(idx[j]) + 1])
+        L, Kj = int(lengths[j]), int(K[j])
+        codes_l.append(rng.integers(0, 4, L, dtype=np.int64))
+        d = np.where(rng.random(Kj, dtype=np.float32) < 0.04, 0, 1 + rng.poisson(1.08, Kj)).astype(np.int64)
+        d[0] = max(d[0], 1)                                  # every read needs at least one event
+        d_l.append(d)
+        E = int(d.sum())
+        scale_t[j] = rng.normal(1.0, 0.04); shift_t[j] = rng.normal(0.0, 6.0)
+        noise_l.append(rng.standard_normal(E, dtype=np.float32))
+        len_l.append((1 + rng.poisson(8.0, E)).astype(np.float32))
+        sd_l.append(0.5 + 2.5 * rng.random(E, dtype=np.float32))
+        bad = rng.random() < bad_frac
+        bad_l.append(bad)
+        badmean_l.append(90.0 + 12.0 * rng.standard_normal(E, dtype=np.float32) if bad else None)
+    tot = int(lengths.sum())
+    codes = np.concatenate(codes_l)
+    starts = np.concatenate([[0], np.cumsum(lengths)[:-1]])
     # k-mer start positions (exclude k-mers that would straddle two reads)
     kpos = np.concatenate([np.arange(s, s + kk) for s, kk in zip(starts, K)])
     kread = np.repeat(np.arange(n), K)
     ranks = _kmer_ranks(np.concatenate([codes, np.zeros(k, dtype=np.int64)]), k)[kpos]
-    d = np.where(rng.random(len(kpos), dtype=np.float32) < 0.04, 0, 1 + rng.poisson(1.08, len(kpos))).astype(np.int64)
-    # every read needs at least one event
-    first = np.concatenate([[0], np.cumsum(K)[:-1]])
-    d[first] = np.maximum(d[first], 1)
+    d = np.concatenate(d_l)
     E = np.bincount(kread, weights=d, minlength=n).astype(np.int64)
     ev_rank = np.repeat(ranks, d)
     ev_read = np.repeat(kread, d)
-    scale_t = rng.normal(1.0, 0.04, n)
-    shift_t = rng.normal(0.0, 6.0, n)
     mu = model["level_mean"][ev_rank]
     sd = model["level_stdv"][ev_rank]
-    noise = rng.standard_normal(len(ev_rank), dtype=np.float32)
+    noise = np.concatenate(noise_l)
     mean = scale_t.astype(np.float32)[ev_read] * mu + shift_t.astype(np.float32)[ev_read] + noise * (1.3 * sd)
-    bad = rng.random(n) < bad_frac
-    if bad.any():
-        bmask = bad[ev_read]
-        mean[bmask] = 90.0 + 12.0 * rng.standard_normal(int(bmask.sum()), dtype=np.float32)
-    length = (1 + rng.poisson(8.0, len(ev_rank))).astype(np.float32)
+    bad = np.array(bad_l, dtype=bool)
+    estart = np.concatenate([[0], np.cumsum(E)[:-1]])
+    for j in np.nonzero(bad)[0]:
+        mean[estart[j]:estart[j] + E[j]] = badmean_l[j]
+    length = np.concatenate(len_l)
     ev = np.zeros(len(ev_rank), dtype=EVENT_DT)
     ev["mean"] = mean.astype(np.float32)
     ev["length"] = length
-    ev["stdv"] = 0.5 + 2.5 * rng.random(len(ev_rank), dtype=np.float32)
-    estart = np.concatenate([[0], np.cumsum(E)[:-1]])
+    ev["stdv"] = np.concatenate(sd_l)
     cs = np.cumsum(length.astype(np.int64))
     run = cs - length.astype(np.int64)
     ev["start"] = (run - np.repeat(run[estart], E)).astype(np.uint64)
@@ -113,20 +126,29 @@ _G = {}
 
 
 def _chunk_job(c):
-    L, model, k, seed, bad_frac, chunk_reads = _G["args"]
-    rng = np.random.default_rng([seed, c + 1])
-    return _chunk(L[c * chunk_reads:(c + 1) * chunk_reads], model, k, rng, bad_frac)
+    idx, L, model, k, seed, bad_frac, chunk_reads = _G["args"]
+    sl = slice(c * chunk_reads, (c + 1) * chunk_reads)
+    return _chunk(idx[sl], L[sl], model, k, seed, bad_frac)
+
+
+def batch_lengths(n_reads, seed, law):
+    """Read lengths of a whole batch (cheap: needs no generation); bench.py shards on them before generating."""
+    return read_lengths(law, n_reads, np.random.default_rng([seed, 0x5EED]))
 
 
 def make_batch(n_reads, model, k, seed, law="gamma8k", bad_frac=0.01, chunk_reads=256, lengths=None,
-               workers=1):
+               workers=1, subset=None):
     """Build a flattened batch. `lengths` overrides the length law (array of read lengths).
-    `workers` > 1 generates chunks in forked processes (same result: chunks are seeded independently)."""
-    rng0 = np.random.default_rng([seed, 0x5EED])
-    L = np.asarray(lengths, dtype=np.int64) if lengths is not None else read_lengths(law, n_reads, rng0)
+    `workers` > 1 generates chunks in forked processes (same result: every read has its own generator).
+    `subset`: indices of the reads to build (in that order) instead of the whole batch."""
+    L = np.asarray(lengths, dtype=np.int64) if lengths is not None else batch_lengths(n_reads, seed, law)
+    idx = np.arange(len(L), dtype=np.int64)
+    if subset is not None:
+        idx = np.asarray(subset, dtype=np.int64)
+        L = L[idx]
     n_reads = len(L)
     n_chunks = (n_reads + chunk_reads - 1) // chunk_reads
-    _G["args"] = (L, model, k, seed, bad_frac, chunk_reads)
+    _G["args"] = (idx, L, model, k, seed, bad_frac, chunk_reads)
     if workers > 1 and n_chunks > 1:
         import multiprocessing as mp
         with mp.get_context("fork").Pool(min(workers, n_chunks)) as pool:
@@ -151,6 +173,21 @@ def make_batch(n_reads, model, k, seed, law="gamma8k", bad_frac=0.01, chunk_read
                          if n_reads else np.zeros(0, np.int64))
     batch["pair_cap"] = int(cap.sum())
     return batch
+
+
+def lpt_bins(weight, world):
+    """Longest-processing-time-first split, the rule of the library's abea_lpt_split: items in descending
+    weight go to the currently lightest bin, ties to the lowest bin.  Returns the bin of every item."""
+    import heapq
+    weight = np.asarray(weight, dtype=np.int64)
+    order = np.argsort(-weight, kind="stable")
+    heap = [(0, r) for r in range(world)]
+    bins = np.zeros(len(weight), dtype=np.int32)
+    for i in order:
+        load, r = heapq.heappop(heap)
+        bins[i] = r
+        heapq.heappush(heap, (load + max(int(weight[i]), 0), r))
+    return bins
 
 
 def batch_from_reads(seqs, events_list, scalings):
@@ -185,17 +222,8 @@ def shard_batch(batch, rank, world):
     """LPT shard of a batch over `world` GPUs: reads sorted by band count E+K
     descending are dealt greedily to the lightest bin; returns the sub-batch of `rank` plus the
     original read indices it holds."""
-    import heapq
-    n = len(batch["read_len"])
     w = batch["n_events"].astype(np.int64) + batch["read_len"].astype(np.int64)
-    order = np.argsort(-w, kind="stable")
-    heap = [(0, r) for r in range(world)]
-    bins = [[] for _ in range(world)]
-    for i in order:
-        load, r = heapq.heappop(heap)
-        bins[r].append(int(i))
-        heapq.heappush(heap, (load + int(w[i]), r))
-    idx = np.array(sorted(bins[rank]), dtype=np.int64)
+    idx = np.nonzero(lpt_bins(w, world) == rank)[0].astype(np.int64)
     return take_reads(batch, idx), idx
 
 
