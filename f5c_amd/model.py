@@ -1,24 +1,40 @@
 """Pore-model tables (reference src/model.c): text format reader and the cached log(stdv)."""
+import ctypes
+import ctypes.util
 import math
 import numpy as np
 from .types import MODEL_DT
 
+_libm = ctypes.CDLL(ctypes.util.find_library("m") or "libm.so.6")
+_libm.logf.restype = ctypes.c_float
+_libm.logf.argtypes = [ctypes.c_float]
 
-def _finish(mean, stdv):
+
+def log_stdv(stdv, flavour="logf"):
+    """level_log_stdv as f5c builds it.  model.c:93,179 write `log(model[i].level_stdv)` with a float argument in a
+    translation unit compiled as C++ (Makefile:6 LANGFLAG = -x c++), so <math.h>'s float overload is chosen: glibc
+    logf, not (float)log((double)x).  The two differ by 1 ULP on 16 of the 4096 R9.4.1 entries; "log" keeps the
+    double-then-round variant for the test that shows the kernels are exact on either table."""
+    stdv = np.asarray(stdv, dtype=np.float32)
+    if flavour == "logf":
+        return np.array([_libm.logf(float(s)) for s in stdv], dtype=np.float32)
+    return np.array([math.log(float(s)) for s in stdv], dtype=np.float32)
+
+
+def _finish(mean, stdv, flavour="logf"):
     m = np.zeros(len(mean), dtype=MODEL_DT)
     m["level_mean"] = mean
     m["level_stdv"] = stdv
-    # model.c:93 / :179 — level_log_stdv = (float) log((double) level_stdv), libm log
-    m["level_log_stdv"] = np.array([math.log(float(s)) for s in m["level_stdv"]], dtype=np.float32)
+    m["level_log_stdv"] = log_stdv(m["level_stdv"], flavour)
     return m
 
 
-def load_model_f32(path):
+def load_model_f32(path, flavour="logf"):
     """Load a [4^k, 2] float32 (level_mean, level_stdv) table; returns (k, model_t[4^k])."""
     tab = np.fromfile(path, dtype=np.float32).reshape(-1, 2)
     k = int(round(math.log(len(tab), 4)))
     assert 4 ** k == len(tab)
-    return k, _finish(tab[:, 0], tab[:, 1])
+    return k, _finish(tab[:, 0], tab[:, 1], flavour)
 
 
 def read_model_text(path):
