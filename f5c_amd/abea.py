@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("ABEA_LIB_PATH", os.path.join(_HERE, "libabea_hip.so")
 
 EXPORTS = ["abea_init", "abea_init_multi", "abea_device_count", "abea_free", "abea_last_error", "abea_align_batch_host",
            "abea_align_batch_device", "abea_detect_events_device", "abea_get_stats", "abea_get_device_stats",
-           "abea_device_info", "abea_selftest", "abea_rsq_format", "abea_lpt_split"]
+           "abea_device_info", "abea_selftest", "abea_rsq_format", "abea_lpt_split", "abea_hmm_score_batch_host"]
 SHIM_EXPORTS = ["abea_f5c_init", "abea_f5c_align", "abea_f5c_align_scale", "abea_f5c_free"]      # include/abea_f5c_shim.h
 
 
@@ -75,9 +75,21 @@ class _SigBatch(C.Structure):
                 ("scalings", C.c_void_p)]
 
 
+class _Scal(C.Structure):
+    _fields_ = [("scale", C.c_float), ("shift", C.c_float), ("var", C.c_float), ("log_var", C.c_float)]
+
+
+class HmmJob(C.Structure):
+    """abea_hmm_job_t: one profile_hmm_score() call (hmm.c:689-735)."""
+    _fields_ = [("m_seq", C.c_char_p), ("m_rc_seq", C.c_char_p), ("events", C.c_void_p), ("scaling", _Scal),
+                ("event_start_idx", C.c_uint32), ("event_stop_idx", C.c_uint32), ("event_stride", C.c_int8),
+                ("rc", C.c_uint8), ("pad", C.c_uint16), ("hmm_flags", C.c_uint32), ("events_per_base", C.c_double)]
+
+
 class Stats(C.Structure):
     _fields_ = [("pre_ms", C.c_double), ("fill_ms", C.c_double), ("trace_ms", C.c_double),
                 ("h2d_ms", C.c_double), ("d2h_ms", C.c_double), ("host_ms", C.c_double), ("event_ms", C.c_double),
+                ("hmm_ms", C.c_double),
                 ("total_ms", C.c_double),
                 ("n_reads_gpu", C.c_int64), ("n_reads_skipped", C.c_int64), ("n_sub_batches", C.c_int64),
                 ("sum_events", C.c_int64), ("sum_bands", C.c_int64), ("sum_pairs", C.c_int64),
@@ -134,6 +146,8 @@ def load_library():
         L.abea_device_info.restype = C.c_int
         L.abea_device_info.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_int32),
                                        C.POINTER(C.c_uint64)]
+        L.abea_hmm_score_batch_host.restype = C.c_int
+        L.abea_hmm_score_batch_host.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_uint32, C.c_void_p]
         L.abea_selftest.restype = C.c_int
         L.abea_selftest.argtypes = [C.c_void_p]
         _LIB = L
@@ -297,6 +311,30 @@ class AbeaContext:
 
     def align_view(self, view):
         self._chk(self._lib.abea_align_batch_host(self._h, C.byref(view["hb"])), "abea_align_batch_host")
+
+    # ---- row N4: profile-HMM forward scores ----
+    def hmm_score_batch(self, jobs, cpgmodel, kmer_size):
+        """jobs: list of dicts(m_seq, m_rc_seq: bytes; events: EVENT_DT array (the read's table); scaling: 4 floats
+        (scale, shift, var, log_var); e_start, e_stop, stride, rc, events_per_base, flags) = the arguments of
+        profile_hmm_score (hmm.c:689-703).  Returns float32[n] scores."""
+        n = len(jobs)
+        arr = (HmmJob * max(1, n))()
+        keep = []
+        for j, jb in enumerate(jobs):
+            ev = np.ascontiguousarray(jb["events"], dtype=EVENT_DT)
+            keep.append(ev)
+            a = arr[j]
+            a.m_seq = jb["m_seq"]; a.m_rc_seq = jb["m_rc_seq"]; a.events = ev.ctypes.data
+            a.scaling = _Scal(*[float(x) for x in jb["scaling"]])
+            a.event_start_idx = int(jb["e_start"]); a.event_stop_idx = int(jb["e_stop"])
+            a.event_stride = int(jb["stride"]); a.rc = int(jb["rc"]); a.hmm_flags = int(jb.get("flags", 0))
+            a.events_per_base = float(jb["events_per_base"])
+        m = np.ascontiguousarray(cpgmodel, dtype=MODEL_DT)
+        assert len(m) == 5 ** kmer_size
+        out = np.zeros(max(1, n), dtype=np.float32)
+        self._chk(self._lib.abea_hmm_score_batch_host(self._h, C.cast(arr, C.c_void_p), n, _p(m), kmer_size, _p(out)),
+                  "abea_hmm_score_batch_host")
+        return out[:n]
 
     # ---- device-resident flattened batch ----
     @staticmethod

@@ -153,6 +153,7 @@ extern "C" void abea_free(abea_ctx* c) {
         hipSetDevice(c->device);
         if (c->stream) hipStreamSynchronize(c->stream);
         abea_host_release(c);
+        abea_hmm_release(c);
         hipFree(c->d_model); hipFree(c->arena);
         hipHostFree(c->h_desc);
         for (auto& e : c->ev) if (e) hipEventDestroy(e);

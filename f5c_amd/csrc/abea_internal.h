@@ -39,6 +39,7 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 /* ------------------------------------------------------------------ context */
 struct abea_host_pool;      /* abea_host.cpp: persistent host worker threads */
 struct abea_host_slot;      /* abea_host.cpp: one chunk in flight (stream, pinned staging, arena share) */
+struct abea_hmm_state;      /* abea_hmm.cpp: log-sum table, CpG model copy, staging of the profile-HMM entry (row N4) */
 
 struct abea_ctx {
     int device = 0;
@@ -55,12 +56,14 @@ struct abea_ctx {
     /* host-buffer entry (abea_host.cpp), created on first use */
     abea_host_pool* pool = nullptr;
     std::vector<abea_host_slot*> slots;
+    abea_hmm_state* hmm = nullptr;
     /* abea_init_multi: a parent context owns one child per device and no device state of its own */
     std::vector<abea_ctx*> children;
     abea_stats stats;
 };
 
 void abea_host_release(abea_ctx* c);       /* frees pool + slots (abea_host.cpp); called by abea_free */
+void abea_hmm_release(abea_ctx* c);        /* abea_hmm.cpp */
 
 /* ------------------------------------------------------------------ batch planning */
 struct plan_read {

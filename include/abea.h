@@ -186,12 +186,34 @@ int64_t abea_rsq_format(char* out, size_t cap, int fmt, const char* read_id, int
                         abea_index_pair_t* base_to_event_map, const abea_event_t* events, int64_t n_samples,
                         float scale, float shift, int rna);
 
+/* ---- profile-HMM forward scores (row N4): batches of profile_hmm_score() calls, src/hmm.c:689-735 ----
+ * One job = one call as calculate_methylation_for_read issues them (src/meth.c:473-474: the unmethylated and the
+ * methylated sequence of a CpG group against one read's events).  Argument meaning as in the reference; `strand` is
+ * ignored there (hmm.c:79 sets it to 0) and absent here.  The score is the table-driven (ESL_LOG_SUM) float forward
+ * log-probability, bit for bit.  Host pointers in, scores[n_jobs] out.  cpgmodel has 5^kmer_size entries (alphabet
+ * A,C,G,M,T, hmm.c:30-61), level_log_stdv cached as in model.c:179. */
+typedef struct {
+    const char* m_seq;                 /* HMMInputSequence: NUL-terminated, may hold 'M' (methylated C) */
+    const char* m_rc_seq;              /* its reverse complement (meth.c:366-400), same length */
+    const abea_event_t* events;        /* db->et[i].event of the read */
+    abea_scalings_t scaling;           /* db->scalings[i] (scale, shift, var, log_var all used: hmm.c:92-103) */
+    uint32_t event_start_idx, event_stop_idx;    /* inclusive; stop < start on the reverse strand (meth.c:457-462) */
+    int8_t   event_stride;             /* +1 / -1 */
+    uint8_t  rc;                       /* bam_is_rev */
+    uint16_t pad;
+    uint32_t hmm_flags;                /* HAF_ALLOW_PRE_CLIP = 1, HAF_ALLOW_POST_CLIP = 2 (f5cmisc.h:40-41) */
+    double   events_per_base;          /* db->events_per_base[i] */
+} abea_hmm_job_t;
+int abea_hmm_score_batch_host(abea_ctx* ctx, const abea_hmm_job_t* jobs, int32_t n_jobs, const abea_model_t* cpgmodel,
+                              uint32_t kmer_size, float* scores);
+
 /* ---- timing / accounting of the last batch (core_t timing fields, src/f5c.h:457-466) ---- */
 typedef struct {
     double pre_ms, fill_ms, trace_ms;     /* HIP-event kernel times on the library's stream, summed over sub-batches
                                              (fill = fused fill+traceback kernel, trace = optional scaling kernel) */
     double h2d_ms, d2h_ms, host_ms;       /* host batch only */
     double event_ms;                      /* abea_detect_events_device: kernel time of the last call */
+    double hmm_ms;                        /* abea_hmm_score_batch_host: kernel time of the last call */
     double total_ms;                      /* wall time of the call */
     int64_t n_reads_gpu, n_reads_skipped, n_sub_batches;
     int64_t sum_events, sum_bands, sum_pairs;

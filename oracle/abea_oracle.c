@@ -627,9 +627,11 @@ float orc_profile_hmm_score(const char* m_seq, const char* m_rc_seq, const orc_e
     float p_bb = p_bad_self, p_bk, p_bm_next, p_bm_self;
     p_bk = p_bm_next = p_bm_self = (1.0f - p_bb) / 3;
     float p_kk = p_skip_self, p_km = 1.0f - p_kk;
-    const float lp_mk = log(p_mk), lp_mb = log(p_mb), lp_mm_self = log(p_mm_self), lp_mm_next = log(p_mm_next);
-    const float lp_bb = log(p_bb), lp_bk = log(p_bk), lp_bm_next = log(p_bm_next), lp_bm_self = log(p_bm_self);
-    const float lp_kk = log(p_kk), lp_km = log(p_km);
+    /* hmm.c is compiled as C++ (reference Makefile:6 LANGFLAG = -x c++): log() of a float argument is the float overload,
+     * i.e. glibc logf, not (float)log((double)x) */
+    const float lp_mk = logf(p_mk), lp_mb = logf(p_mb), lp_mm_self = logf(p_mm_self), lp_mm_next = logf(p_mm_next);
+    const float lp_bb = logf(p_bb), lp_bk = logf(p_bk), lp_bm_next = logf(p_bm_next), lp_bm_self = logf(p_bm_self);
+    const float lp_kk = logf(p_kk), lp_km = logf(p_km);
     /* k-mer ranks (hmm.c:383-397) */
     uint32_t* ranks = (uint32_t*)malloc(sizeof(uint32_t) * n_kmers);
     const int32_t seq_len = (int32_t)strlen(m_seq);

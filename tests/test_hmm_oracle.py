@@ -15,7 +15,8 @@ def _cpg_model(k, seed):
     m = np.zeros(5 ** k, dtype=MODEL_DT)
     m["level_mean"] = np.clip(r.normal(90, 12, 5 ** k), 50, 140).astype(np.float32)
     m["level_stdv"] = r.uniform(1.2, 3.5, 5 ** k).astype(np.float32)
-    m["level_log_stdv"] = np.log(m["level_stdv"].astype(np.float64)).astype(np.float32)     # model.c caches log(stdv)
+    from f5c_amd.model import log_stdv
+    m["level_log_stdv"] = log_stdv(m["level_stdv"])                                         # model.c:179 caches logf(stdv)
     return m
 
 
@@ -60,7 +61,8 @@ def _twin(tbl, m_seq, m_rc_seq, ev, scaling, model, k, e_start, e_stop, stride, 
     n_ev = abs(int(e_stop) - int(e_start)) + 1
     p_stay = F(1 - (1 / epb))
     p_skip, p_bad, p_skip_self = F(0.0025), F(0.001), F(0.3)
-    lg = lambda p: F(np.log(np.float64(p)))
+    from f5c_amd.model import _libm
+    lg = lambda p: F(_libm.logf(float(p)))               # hmm.c is compiled as C++: log(float) is glibc logf
     lp_mk, lp_mb, lp_mm_self = lg(p_skip), lg(p_bad), lg(p_stay)
     lp_mm_next = lg(F(F(F(F(1.0) - p_stay) - p_skip) - p_bad))
     lp_bb = lg(p_bad)
