@@ -47,6 +47,8 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to exercise the N>1 path on one GPU)")
     ap.add_argument("--one-device", action="store_true", help="testing aid: every rank / context uses device 0")
+    ap.add_argument("--batch-cache", default="", help="np.savez cache of the generated batch (profiling runs: generate once, "
+                    "then reload under rocprofv3 without the forked generator pool)")
     ap.add_argument("--single-process", action="store_true", help="N GPUs from ONE process (abea_init_multi) instead of one rank per GPU")
     args = ap.parse_args()
 
@@ -72,7 +74,12 @@ def main():
     # ---- the batch: every rank builds only the reads it aligns ----
     t0 = time.time()
     workers = max(1, min(16, effective_cpus() // max(1, world)))
-    if world > 1 and args.scaling == "strong":
+    cache = f"{args.batch_cache}.{args.config}.{n_total}.r{rank}of{world}.npz" if args.batch_cache else ""
+    if cache and os.path.exists(cache):
+        z = np.load(cache)
+        batch = {k_: z[k_] for k_ in z.files}
+        batch["pair_cap"] = int(batch["pair_cap"])
+    elif world > 1 and args.scaling == "strong":
         # config 4: ONE batch, LPT-split on the band count; the read lengths are known before generation
         # (E is ~2.04 L for this generator, so 3L stands for E + K) and each rank generates just its shard
         L_all = synth.batch_lengths(n_total, cfg["seed"], cfg["law"])
@@ -82,6 +89,8 @@ def main():
         batch = synth.make_batch(n_total, model, k, seed=cfg["seed"] + 1000 * rank, law=cfg["law"], workers=workers)
     else:
         batch = synth.make_batch(n_total, model, k, seed=cfg["seed"], law=cfg["law"], workers=workers)
+    if cache and not os.path.exists(cache):
+        np.savez(cache, **batch)
     t_gen = time.time() - t0
     sum_events = int(batch["n_events"].sum())
     n_reads = len(batch["read_len"])

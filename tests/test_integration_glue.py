@@ -1,0 +1,64 @@
+"""The f5c-side glue printed in INTEGRATION.md, compile-checked against the REAL reference headers (src/f5c.h,
+src/f5cmisc.h) — build container only: /root/reference is absent on the GPU box.  htslib is not in the image, so
+opaque typedef stubs for the six htslib types f5c.h names are generated into a temp dir; nothing of this is committed
+or shipped, and nothing is linked or run (-fsyntax-only).  Also asserts the POD layouts the shim's casts rely on."""
+import os
+import re
+import subprocess
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+
+pytestmark = pytest.mark.skipif(not os.path.exists(os.path.join(REF, "src", "f5c.h")),
+                                reason="reference headers not mounted (GPU box)")
+
+LAYOUT = r'''
+#include <cstddef>
+#include "f5c.h"
+#include "f5cmisc.h"
+#include "abea_f5c_shim.h"
+// the casts in the glue: (abea_f5c_event_table*)db->et, (abea_scalings_t*)db->scalings, (abea_pair_t**)..., (const abea_model_t*)core->model
+static_assert(sizeof(event_table) == sizeof(abea_f5c_event_table), "event_table size (f5c.h:139-144)");
+static_assert(offsetof(event_table, n) == offsetof(abea_f5c_event_table, n), "event_table.n");
+static_assert(offsetof(event_table, start) == offsetof(abea_f5c_event_table, start), "event_table.start");
+static_assert(offsetof(event_table, end) == offsetof(abea_f5c_event_table, end), "event_table.end");
+static_assert(offsetof(event_table, event) == offsetof(abea_f5c_event_table, event), "event_table.event");
+static_assert(sizeof(event_t) == sizeof(abea_event_t) && offsetof(event_t, mean) == offsetof(abea_event_t, mean), "event_t (f5c.h:129-136)");
+static_assert(offsetof(event_t, start) == offsetof(abea_event_t, start) && offsetof(event_t, length) == offsetof(abea_event_t, length), "event_t");
+static_assert(sizeof(model_t) == sizeof(abea_model_t) && offsetof(model_t, level_stdv) == offsetof(abea_model_t, level_stdv), "model_t (f5c.h:147-155)");
+static_assert(offsetof(model_t, level_log_stdv) == offsetof(abea_model_t, level_log_stdv), "model_t needs CACHED_LOG");
+static_assert(sizeof(scalings_t) == sizeof(abea_scalings_t) && offsetof(scalings_t, shift) == offsetof(abea_scalings_t, shift), "scalings_t (f5c.h:158-172)");
+static_assert(offsetof(scalings_t, var) == offsetof(abea_scalings_t, var) && offsetof(scalings_t, log_var) == offsetof(abea_scalings_t, log_var), "scalings_t");
+static_assert(sizeof(AlignedPair) == sizeof(abea_pair_t) && offsetof(AlignedPair, read_pos) == offsetof(abea_pair_t, read_pos), "AlignedPair (f5c.h:181-184)");
+static_assert(sizeof(index_pair_t) == sizeof(abea_index_pair_t) && offsetof(index_pair_t, stop) == offsetof(abea_index_pair_t, stop), "index_pair_t (f5c.h:187-190)");
+static_assert(ALN_BANDWIDTH == ABEA_BANDWIDTH && MAX_KMER_SIZE == ABEA_MAX_KMER_SIZE, "compile-time constants (f5c.h:30,34)");
+static_assert(FAILED_CALIBRATION == ABEA_FAILED_CALIBRATION && FAILED_ALIGNMENT == ABEA_FAILED_ALIGNMENT &&
+              FAILED_QUALITY_CHK == ABEA_FAILED_QUALITY_CHK, "read_stat_flag bits (f5c.h:66-68)");
+// the prototypes the glue defines
+void (*p_init)(core_t*) = init_cuda;
+void (*p_free)(core_t*) = free_cuda;
+void (*p_align)(core_t*, db_t*) = align_cuda;
+'''
+
+
+def test_glue_compiles_against_the_reference_headers(tmp_path):
+    stub = tmp_path / "stub" / "htslib"
+    stub.mkdir(parents=True)
+    (stub / "hts.h").write_text("#pragma once\ntypedef struct htsFile htsFile; typedef struct hts_idx_t hts_idx_t; "
+                                "typedef struct hts_itr_t hts_itr_t;\n")
+    (stub / "sam.h").write_text("#pragma once\ntypedef struct htsFile samFile; typedef struct bam1_t bam1_t; "
+                                "typedef struct bam_hdr_t bam_hdr_t; typedef struct sam_hdr_t sam_hdr_t;\n")
+    (stub / "faidx.h").write_text("#pragma once\ntypedef struct faidx_t faidx_t;\n")
+    md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    m = re.search(r"```c\n(// src/abea_glue\.c.*?)```", md, re.S)
+    assert m, "INTEGRATION.md lost its glue block"
+    (tmp_path / "abea_glue.c").write_text(m.group(1))
+    (tmp_path / "layout.cpp").write_text(LAYOUT)
+    inc = ["-I", str(tmp_path / "stub"), "-I", os.path.join(REF, "src"), "-I", os.path.join(REF, "slow5lib", "include"),
+           "-I", os.path.join(ROOT, "include")]
+    # the reference compiles its .c files as C++11 with HAVE_CUDA on the GPU build (Makefile:5-8, 40-46)
+    base = ["g++", "-x", "c++", "-std=c++11", "-fsyntax-only", "-DHAVE_CUDA=1", "-Wall", "-Werror=return-type"]
+    for src in ("abea_glue.c", "layout.cpp"):
+        r = subprocess.run(base + inc + [str(tmp_path / src)], capture_output=True, text=True)
+        assert r.returncode == 0, f"{src}:\n{r.stderr[-3000:]}"
