@@ -375,6 +375,9 @@ class AbeaContext:
             sc = [_p(dbatch["kmer_ptr"]), dbatch["b2e"].data_ptr(), dbatch["scalings_io"].data_ptr(),
                   dbatch["events_per_base"].data_ptr(), dbatch["read_stat_flag"].data_ptr(),
                   dbatch["n_event_alignment"].data_ptr(), 0, 0]
+        # the library launches on its own non-blocking streams: everything torch queued on the current stream for these
+        # buffers (uploads, fills) must have finished before the library's kernels read or OR into them
+        torch.cuda.current_stream().synchronize()
         db = _DevBatch(dbatch["n_reads"], _p(dbatch["read_ptr"]), _p(dbatch["read_len"]),
                        _p(dbatch["event_ptr"]), _p(dbatch["n_events"]), _p(dbatch["pair_ptr"]),
                        _p(dbatch["scalings"]),
@@ -410,6 +413,7 @@ class AbeaContext:
                 flat[rp[i]:rp[i] + rl[i]] = np.frombuffer(s, dtype=np.uint8)
             d_reads = torch.from_numpy(flat).to(dev)
             d_scal = torch.zeros(n * SCAL_DT.itemsize, dtype=torch.uint8, device=dev)
+        torch.cuda.current_stream().synchronize()        # see align_db_device: the library's streams do not order with torch's
         sb = _SigBatch(n, _p(sig_ptr), _p(ns), _p(sc), _p(ev_ptr), _p(cap), _p(rp) if rp is not None else None,
                        _p(rl) if rl is not None else None, d_sig.data_ptr(),
                        d_reads.data_ptr() if d_reads is not None else None, d_ev.data_ptr(), d_ne.data_ptr(),
@@ -418,12 +422,22 @@ class AbeaContext:
         return dict(n=n, cap=cap, ev_ptr=ev_ptr, read_ptr=rp, read_len=rl, d_ev=d_ev, d_ne=d_ne, d_scal=d_scal,
                     d_reads=d_reads)
 
+    @staticmethod
+    def _check_event_cap(n_events, cap):
+        """A read with more events than its table holds would be aligned on a cut-off table (and its method-of-moments
+        scalings would mix the truncated sum with the true count): refuse instead of truncating silently."""
+        over = np.nonzero(n_events > cap)[0]
+        if len(over):
+            raise AbeaError(f"event detection found more events than event_cap on {len(over)} read(s) (first: read "
+                            f"{int(over[0])}: {int(n_events[over[0]])} > {int(cap[over[0]])}); call again with a smaller cap_div")
+
     def detect_events_device(self, signals, scaling, seqs=None, cap_div=4):
         """Row N2: raw ADC signals -> event tables (+ method-of-moments scalings when `seqs` is given) on the
         device. signals: list of int16 arrays; scaling: float32 [n,3] (offset, range, digitisation).
         Returns (list of EVENT_DT arrays, n_events int32[n], scalings SCAL_DT[n] or None)."""
         r = self._detect(signals, scaling, seqs, cap_div)
         ne = r["d_ne"].cpu().numpy()
+        self._check_event_cap(ne, r["cap"])
         allev = r["d_ev"].cpu().numpy().view(EVENT_DT)
         evs = [allev[r["ev_ptr"][i]:r["ev_ptr"][i] + min(ne[i], r["cap"][i])] for i in range(r["n"])]
         return evs, ne, (r["d_scal"].cpu().numpy().view(SCAL_DT) if r["d_scal"] is not None else None)
@@ -435,6 +449,7 @@ class AbeaContext:
         import torch
         r = self._detect(signals, scaling, seqs, cap_div)
         n = r["n"]
+        self._check_event_cap(r["d_ne"].cpu().numpy(), r["cap"])
         ne = np.minimum(r["d_ne"].cpu().numpy(), r["cap"]).astype(np.int32)
         cap_pairs = ne.astype(np.int64) + r["read_len"].astype(np.int64)
         dev = r["d_ev"].device

@@ -156,7 +156,11 @@ int abea_align_batch_device(abea_ctx* ctx, const abea_device_batch* batch);
 /* ---- raw-signal batch: the front half of event_single() on the device (src/f5c.c:682-712; row N2) ----
  * ADC samples -> pA -> getevents() (src/events.c:562-582) -> estimate_scalings_using_mom() (src/align.c:58-106).
  * Index / scaling arrays are HOST pointers, bulk arrays DEVICE pointers.  Events of read i are written at
- * events[event_ptr[i] ...] up to event_cap[i] entries; n_events[i] is the true count (> cap means truncated). */
+ * events[event_ptr[i] ...] up to event_cap[i] entries; n_events[i] is the true count (> cap means truncated: the caller
+ * must re-run that read with a larger table, a truncated table is not a valid input of the alignment).
+ * DNA only: the detector runs with event_detection_defaults (src/events.c:52-58: windows 3 / 6, thresholds 1.4 / 9.0,
+ * peak height 0.2); getevents()'s RNA branch (event_detection_rna, events.c:59-65,575-577) and event_single()'s RNA event
+ * reversal (f5c.c:711-719) are not implemented — RNA reads must keep using the host getevents(). */
 typedef struct {
     int32_t n_reads;
     const int64_t* sig_ptr;        /* HOST: offset of read i in `signal` (samples); multiples of 8 are fastest (16-byte loads) */

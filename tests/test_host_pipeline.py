@@ -257,3 +257,33 @@ def test_cpp_caller_nsample_multi_device_and_fused(orc, r9, tmp_path):
                 assert np.float32(float.fromhex(f[6])) == r["scalings"]["var"]
         else:
             assert f[7].strip() == "NULL"                      # f5c.c:787 base_to_event_map[i] = NULL
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_and_single_process_two_contexts(tmp_path):
+    """bench.py's N>1 paths on the GPU box: two ranks under torch.distributed.run (strong scaling of ONE batch, each
+    rank generating only its LPT shard; gloo + both ranks on device 0 because the box has one GPU), and one process
+    driving two device contexts through abea_init_multi.  Both must account for every event of the whole batch."""
+    import json
+    import sys
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--config", "r9_10k_8kb", "--reads", "1500", "--steps", "2",
+            "--warmup", "1", "--one-device", "--arena-gib", "8", "--no-cpu-baseline", "--no-small-batch", "--mode", "host"]
+    one = subprocess.run(base + ["--gpus", "1"], capture_output=True, text=True, env=env, timeout=600)
+    assert one.returncode == 0, one.stderr[-2000:]
+    ref = json.loads(one.stdout.strip().splitlines()[-1])
+    port = 29600 + os.getpid() % 300
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port)] + base[1:] +
+                         ["--gpus", "2", "--backend", "gloo"], capture_output=True, text=True, env=env, timeout=600)
+    assert two.returncode == 0, two.stderr[-2000:]
+    j2 = json.loads([ln for ln in two.stdout.splitlines() if ln.startswith("{")][-1])
+    sp = subprocess.run(base + ["--gpus", "2", "--single-process"], capture_output=True, text=True, env=env, timeout=600)
+    assert sp.returncode == 0, sp.stderr[-2000:]
+    j3 = json.loads(sp.stdout.strip().splitlines()[-1])
+    for j in (j2, j3):
+        assert j["n_gpus"] == 2 and j["scaling"] == "strong" and j["value"] > 0
+        assert j["config"]["events"] == ref["config"]["events"] and j["config"]["reads"] == 1500
+        assert abs(j["qc_pass_frac"] - ref["qc_pass_frac"]) < 1e-9
+    assert j2["config"]["events_rank0"] < 0.6 * ref["config"]["events"]          # rank 0 holds its shard only
+    assert j3["host_to_host"]["devices"] == 2

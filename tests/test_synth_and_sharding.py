@@ -55,13 +55,16 @@ def _worker(rank, world, port, out):
     from oracle import orc
     dist.init_process_group("gloo", rank=rank, world_size=world)
     k, model = load_model_f32(os.path.join(ROOT, "tests", "golden", "r9.4_450bps.6mer.f32"))
-    full = synth.make_batch(24, model, k, seed=8, law=1200, bad_frac=0.1)
-    sub, idx = synth.shard_batch(full, rank, world)
-    # the CPU checker stands in for the per-rank GPU call here; the sharding / gather logic is what is tested
+    # as bench.py does for config 4: split on the read lengths BEFORE generating, then build only this rank's reads
+    L_all = synth.batch_lengths(24, 8, "loguniform")
+    idx = np.nonzero(synth.lpt_bins(3 * L_all, world) == rank)[0]
+    sub = synth.make_batch(24, model, k, seed=8, law="loguniform", bad_frac=0.1, subset=idx)
+    # the CPU checker stands in for the per-rank GPU call here (tests/test_host_pipeline.py runs the real bench with
+    # 2 ranks on the GPU box); the sharding / gather logic is what is tested
     _, n_pairs, _ = orc.align_batch(sub, model, k, n_threads=2, want_diag=False)
     stats = dist_util.gather_stats(dict(elapsed=0.01 * (rank + 1), events=float(sub["n_events"].sum()),
                                         reads=float(len(idx)), pairs=float(n_pairs.sum())), device="cpu")
-    allp = dist_util.gather_per_read(idx, n_pairs, len(full["read_len"]), device="cpu")
+    allp = dist_util.gather_per_read(idx, n_pairs, len(L_all), device="cpu")
     if rank == 0:
         np.save(out, np.concatenate([[stats["t_max"], stats["events"], stats["reads"], stats["pairs"]], allp]))
     dist.barrier()
@@ -76,7 +79,7 @@ def test_two_rank_gloo_shard_and_gather(r9, orc, tmp_path):
     port = 29500 + (os.getpid() % 2000)
     mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
     res = np.load(out)
-    full = synth.make_batch(24, model, k, seed=8, law=1200, bad_frac=0.1)
+    full = synth.make_batch(24, model, k, seed=8, law="loguniform", bad_frac=0.1)     # shards built alone == slices of the whole
     _, n_pairs, _ = orc.align_batch(full, model, k, n_threads=4, want_diag=False)
     assert res[0] == pytest.approx(0.02)                   # MAX over ranks
     assert res[1] == full["n_events"].sum() and res[2] == 24 and res[3] == n_pairs.sum()
