@@ -346,8 +346,13 @@ static int host_run(abea_ctx* c, const abea_host_batch* H, const int32_t* mine, 
             }
         }
     }
-    std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) {
-        return S.reads[(size_t)a].n_bands > S.reads[(size_t)b].n_bands; });
+    {   /* longest first, ties in caller order: sort packed (band count, inverted position) keys, no indirection */
+        std::vector<uint64_t> key(order.size());
+        for (size_t t = 0; t < order.size(); ++t)
+            key[t] = ((uint64_t)S.reads[(size_t)order[t]].n_bands << 32) | (uint32_t)(0xFFFFFFFFu - (uint32_t)order[t]);
+        std::sort(key.begin(), key.end(), std::greater<uint64_t>());
+        for (size_t t = 0; t < order.size(); ++t) order[t] = (int32_t)(0xFFFFFFFFu - (uint32_t)key[t]);
+    }
 
     /* device + pinned bytes one read adds to a chunk besides scratch_bytes() */
     auto io_bytes = [&](const plan_read& r) {
