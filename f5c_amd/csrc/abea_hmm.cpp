@@ -2,6 +2,7 @@
  * meth.c:473-474: two per CpG group and read) scored on the GPU.  Builds the job descriptors (per-job transition
  * log-probabilities exactly as calculate_transitions does, hmm.c:240-310), flattens the event windows and sequences
  * into pinned memory, runs abea_hmm_forward_kernel and copies the scores back.  No CPU scoring fallback. */
+#include <atomic>
 #include <cmath>
 #include <numeric>
 #include "abea_internal.h"
@@ -58,19 +59,25 @@ extern "C" int abea_hmm_score_batch_host(abea_ctx* c, const abea_hmm_job_t* jobs
     std::vector<int32_t> seq_len((size_t)n_jobs), n_ev((size_t)n_jobs);
     size_t tot_ev = 0, tot_seq = 0, tot_col = 0;
     int32_t max_ev = 0, n16 = 0;
+    std::atomic<int32_t> bad_job{-1};
+    abea_parallel_for(c, n_jobs, 2048, [&](int64_t lo, int64_t hi) {
+        for (int64_t j = lo; j < hi; ++j) {
+            const abea_hmm_job_t& J = jobs[j];
+            seq_len[(size_t)j] = -1; n_ev[(size_t)j] = 0;
+            if (!J.m_seq || !J.m_rc_seq || !J.events) { bad_job.store((int32_t)j); continue; }
+            const size_t L = strlen(J.m_seq);
+            if (L < kmer_size || L > (1u << 20) ||
+                (J.rc && J.event_stride != -1) || (!J.rc && J.event_stride != 1)) { bad_job.store((int32_t)j); continue; }   /* hmm.c:331 assert */
+            seq_len[(size_t)j] = (int32_t)L;
+            n_ev[(size_t)j] = (int32_t)(J.event_stop_idx > J.event_start_idx ? J.event_stop_idx - J.event_start_idx + 1
+                                                                              : J.event_start_idx - J.event_stop_idx + 1);   /* hmm.c:649-654 */
+        }
+    });
+    if (bad_job.load() >= 0)
+        return abea_fail(ABEA_EINVAL, "job %d: null pointer, sequence shorter than k or longer than 1 Mbase, or rc / event_stride mismatch", bad_job.load());
     for (int32_t j = 0; j < n_jobs; ++j) {
-        const abea_hmm_job_t& J = jobs[j];
-        if (!J.m_seq || !J.m_rc_seq || !J.events) return abea_fail(ABEA_EINVAL, "job %d: null pointer", j);
-        const size_t L = strlen(J.m_seq);
-        if (L < kmer_size || L > (1u << 20)) return abea_fail(ABEA_EINVAL, "job %d: sequence length %zu", j, L);
-        if ((J.rc && J.event_stride != -1) || (!J.rc && J.event_stride != 1))               /* hmm.c:331 assert */
-            return abea_fail(ABEA_EINVAL, "job %d: rc %d with event_stride %d", j, (int)J.rc, (int)J.event_stride);
-        seq_len[(size_t)j] = (int32_t)L;
-        const uint32_t ne = J.event_stop_idx > J.event_start_idx ? J.event_stop_idx - J.event_start_idx + 1
-                                                                 : J.event_start_idx - J.event_stop_idx + 1;   /* hmm.c:649-654 */
-        n_ev[(size_t)j] = (int32_t)ne;
-        max_ev = std::max(max_ev, (int32_t)ne);
-        n16 += (L - kmer_size + 1) <= 16;
+        max_ev = std::max(max_ev, n_ev[(size_t)j]);
+        n16 += ((size_t)seq_len[(size_t)j] - kmer_size + 1) <= 16;
     }
     {
         int32_t a = 0, b = n16;
@@ -79,9 +86,8 @@ extern "C" int abea_hmm_score_batch_host(abea_ctx* c, const abea_hmm_job_t* jobs
         }
     }
     std::vector<abea_hmm_job> desc((size_t)n_jobs);
-    for (int32_t q = 0; q < n_jobs; ++q) {
+    for (int32_t q = 0; q < n_jobs; ++q) {                           /* offsets: serial prefix sums */
         const int32_t j = order[(size_t)q];
-        const abea_hmm_job_t& J = jobs[j];
         abea_hmm_job& d = desc[(size_t)q];
         memset(&d, 0, sizeof d);
         d.ev_off = (int64_t)tot_ev;   tot_ev += align_up((size_t)n_ev[(size_t)j], 4);
@@ -89,19 +95,26 @@ extern "C" int abea_hmm_score_batch_host(abea_ctx* c, const abea_hmm_job_t* jobs
         d.seq_len = seq_len[(size_t)j]; d.n_events = n_ev[(size_t)j];
         const size_t nk = (size_t)d.seq_len - kmer_size + 1;
         d.col_off = (int64_t)tot_col; if (nk > 64) tot_col += 3 * ((size_t)d.n_events + 1);
-        d.rc = J.rc ? 1 : 0; d.flags = J.hmm_flags; d.out_idx = j;
-        d.scale = J.scaling.scale; d.shift = J.scaling.shift; d.var = J.scaling.var; d.log_var = J.scaling.log_var;
-        /* calculate_transitions (hmm.c:240-310); hmm.c is compiled as C++ (Makefile:6), so log() of a float is logf */
-        float p_stay = 1 - (1 / J.events_per_base);
-        float p_skip = 0.0025, p_bad = 0.001, p_bad_self = p_bad, p_skip_self = 0.3;
-        float p_mk = p_skip, p_mb = p_bad, p_mm_self = p_stay, p_mm_next = 1.0f - p_mm_self - p_mk - p_mb;
-        float p_bb = p_bad_self, p_bk, p_bm_next, p_bm_self;
-        p_bk = p_bm_next = p_bm_self = (1.0f - p_bb) / 3;
-        float p_kk = p_skip_self, p_km = 1.0f - p_kk;
-        d.lp_mk = logf(p_mk); d.lp_mb = logf(p_mb); d.lp_mm_self = logf(p_mm_self); d.lp_mm_next = logf(p_mm_next);
-        d.lp_bb = logf(p_bb); d.lp_bk = logf(p_bk); d.lp_bm_next = logf(p_bm_next); d.lp_bm_self = logf(p_bm_self);
-        d.lp_kk = logf(p_kk); d.lp_km = logf(p_km);
+        d.out_idx = j;
     }
+    abea_parallel_for(c, n_jobs, 2048, [&](int64_t lo, int64_t hi) {
+        for (int64_t q = lo; q < hi; ++q) {
+            const abea_hmm_job_t& J = jobs[order[(size_t)q]];
+            abea_hmm_job& d = desc[(size_t)q];
+            d.rc = J.rc ? 1 : 0; d.flags = J.hmm_flags;
+            d.scale = J.scaling.scale; d.shift = J.scaling.shift; d.var = J.scaling.var; d.log_var = J.scaling.log_var;
+            /* calculate_transitions (hmm.c:240-310); hmm.c is compiled as C++ (Makefile:6), so log() of a float is logf */
+            float p_stay = 1 - (1 / J.events_per_base);
+            float p_skip = 0.0025, p_bad = 0.001, p_bad_self = p_bad, p_skip_self = 0.3;
+            float p_mk = p_skip, p_mb = p_bad, p_mm_self = p_stay, p_mm_next = 1.0f - p_mm_self - p_mk - p_mb;
+            float p_bb = p_bad_self, p_bk, p_bm_next, p_bm_self;
+            p_bk = p_bm_next = p_bm_self = (1.0f - p_bb) / 3;
+            float p_kk = p_skip_self, p_km = 1.0f - p_kk;
+            d.lp_mk = logf(p_mk); d.lp_mb = logf(p_mb); d.lp_mm_self = logf(p_mm_self); d.lp_mm_next = logf(p_mm_next);
+            d.lp_bb = logf(p_bb); d.lp_bk = logf(p_bk); d.lp_bm_next = logf(p_bm_next); d.lp_bm_self = logf(p_bm_self);
+            d.lp_kk = logf(p_kk); d.lp_km = logf(p_km);
+        }
+    });
     /* pre_flank (hmm.c:188-233); post_flank[i] = pre_flank[n_events-1-i] term by term (hmm.c:141-185) */
     std::vector<float> flank((size_t)max_ev + 1);
     flank[0] = log(1 - 0.5);
@@ -122,14 +135,16 @@ extern "C" int abea_hmm_score_batch_host(abea_ctx* c, const abea_hmm_job_t* jobs
     if (rc) return rc;
     memcpy(S->pin + o_desc, desc.data(), (size_t)n_jobs * sizeof(abea_hmm_job));
     memcpy(S->pin + o_flank, flank.data(), flank.size() * 4);
-    for (int32_t q = 0; q < n_jobs; ++q) {
-        const abea_hmm_job_t& J = jobs[order[(size_t)q]];
-        const abea_hmm_job& d = desc[(size_t)q];
-        memcpy(S->pin + o_seq + d.seq_off, d.rc ? J.m_rc_seq : J.m_seq, (size_t)d.seq_len + 1);
-        float* w = (float*)(S->pin + o_ev) + d.ev_off;
-        for (int32_t r = 0; r < d.n_events; ++r)                       /* event_idx = e_start + (row-1)*stride, hmm.c:432 */
-            w[r] = J.events[(int64_t)J.event_start_idx + (int64_t)r * J.event_stride].mean;
-    }
+    abea_parallel_for(c, n_jobs, 1024, [&](int64_t lo, int64_t hi) {
+        for (int64_t q = lo; q < hi; ++q) {
+            const abea_hmm_job_t& J = jobs[order[(size_t)q]];
+            const abea_hmm_job& d = desc[(size_t)q];
+            memcpy(S->pin + o_seq + d.seq_off, d.rc ? J.m_rc_seq : J.m_seq, (size_t)d.seq_len + 1);
+            float* w = (float*)(S->pin + o_ev) + d.ev_off;
+            for (int32_t r = 0; r < d.n_events; ++r)                   /* event_idx = e_start + (row-1)*stride, hmm.c:432 */
+                w[r] = J.events[(int64_t)J.event_start_idx + (int64_t)r * J.event_stride].mean;
+        }
+    });
     uint8_t* dev = c->arena;
     HIP_TRY(hipMemcpyAsync(dev, S->pin, up_bytes, hipMemcpyHostToDevice, c->stream));
     const int blocks16 = (n16 + 15) / 16, blocks64 = (n_jobs - n16 + 3) / 4;

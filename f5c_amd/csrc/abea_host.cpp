@@ -136,6 +136,20 @@ static int slot_create(abea_host_slot** out) {
     return ABEA_OK;
 }
 
+int abea_default_host_threads() {
+    /* leave two of the CPUs this process may use to the HIP runtime's own threads: under a cgroup CPU quota a pool as
+     * wide as the quota gets the whole process throttled (measured on the GPU box, DESIGN.md §6) */
+    const int cpus = effective_cpus();
+    int threads = std::min(16, cpus > 4 ? cpus - 2 : cpus);
+    if (const char* e = getenv("ABEA_HOST_THREADS")) threads = std::max(1, atoi(e));
+    return threads;
+}
+
+void abea_parallel_for(abea_ctx* c, int64_t n, int64_t grain, const std::function<void(int64_t, int64_t)>& f) {
+    if (!c->pool) c->pool = new abea_host_pool(abea_default_host_threads());
+    c->pool->run(n, grain, f);
+}
+
 void abea_host_release(abea_ctx* c) {
     for (abea_host_slot* s : c->slots) {
         if (!s) continue;
@@ -598,11 +612,7 @@ extern "C" int abea_align_batch_host(abea_ctx* c, const abea_host_batch* H) {
     if (!H->pairs && !H->base_to_event_map)
         return abea_fail(ABEA_EINVAL, "abea_align_batch_host: neither pairs nor base_to_event_map requested");
     const double t_start = abea_now_ms();
-    /* leave two of the CPUs this process may use to the HIP runtime's own threads: under a cgroup CPU quota a pool as
-     * wide as the quota gets the whole process throttled (measured on the GPU box, DESIGN.md §6) */
-    const int cpus = effective_cpus();
-    int threads = std::min(16, cpus > 4 ? cpus - 2 : cpus);
-    if (const char* e = getenv("ABEA_HOST_THREADS")) threads = std::max(1, atoi(e));
+    const int threads = abea_default_host_threads();
     if (c->children.empty()) {
         abea_stats st;
         const int rc = host_run(c, H, nullptr, n, threads, &st);

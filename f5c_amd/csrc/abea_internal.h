@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <vector>
 #include "abea_device.h"
 
@@ -64,6 +65,10 @@ struct abea_ctx {
 
 void abea_host_release(abea_ctx* c);       /* frees pool + slots (abea_host.cpp); called by abea_free */
 void abea_hmm_release(abea_ctx* c);        /* abea_hmm.cpp */
+/* run f(lo, hi) over [0, n) in pieces of `grain` items on the context's persistent worker pool (created on first use;
+ * the caller's thread takes part) — abea_host.cpp */
+void abea_parallel_for(abea_ctx* c, int64_t n, int64_t grain, const std::function<void(int64_t, int64_t)>& f);
+int abea_default_host_threads();
 
 /* ------------------------------------------------------------------ batch planning */
 struct plan_read {
