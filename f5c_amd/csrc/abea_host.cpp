@@ -183,6 +183,13 @@ static void expand_codes(const uint32_t* codes, int32_t n, int32_t k, int32_t e,
     }
 }
 
+/* host-only entry over the same routine, so that the expansion can be unit-tested without a GPU */
+extern "C" int abea_expand_walk_codes(const uint32_t* codes, int32_t n_steps, int32_t last_kmer, int32_t end_event, abea_pair_t* out) {
+    if (n_steps < 0 || (n_steps && (!codes || !out))) return abea_fail(ABEA_EINVAL, "abea_expand_walk_codes: bad argument");
+    expand_codes(codes, n_steps, last_kmer, end_event, out);
+    return ABEA_OK;
+}
+
 struct host_opts {
     size_t chunk_events;
     int32_t chunk_reads_min, chunk_reads_max;

@@ -240,6 +240,10 @@ int abea_get_device_stats(abea_ctx* ctx, int32_t device, abea_stats* out);
  * (one process per GPU): reads in descending weight (band count n_events + n_kmers + 2; <= 0 for reads the guards skip)
  * go to the currently lightest of n_bins bins, ties to the lowest bin.  Host-only, needs no context. */
 int abea_lpt_split(const int64_t* weight, int32_t n, int32_t n_bins, int32_t* bin_of);
+/* The un-flatten step of the host entry on its own (host-only): the traceback walk as it crosses PCIe — 2 bits per
+ * step, 16 steps per word, step 0 = the end cell (last_kmer, end_event); 0 = diagonal, 1 = up (event only), 2 = left
+ * (k-mer only) — expanded into the ascending (ref_pos, read_pos) list align() returns (src/align.c:452-513). */
+int abea_expand_walk_codes(const uint32_t* codes, int32_t n_steps, int32_t last_kmer, int32_t end_event, abea_pair_t* out);
 
 /* Library / device introspection: "gfx950", CU count; used by tests to assert the native path ran. */
 int abea_device_info(abea_ctx* ctx, char* arch, size_t arch_len, int32_t* n_cu, uint64_t* arena_bytes);

@@ -53,6 +53,51 @@ def test_lpt_split_is_the_sharding_rule(r9):
     assert lib.abea_lpt_split(None, 3, 2, bins.ctypes.data) != 0
 
 
+def test_walk_code_expansion_matches_the_traceback(orc, r9):
+    """abea_expand_walk_codes (what the host entry's un-flatten does with the 2-bit walk that crosses PCIe) rebuilds
+    the oracle's pair list from the moves of that list, for real alignments and for hand-made corner cases."""
+    import ctypes
+    from f5c_amd import abea, synth
+    from f5c_amd.types import PAIR_DT
+    k, model = r9
+    lib = abea.load_library()
+    lib.abea_expand_walk_codes.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]
+
+    def roundtrip(pairs):
+        p = np.asarray(pairs).view(np.int32).reshape(-1, 2).astype(np.int64)
+        n = len(p)
+        # walk order = last pair first; code of step j = the move from pair n-1-j to pair n-2-j
+        dk = p[1:, 0] - p[:-1, 0]; de = p[1:, 1] - p[:-1, 1]
+        assert ((dk | de) == 1).all() and (dk >= 0).all() and (de >= 0).all()
+        code = np.where((dk == 1) & (de == 1), 0, np.where(de == 1, 1, 2))[::-1]      # 0 diagonal, 1 up, 2 left
+        code = np.concatenate([code, [3]])                     # the last step's code is never applied to a pair
+        words = np.zeros((n + 15) // 16 + 1, dtype=np.uint32)
+        for j, c in enumerate(code):
+            words[j >> 4] |= np.uint32(int(c) << (2 * (j & 15)))
+        out = np.zeros(n + 2, dtype=PAIR_DT)
+        out["ref_pos"][-1] = -7                                # canary
+        assert lib.abea_expand_walk_codes(words.ctypes.data, n, int(p[-1, 0]), int(p[-1, 1]), out.ctypes.data) == 0
+        got = out.view(np.int32).reshape(-1, 2)
+        assert (got[:n] == p).all() and got[n + 1, 0] == -7
+
+    batch = synth.make_batch(12, model, k, seed=3, law=900, bad_frac=0.0)
+    o_pairs, o_n, _ = orc.align_batch(batch, model, k, n_threads=2)
+    done = 0
+    for i in range(12):
+        if o_n[i] > 0:
+            s = int(batch["pair_ptr"][i])
+            roundtrip(o_pairs[s:s + o_n[i]])
+            done += 1
+    assert done >= 8
+    for n in (1, 2, 15, 16, 17, 31, 32, 33, 1024, 1025):       # word boundaries
+        steps = np.random.default_rng(n).integers(0, 3, n - 1)
+        p = np.zeros((n, 2), dtype=np.int32)
+        for j, c in enumerate(steps):
+            p[j + 1] = p[j] + [(1, 1), (0, 1), (1, 0)][c]
+        roundtrip(p.copy().view(PAIR_DT).ravel())
+    assert lib.abea_expand_walk_codes(None, 0, 0, 0, None) == 0 and lib.abea_expand_walk_codes(None, 3, 0, 0, None) != 0
+
+
 # ---------------------------------------------------------------- GPU
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode", ["codes", "device"])
