@@ -31,9 +31,14 @@ EXPERIMENT = VB != 64 or TIED
 MF0, MF1, SHR, SHD = VB + 0, VB + 1, VB + 2, VB + 3
 TR = [dict(c0=VB + 4, c1=VB + 6, cs=VB + 8), dict(c0=VB + 10, c1=VB + 12, cs=VB + 14)]
 X0, X1 = VB + 16, VB + 17
-G0, C0, G1, C1 = VB + 18, VB + 19, VB + 20, VB + 21
-I0, I1 = VB + 22, VB + 24
-NK = VB + 26       # v[90:93] = incoming k-mer {gpm, ck, istd}
+# k-mer parameter quads {gpm, ck, istd lo, istd hi} (the layout of abea_kpar_t, so ds_read_b128 lands one whole):
+# the roles "cell 0", "cell 1", "incoming k-mer" ROTATE over the three quads with every right move (state rs =
+# number of right moves mod 3: cell 0 = KQ[rs], cell 1 = KQ[rs+1], incoming = KQ[rs+2]), so a right move is four DPP
+# shifts into the incoming quad and no register-to-register moves; rs = 0 is the layout at entry / exit.
+KQ = [VB + 18, VB + 22, VB + 26]
+G0, C0, I0 = KQ[0], KQ[0] + 1, KQ[0] + 2
+G1, C1, I1 = KQ[1], KQ[1] + 1, KQ[1] + 2
+NK = KQ[2]         # v[90:93] = incoming k-mer {gpm, ck, istd} at rs = 0
 NX = VB + 30
 EPEND = VB + 31
 KPEND = VB + 32    # v[96:99]
@@ -97,10 +102,10 @@ DPP_SHL = "wave_shl:1 row_mask:0xf bank_mask:0xf"
 DPP_SHR = "wave_shr:1 row_mask:0xf bank_mask:0xf"
 
 
-def cell_ops(j, D, U, L):
-    """Instruction list for cell j (0/1); D,U,L = first register of the f64 pairs."""
+def cell_ops(j, D, U, L, quad):
+    """Instruction list for cell j (0/1); D,U,L = first register of the f64 pairs; quad = the cell's k-mer quad."""
     x = X0 + j
-    g, ck, i = (G0, C0, I0) if j == 0 else (G1, C1, I1)
+    g, ck, i = quad, quad + 1, quad + 2
     lpd, td, tu = LPD[j], TD[j], TU[j]
     t32 = td          # 32-bit scratch: low half of td before td is used
     sd, su, sl = td, tu, lpd   # after the adds the pair's low dword holds the float result (cvt in place)
@@ -159,49 +164,47 @@ def interleave(a, b):
     return res
 
 
-def decide(p_next, m_last):
+def decide(p_next, m_last, rs):
     """Tail of a band (or the entry stub): pick the move of the NEXT band and jump to its body.
     Expects: %[t0] = readlane(mf0, lane 0) already issued, vcc = (t0 < mf1) per lane already issued."""
     tag = f"{p_next}{m_last}"
     emit("s_cmp_eq_u32 %[b], %[b_end]")
-    emit(f"s_cbranch_scc1 exit_{tag}_%=")
+    emit(f"s_cbranch_scc1 exit_{tag}{rs}_%=")
     emit("s_bitcmp1_b32 vcc_hi, 17")                     # lane 49: ll < ur  -> right (align.c:313); -inf < finite too
-    emit(f"s_cbranch_scc1 body_{tag}R_%=")
+    emit(f"s_cbranch_scc1 body_{tag}R{rs}_%=")
     emit("s_cmp_eq_u32 %[t0], 0xff800000")               # not (ll < ur): both may be -inf
-    emit(f"s_cbranch_scc1 llinf_{tag}_{newid()}_%=")
-    lbl = f"llinf_{tag}_{lbl_id[0]}_%="
-    emit(f"s_branch body_{tag}D_%=")
+    emit(f"s_cbranch_scc1 llinf_{tag}{rs}_{newid()}_%=")
+    lbl = f"llinf_{tag}{rs}_{lbl_id[0]}_%="
+    emit(f"s_branch body_{tag}D{rs}_%=")
     return lbl
 
 
-def llinf_block(lbl, p_next, m_last):
+def llinf_block(lbl, p_next, m_last, rs):
     tag = f"{p_next}{m_last}"
     emit(f"{lbl}:")
     emit(f"v_readlane_b32 %[t1], {v(MF1)}, 49")
     emit("s_cmp_eq_u32 %[t1], 0xff800000")
-    emit(f"s_cbranch_scc0 body_{tag}R_%=")               # ll = -inf < finite ur
+    emit(f"s_cbranch_scc0 body_{tag}R{rs}_%=")           # ll = -inf < finite ur
     emit("s_bitcmp1_b32 %[b], 0")                         # both -inf: alternate, right on odd bands (align.c:311)
-    emit(f"s_cbranch_scc1 body_{tag}R_%=")
-    emit(f"s_branch body_{tag}D_%=")
+    emit(f"s_cbranch_scc1 body_{tag}R{rs}_%=")
+    emit(f"s_branch body_{tag}D{rs}_%=")
 
 
-def body(p, ml, m):
-    """Band body for parity p, previous move ml, this move m ('R'/'D')."""
+def body(p, ml, m, rs):
+    """Band body for parity p, previous move ml, this move m ('R'/'D'), k-mer quad rotation rs at entry."""
     T, Tp = TR[p], TR[p ^ 1]
-    tag = f"{p}{ml}{m}"
+    tag = f"{p}{ml}{m}{rs}"
     emit(f"body_{tag}_%=:")
     if m == 'R':
+        c0q, inq = KQ[rs], KQ[(rs + 2) % 3]
+        rs = (rs + 1) % 3                                    # roles after the move: cell 0 = old cell 1, cell 1 = old incoming
         emit("s_add_u32 %[ll_k], %[ll_k], 1")
         emit(f"v_mov_b32_dpp {v(SHR)}, {v(MF0)} {DPP_SHL}")
         emit("s_waitcnt lgkmcnt(1)" if ml == 'D' else "s_waitcnt lgkmcnt(0)")     # incoming k-mer landed
-        emit(f"v_mov_b32_dpp {v(NK)}, {v(G0)} {DPP_SHL}")
-        emit(f"v_mov_b32_dpp {v(NK+1)}, {v(C0)} {DPP_SHL}")
-        emit(f"v_mov_b32_dpp {v(NK+2)}, {v(I0)} {DPP_SHL}")
-        emit(f"v_mov_b32_dpp {v(NK+3)}, {v(I0+1)} {DPP_SHL}")
-        emit(f"v_mov_b64 {vp(G0)}, {vp(G1)}")
-        emit(f"v_mov_b64 {vp(I0)}, {vp(I1)}")
-        emit(f"v_mov_b64 {vp(G1)}, {vp(NK)}")
-        emit(f"v_mov_b64 {vp(I1)}, {vp(NK+2)}")
+        # every offset takes the k-mer of the offset above: cell 0's quad slides down one lane INTO the incoming quad,
+        # whose lane 63 keeps the pre-read incoming k-mer (DPP `old`); cell 1's quad becomes cell 0's by renaming
+        for j in range(4):
+            emit(f"v_mov_b32_dpp {v(inq + j)}, {v(c0q + j)} {DPP_SHL}")
         emit("s_lshl1_add_u32 %[mvacc], %[mvacc], 1")       # band-move bits, oldest band in the top bit
         emit("s_add_u32 %[k_addr], %[k_addr], 16")          # LDS address of the next incoming k-mer (2 KiB ring at 0)
         emit("s_bitset0_b32 %[k_addr], 11")
@@ -210,7 +213,7 @@ def body(p, ml, m):
         emit(f"kcont_{tag}_%=:")
         emit(f"v_mov_b32 {v(TMP)}, %[k_addr]")
         emit(f"v_cvt_f64_f32 {vp(T['c0'])}, {v(MF0)}")
-        emit(f"ds_read_b128 {vq(NK)}, {v(TMP)}")
+        emit(f"ds_read_b128 {vq(KQ[(rs + 2) % 3])}, {v(TMP)}")    # the next incoming k-mer lands in the old cell-0 quad (dead now)
         sh = SHR
         U = (T['c1'], T['cs']); L = (T['c0'], T['c1'])
         D = (Tp['c1'], Tp['cs']) if ml == 'R' else (Tp['c0'], Tp['c1'])
@@ -253,7 +256,7 @@ def body(p, ml, m):
         emit(f"v_subrev_u32 {v(F[1])}, %[t2], {v(O1)}")
         emit(f"v_cmp_gt_u32 %[cv0], %[t3], {v(F[0])}")
         emit(f"v_cmp_gt_u32 %[cv1], %[t3], {v(F[1])}")
-    ops0 = cell_ops(0, D[0], U[0], L[0]); ops1 = cell_ops(1, D[1], U[1], L[1])
+    ops0 = cell_ops(0, D[0], U[0], L[0], KQ[rs]); ops1 = cell_ops(1, D[1], U[1], L[1], KQ[(rs + 1) % 3])
     if BORDER:
         # split off the two trailing from-code selects of each cell (and the s_nop before them)
         tail0, tail1 = ops0[-2:], ops1[-2:]
@@ -340,8 +343,8 @@ def body(p, ml, m):
     emit("s_and_b32 %[t1], %[b], 7")
     emit(f"s_cbranch_scc0 rot_{tag}_%=")                 # band b-1 completed a dword: every 8th band, out of line
     emit(f"rotret_{tag}_%=:")
-    lbl = decide(p ^ 1, m)
-    llinf_block(lbl, p ^ 1, m)
+    lbl = decide(p ^ 1, m, rs)
+    llinf_block(lbl, p ^ 1, m, rs)
     # ---- out-of-line: dword rotation / group store
     emit(f"rot_{tag}_%=:")
     emit("s_and_b32 %[t1], %[b], 31")
@@ -407,10 +410,19 @@ def body(p, ml, m):
         emit(f"s_branch econt_{tag}_%=")
 
 
-def exit_stub(p, ml):
-    tag = f"{p}{ml}"
+def exit_stub(p, ml, rs):
+    tag = f"{p}{ml}{rs}"
     Tl = TR[p ^ 1]
     emit(f"exit_{tag}_%=:")
+    if rs:
+        # back to the entry layout: cell 0 -> KQ[0], cell 1 -> KQ[1], incoming -> KQ[2], through the per-cell temps
+        tq = [LPD[0], TD[0], TU[0]]                          # three free quads (v106..v117)
+        for j in range(3):
+            emit(f"v_mov_b64 {vp(tq[j])}, {vp(KQ[(rs + j) % 3])}")
+            emit(f"v_mov_b64 {vp(tq[j] + 2)}, {vp(KQ[(rs + j) % 3] + 2)}")
+        for j in range(3):
+            emit(f"v_mov_b64 {vp(KQ[j])}, {vp(tq[j])}")
+            emit(f"v_mov_b64 {vp(KQ[j] + 2)}, {vp(tq[j] + 2)}")
     if ml == 'R':
         mv = [("L0", Tl['c0']), ("L1", Tl['c1']), ("U0", Tl['c1']), ("U1", Tl['cs'])]
     else:
@@ -437,15 +449,17 @@ def variant_code(border):
     emit(f"v_readlane_b32 %[t0], {v(MF0)}, 0")
     emit("s_nop 1")
     emit(f"v_cmp_lt_f32 vcc, %[t0], {v(MF1)}")
-    lbl = decide(0, 'R')
-    llinf_block(lbl, 0, 'R')
-    for p in (0, 1):
-        for ml in "RD":
-            for m in "RD":
-                body(p, ml, m)
-    for p in (0, 1):
-        for ml in "RD":
-            exit_stub(p, ml)
+    lbl = decide(0, 'R', 0)
+    llinf_block(lbl, 0, 'R', 0)
+    for rs in (0, 1, 2):
+        for p in (0, 1):
+            for ml in "RD":
+                for m in "RD":
+                    body(p, ml, m, rs)
+    for rs in (0, 1, 2):
+        for p in (0, 1):
+            for ml in "RD":
+                exit_stub(p, ml, rs)
     sfx = "B" if border else "I"
     return [ln.replace("done_%=", "DONE").replace("_%=", f"_{sfx}%=").replace("DONE", "done_%=") for ln in out]
 
