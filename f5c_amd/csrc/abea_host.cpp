@@ -214,6 +214,86 @@ static host_opts read_opts() {
     return o;
 }
 
+/* ------------------------------------------------------------------ chunk carving (pure host logic) */
+struct chunk_span { size_t begin, end; size_t events; bool whole_arena; };
+
+/* device + pinned bytes one read adds to a chunk besides scratch_bytes() */
+static size_t chunk_io_bytes(const plan_read& r, bool pairs_on_device, bool scaling) {
+    size_t b = align_up((size_t)r.L + 1, 16) + 4 + sizeof(abea_read_diag) + 8;
+    if (pairs_on_device) b += ((size_t)r.E + (size_t)r.L) * sizeof(abea_pair_t);
+    if (scaling) b += (size_t)r.K * sizeof(abea_index_pair_t) + sizeof(abea_scalings_t) + 8 + 4 + 4;
+    return b + 64;
+}
+
+/* Cut the reads `order` (positions into `reads`, longest first) into chunks: a chunk closes once it holds at least
+ * chunk_reads_min reads AND chunk_events events (the first two chunks a quarter / half of that, so the GPU starts
+ * early), at chunk_reads_max reads, or when the next read would not fit the slot's share of the arena; a read that
+ * does not fit a share on its own gets the whole arena, alone. */
+static std::vector<chunk_span> carve_chunks(const std::vector<plan_read>& reads, const std::vector<int32_t>& order,
+                                            const host_opts& opt, size_t slot_arena, bool pairs_on_device, bool scaling) {
+    std::vector<chunk_span> out;
+    size_t pos = 0;
+    while (pos < order.size()) {
+        const int ramp = out.size() == 0 ? 4 : out.size() == 1 ? 2 : 1;
+        const size_t want_ev = opt.chunk_events / (size_t)ramp;
+        const int32_t want_reads = std::max(1, opt.chunk_reads_min / ramp);
+        size_t bytes = 65536, ev = 0, end = pos;
+        bool whole_arena = false;
+        while (end < order.size()) {
+            const plan_read& r = reads[(size_t)order[end]];
+            const size_t need = scratch_bytes(r) + chunk_io_bytes(r, pairs_on_device, scaling);
+            if (bytes + need > slot_arena) {
+                if (end > pos) break;
+                whole_arena = true;                      /* an over-long read: give it the whole arena, alone */
+            }
+            bytes += need; ev += (size_t)r.E; ++end;
+            const int32_t cnt = (int32_t)(end - pos);
+            if (whole_arena || (cnt >= want_reads && ev >= want_ev) || cnt >= opt.chunk_reads_max) break;
+        }
+        out.push_back(chunk_span{pos, end, ev, whole_arena});
+        pos = end;
+    }
+    return out;
+}
+
+/* longest first, ties in caller order: sort packed (band count, inverted position) keys, no indirection */
+static void order_longest_first(const std::vector<plan_read>& reads, std::vector<int32_t>& order) {
+    std::vector<uint64_t> key(order.size());
+    for (size_t t = 0; t < order.size(); ++t)
+        key[t] = ((uint64_t)reads[(size_t)order[t]].n_bands << 32) | (uint32_t)(0xFFFFFFFFu - (uint32_t)order[t]);
+    std::sort(key.begin(), key.end(), std::greater<uint64_t>());
+    for (size_t t = 0; t < order.size(); ++t) order[t] = (int32_t)(0xFFFFFFFFu - (uint32_t)key[t]);
+}
+
+/* The chunk plan abea_align_batch_host would use for these reads on an arena of `arena_bytes` (pairs returned through
+ * the walk codes, no fused scaling), host-only: chunk_of[i] = chunk of read i, -1 for reads the align_single guards
+ * skip; chunks are numbered in launch order.  Exposed so that the planning logic is testable without a GPU. */
+extern "C" int abea_host_plan_chunks(const int32_t* read_len, const int32_t* n_events, int32_t n_reads, uint32_t kmer_size,
+                                     uint64_t arena_bytes, int32_t* chunk_of, int32_t* n_chunks) {
+    if (n_reads < 0 || (n_reads && (!read_len || !n_events || !chunk_of)) || !n_chunks || kmer_size < 1)
+        return abea_fail(ABEA_EINVAL, "abea_host_plan_chunks: bad argument");
+    const host_opts opt = read_opts();
+    std::vector<plan_read> reads((size_t)n_reads);
+    std::vector<int32_t> order;
+    for (int32_t i = 0; i < n_reads; ++i) {
+        reads[(size_t)i] = make_plan(i, read_len[i], n_events[i], kmer_size);
+        chunk_of[i] = -1;
+        if (reads[(size_t)i].run) {
+            if (scratch_bytes(reads[(size_t)i]) + chunk_io_bytes(reads[(size_t)i], false, false) + 65536 > arena_bytes)
+                return abea_fail(ABEA_ENOMEM, "read %d (L=%d, E=%d) needs more scratch than the %llu-byte arena", i, read_len[i],
+                                 n_events[i], (unsigned long long)arena_bytes);
+            order.push_back(i);
+        }
+    }
+    order_longest_first(reads, order);
+    const size_t slot_arena = (size_t)arena_bytes / (size_t)opt.n_slots / 4096 * 4096;
+    const std::vector<chunk_span> chunks = carve_chunks(reads, order, opt, slot_arena, false, false);
+    for (size_t c = 0; c < chunks.size(); ++c)
+        for (size_t t = chunks[c].begin; t < chunks[c].end; ++t) chunk_of[order[t]] = (int32_t)c;
+    *n_chunks = (int32_t)chunks.size();
+    return ABEA_OK;
+}
+
 /* ------------------------------------------------------------------ the pipeline on one device */
 struct host_run_state {
     double t_origin = 0; bool trace = false;
@@ -370,21 +450,8 @@ static int host_run(abea_ctx* c, const abea_host_batch* H, const int32_t* mine, 
             }
         }
     }
-    {   /* longest first, ties in caller order: sort packed (band count, inverted position) keys, no indirection */
-        std::vector<uint64_t> key(order.size());
-        for (size_t t = 0; t < order.size(); ++t)
-            key[t] = ((uint64_t)S.reads[(size_t)order[t]].n_bands << 32) | (uint32_t)(0xFFFFFFFFu - (uint32_t)order[t]);
-        std::sort(key.begin(), key.end(), std::greater<uint64_t>());
-        for (size_t t = 0; t < order.size(); ++t) order[t] = (int32_t)(0xFFFFFFFFu - (uint32_t)key[t]);
-    }
-
-    /* device + pinned bytes one read adds to a chunk besides scratch_bytes() */
-    auto io_bytes = [&](const plan_read& r) {
-        size_t b = align_up((size_t)r.L + 1, 16) + 4 + sizeof(abea_read_diag) + 8;
-        if (pairs_on_device) b += ((size_t)r.E + (size_t)r.L) * sizeof(abea_pair_t);
-        if (scaling) b += (size_t)r.K * sizeof(abea_index_pair_t) + sizeof(abea_scalings_t) + 8 + 4 + 4;
-        return b + 64;
-    };
+    order_longest_first(S.reads, order);
+    auto io_bytes = [&](const plan_read& r) { return chunk_io_bytes(r, pairs_on_device, scaling); };
     /* check every read against the arena before anything is launched */
     for (int32_t q : order) {
         const plan_read& r = S.reads[(size_t)q];
@@ -395,26 +462,11 @@ static int host_run(abea_ctx* c, const abea_host_batch* H, const int32_t* mine, 
     const size_t slot_arena = c->arena_bytes / (size_t)n_slots / 4096 * 4096;
     const int min_rescale = H->min_num_events_to_rescale > 0 ? H->min_num_events_to_rescale : 200;
 
-    size_t pos = 0;
-    int turn = 0, chunk_no = 0;
-    while (pos < order.size()) {
-        /* ---- carve a chunk: the first chunks are small so that the longest reads start early ---- */
-        const int ramp = chunk_no == 0 ? 4 : chunk_no == 1 ? 2 : 1;
-        const size_t want_ev = S.opt.chunk_events / ramp;
-        const int32_t want_reads = std::max(1, S.opt.chunk_reads_min / ramp);
-        size_t bytes = 65536, ev = 0, end = pos;
-        bool whole_arena = false;
-        while (end < order.size()) {
-            const plan_read& r = S.reads[(size_t)order[end]];
-            const size_t need = scratch_bytes(r) + io_bytes(r);
-            if (bytes + need > slot_arena) {
-                if (end > pos) break;
-                whole_arena = true;                      /* an over-long read: give it the whole arena, alone */
-            }
-            bytes += need; ev += (size_t)r.E; ++end;
-            const int32_t cnt = (int32_t)(end - pos);
-            if (whole_arena || (cnt >= want_reads && ev >= want_ev) || cnt >= S.opt.chunk_reads_max) break;
-        }
+    const std::vector<chunk_span> chunks = carve_chunks(S.reads, order, S.opt, slot_arena, pairs_on_device, scaling);
+    int turn = 0;
+    for (int chunk_no = 0; chunk_no < (int)chunks.size(); ++chunk_no) {
+        const size_t pos = chunks[(size_t)chunk_no].begin, end = chunks[(size_t)chunk_no].end, ev = chunks[(size_t)chunk_no].events;
+        const bool whole_arena = chunks[(size_t)chunk_no].whole_arena;
         const int32_t m = (int32_t)(end - pos);
         abea_host_slot& sl = *c->slots[(size_t)(whole_arena ? 0 : turn % n_slots)];
         int rc;
@@ -567,7 +619,6 @@ static int host_run(abea_ctx* c, const abea_host_batch* H, const int32_t* mine, 
         S.st.n_sub_batches += 1; S.st.fill_launches += 1;
         if (whole_arena) { if ((rc = slot_retire(S, sl))) return rc; }
         else ++turn;
-        pos = end; ++chunk_no;
         for (abea_host_slot* o2 : c->slots) if ((rc = slot_stage(S, *o2, false))) return rc;
     }
     /* ---- drain, oldest chunk first ---- */

@@ -244,6 +244,13 @@ int abea_lpt_split(const int64_t* weight, int32_t n, int32_t n_bins, int32_t* bi
  * step, 16 steps per word, step 0 = the end cell (last_kmer, end_event); 0 = diagonal, 1 = up (event only), 2 = left
  * (k-mer only) — expanded into the ascending (ref_pos, read_pos) list align() returns (src/align.c:452-513). */
 int abea_expand_walk_codes(const uint32_t* codes, int32_t n_steps, int32_t last_kmer, int32_t end_event, abea_pair_t* out);
+/* The chunk plan abea_align_batch_host() uses for a batch on an arena of arena_bytes (host-only; pairs returned, no
+ * fused scaling): chunk_of[i] = launch-order number of the chunk read i goes into, -1 for reads skipped by the
+ * align_single guards (src/f5c.c:813-814).  Reads go longest first; a chunk holds >= 2048 reads and >= 48 M events (the
+ * first two a quarter / half of that), at most 16384 reads, and fits an eighth of the arena; ABEA_HOST_CHUNK_* and
+ * ABEA_HOST_SLOTS in the environment override the numbers. */
+int abea_host_plan_chunks(const int32_t* read_len, const int32_t* n_events, int32_t n_reads, uint32_t kmer_size,
+                          uint64_t arena_bytes, int32_t* chunk_of, int32_t* n_chunks);
 
 /* Library / device introspection: "gfx950", CU count; used by tests to assert the native path ran. */
 int abea_device_info(abea_ctx* ctx, char* arch, size_t arch_len, int32_t* n_cu, uint64_t* arena_bytes);

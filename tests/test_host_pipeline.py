@@ -98,6 +98,57 @@ def test_walk_code_expansion_matches_the_traceback(orc, r9):
     assert lib.abea_expand_walk_codes(None, 0, 0, 0, None) == 0 and lib.abea_expand_walk_codes(None, 3, 0, 0, None) != 0
 
 
+def test_chunk_plan_of_the_host_entry(monkeypatch):
+    """abea_host_plan_chunks = the carving abea_align_batch_host applies: every runnable read in exactly one chunk, chunks in
+    descending read length, size rules (>= 2048 reads and >= 48 M events, first two chunks a quarter / half, <= 16384 reads),
+    the arena share respected, over-long reads alone, guard failures left out."""
+    import ctypes
+    from f5c_amd import abea, synth
+    lib = abea.load_library()
+    lib.abea_host_plan_chunks.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_uint32, ctypes.c_uint64,
+                                          ctypes.c_void_p, ctypes.c_void_p]
+    for var in ("ABEA_HOST_CHUNK_EVENTS", "ABEA_HOST_CHUNK_READS", "ABEA_HOST_CHUNK_READS_MAX", "ABEA_HOST_SLOTS"):
+        monkeypatch.delenv(var, raising=False)
+
+    def plan(L, E, arena):
+        L = np.ascontiguousarray(L, dtype=np.int32); E = np.ascontiguousarray(E, dtype=np.int32)
+        out = np.full(len(L), -2, dtype=np.int32); n = ctypes.c_int32(-1)
+        rc = lib.abea_host_plan_chunks(L.ctypes.data, E.ctypes.data, len(L), 6, arena, out.ctypes.data, ctypes.byref(n))
+        return rc, out, n.value
+
+    L = synth.batch_lengths(100_000, 20250003, "loguniform")            # BASELINE configs[2]
+    E = 2 * L + (L % 7)
+    E[::1000] = 20 * L[::1000]                                          # over-segmented: skipped by E/L >= 15
+    rc, ch, n = plan(L, E, 150 << 30)
+    assert rc == 0 and 20 <= n <= 40
+    skipped = np.zeros(len(L), bool); skipped[::1000] = True
+    assert (ch[skipped] == -1).all() and (ch[~skipped] >= 0).all() and ch.max() == n - 1
+    bands = E.astype(np.int64) + L
+    for c in range(n):
+        m = ch == c
+        cnt, ev = int(m.sum()), int(E[m].sum())
+        ramp = 4 if c == 0 else 2 if c == 1 else 1
+        if c < n - 1:
+            assert cnt >= 2048 // ramp and (ev >= (48 << 20) // ramp or cnt == 16384)
+            assert bands[m].min() >= bands[ch == c + 1].max()           # longest first across chunks
+        assert cnt <= 16384
+        # closing rule: without its last (shortest) read the chunk would have been below one of the two thresholds
+        last = np.nonzero(m)[0][np.argmin(bands[m])]
+        if c < n - 1 and cnt < 16384:
+            assert cnt - 1 < 2048 // ramp or ev - int(E[last]) < (48 << 20) // ramp
+    # a small arena: shares of 2 MiB; the long read runs alone, the others are packed under the share
+    L2 = np.array([1500, 40000, 1200, 2500, 60000, 1800]); E2 = 2 * L2
+    rc, ch2, n2 = plan(L2, E2, 16 << 20)
+    assert rc == 0 and ch2[4] == 0 and ch2[1] == 1 and (ch2 == 0).sum() == 1 and (ch2 == 1).sum() == 1
+    assert n2 >= 3 and set(ch2[[0, 2, 3, 5]]) <= set(range(2, n2))
+    rc, _, _ = plan([250000], [500000], 16 << 20)
+    assert rc != 0 and b"arena" in lib.abea_last_error()
+    # the env knobs the GPU tests use
+    monkeypatch.setenv("ABEA_HOST_CHUNK_READS", "4"); monkeypatch.setenv("ABEA_HOST_CHUNK_EVENTS", "20000")
+    rc, ch3, n3 = plan(np.full(60, 1800), np.full(60, 3600), 4 << 30)
+    assert rc == 0 and n3 >= 8 and (np.bincount(ch3)[2:-1] >= 4).all()
+
+
 # ---------------------------------------------------------------- GPU
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode", ["codes", "device"])
