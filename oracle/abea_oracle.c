@@ -579,7 +579,9 @@ long orc_rsq_format(char* out, size_t cap, int fmt, const char* read_id, int32_t
  * Restates profile_hmm_score -> profile_hmm_score_r9 -> profile_hmm_fill_generic_r9<ProfileHMMForwardOutputR9>
  * (src/hmm.c:314-535, 613-735) as it is compiled in the reference: ESL_LOG_SUM = 1 (f5c.h:88: table-driven float
  * log-sum, logsum.h:40-71), CACHED_LOG, HMM_REVERSE_FIX undefined, USE_EXTERNAL_PARAMS undefined.
- * UNPINNED: the reference's only goldens for this path (meth.exp) need draft.fa, which the mount does not hold. */
+ * PINNED: test/ecoli_2kb_region/single_read/meth_input.exp lists the arguments of read1's 90 calls and single_read/meth.exp
+ * prints their results; this function reproduces all 90 (89 equal at the printed %.2f, one 0.005 from a rounding boundary):
+ * tests/test_hmm_pin.py. */
 #define ORC_LOGSUM_TBL 16000
 static float orc_flogsum_tbl[ORC_LOGSUM_TBL];
 static int orc_flogsum_ready = 0;

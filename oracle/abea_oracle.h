@@ -79,7 +79,7 @@ int32_t orc_scaling_single(const orc_pair_t* pairs, int32_t n_pairs, const char*
 long orc_rsq_format(char* out, size_t cap, int fmt, const char* read_id, int32_t read_len, uint32_t kmer_size,
                     orc_index_pair_t* map, const orc_event_t* event, long nsample, float sc_scale, float sc_shift, int rna);
 
-/* profile-HMM forward score (src/hmm.c:314-735), row N4; UNPINNED (see abea_oracle.c).  hmm_flags: 1 = HAF_ALLOW_PRE_CLIP,
+/* profile-HMM forward score (src/hmm.c:314-735), row N4; pinned to single_read/meth_input.exp + meth.exp (tests/test_hmm_pin.py).  hmm_flags: 1 = HAF_ALLOW_PRE_CLIP,
  * 2 = HAF_ALLOW_POST_CLIP (f5cmisc.h:40-41).  cpgmodel: 5^k entries over the alphabet A,C,G,M,T. */
 void orc_flogsum_init(void);
 const float* orc_flogsum_table(void);

@@ -148,7 +148,7 @@ class _Scal(C.Structure):
 def profile_hmm_score(m_seq: bytes, m_rc_seq: bytes, events, scaling, cpgmodel, k, e_start, e_stop, stride, rc,
                       events_per_base, hmm_flags=3):
     """profile_hmm_score (hmm.c:692 -> :628): forward log-likelihood of events e_start..e_stop against m_seq.
-    scaling = (scale, shift, var, log_var); UNPINNED restatement (row N4)."""
+    scaling = (scale, shift, var, log_var); pinned to single_read/meth.exp (tests/test_hmm_pin.py)."""
     L = lib()
     L.orc_profile_hmm_score.restype = C.c_float
     L.orc_profile_hmm_score.argtypes = [C.c_char_p, C.c_char_p, C.c_void_p, _Scal, C.c_void_p, C.c_uint32, C.c_uint32,

@@ -13,6 +13,25 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def _have_gpu():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+def pytest_collection_modifyitems(config, items):
+    """Every `gpu` test is skipped before any batch is generated or context built when no device is present (a plain
+    `pytest tests` on a CPU box used to build the 60 GB full-size batch and die; round-2 advisor finding)."""
+    if _have_gpu():
+        return
+    skip = pytest.mark.skip(reason="no GPU visible (run with -m gpu on an MI355X box)")
+    for it in items:
+        if "gpu" in it.keywords:
+            it.add_marker(skip)
+
+
 @pytest.fixture(scope="session")
 def r9():
     from f5c_amd import load_model_f32

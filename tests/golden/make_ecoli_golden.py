@@ -7,7 +7,12 @@ Run in the build container only (needs /root/reference and /opt/conda/bin/h5dump
   adaptive.exp / est_scalings.exp / recalib_scalings.exp (143 BAM records over 112 reads; order unknown
   without htslib, so lines are matched as a multiset of printed values).
 Writes tests/golden/ecoli_reads.npz: int16 signals + scaling + sequence + the golden line of a subset of
-reads, so the chain is also checked where /root/reference is absent (GPU box).
+reads, so the chain is also checked where /root/reference is absent (GPU box); `ada` is the oracle's own
+"sum n_aligned", `ada_printed` the reference's printed adaptive.exp record of that read.
+Writes tests/golden/ecoli_events.npz: for EVERY read of the set the mean-only event table (float32; ABEA and
+scaling_single read nothing else of event_t, align.c:131,738), the sequence, the method-of-moments scalings as float32
+bits, and the reference's PRINTED adaptive.exp / est_scalings.exp / recalib_scalings.exp records it matched — so that
+configs[0] is checked GPU-vs-reference on all 111 reads of the BAM on the GPU box (round-2 verdict item 3).
 """
 import glob, os, re, subprocess, sys, tempfile
 import numpy as np
@@ -66,7 +71,7 @@ def main(write=True):
     def ada_match(d):
         s_, n_ = d["sum_emission"], d["n_aligned"]
         hit = gold_rows[(gold_rows[:, 1] == n_) & (np.abs(gold_rows[:, 0] - s_) <= 1e-6 * abs(s_) + 1e-6)]
-        return len(hit) > 0
+        return hit[0] if len(hit) else None
     gold_ada = {"%.0f" % r[1] for r in gold_rows}
     gold_rec = {"%.2f %.2f %.2f" % tuple(r) for r in g["recalib"]}
     gold_est = {"%.2f %.2f" % (a, b) for a, b in zip(g["est_shift"], g["est_scale"])}
@@ -74,20 +79,29 @@ def main(write=True):
     ok_ada = ok_rec = ok_est = n = 0
     seen_ada = set()
     keep = []
+    allreads = []
     for path in files:
         f5 = read_fast5(path)
         seq = seqs[f5["read_id"]]
         ev, (scale, shift), pairs, d, rec = chain(orc, model, k, seq, f5)
         n += 1
         ada = "%.0f" % d["n_aligned"]
-        ada_ok = ada_match(d)
+        ada_row = ada_match(d)
+        ada_ok = ada_row is not None
         est = "%.2f %.2f" % (shift, scale)
         recs = "%.2f %.2f %.2f" % (rec["scalings"]["shift"], rec["scalings"]["scale"], rec["scalings"]["var"]) if rec else None
         ok_ada += ada_ok; ok_est += est in gold_est; ok_rec += (recs in gold_rec) if recs else 0
         seen_ada.add(ada)
         if ada_ok and (est in gold_est) and recs in gold_rec and len(keep) < 10 and len(f5["signal"]) < 120000:
             keep.append(dict(f5, seq=seq, ada="%.6f %d" % (d["sum_emission"], d["n_aligned"]), est=est, rec=recs,
-                             n_events=len(ev)))
+                             ada_printed="%.6f %d" % (ada_row[0], ada_row[1]), n_events=len(ev)))
+        if ada_ok:                                        # the 111 reads of the BAM (the 112th FAST5 has no record)
+            allreads.append(dict(read_id=f5["read_id"], seq=seq, mean=ev["mean"].astype(np.float32),
+                                 scale=np.float32(scale), shift=np.float32(shift),
+                                 printed_sum=ada_row[0], printed_n=int(ada_row[1]), printed_avg=ada_row[2],
+                                 oracle_sum=float(d["sum_emission"]),
+                                 est=est if est in gold_est else "", rec=recs if recs in gold_rec else "",
+                                 n_samples=len(f5["signal"])))
         if not ada_ok or est not in gold_est or recs not in gold_rec:
             print("MISMATCH", f5["read_id"], "n_aligned", ada, ada_ok, "est", est, est in gold_est, "recalib", recs,
                   recs in gold_rec)
@@ -101,10 +115,26 @@ def main(write=True):
                         **{f"sig{i}": r["signal"] for i, r in enumerate(keep)},
                         **{f"seq{i}": np.frombuffer(r["seq"], dtype=np.uint8) for i, r in enumerate(keep)},
                         scaling=np.array([[r["offset"], r["range"], r["digitisation"]] for r in keep]),
-                        ada=np.array([r["ada"] for r in keep]), est=np.array([r["est"] for r in keep]),
+                        ada=np.array([r["ada"] for r in keep]), ada_printed=np.array([r["ada_printed"] for r in keep]),
+                        est=np.array([r["est"] for r in keep]),
                         rec=np.array([r["rec"] for r in keep]), n_events=np.array([r["n_events"] for r in keep]),
                         read_id=np.array([r["read_id"] for r in keep]),
                         summary=np.array([n, ok_ada, ok_est, ok_rec, len(gold_ada), len(seen_ada & gold_ada)]))
+    ev_ptr = np.concatenate([[0], np.cumsum([len(r["mean"]) for r in allreads])]).astype(np.int64)
+    seq_ptr = np.concatenate([[0], np.cumsum([len(r["seq"]) for r in allreads])]).astype(np.int64)
+    np.savez_compressed(os.path.join(OUT, "ecoli_events.npz"),
+                        read_id=np.array([r["read_id"] for r in allreads]),
+                        mean=np.concatenate([r["mean"] for r in allreads]), ev_ptr=ev_ptr,
+                        seq=np.frombuffer(b"".join(r["seq"] for r in allreads), dtype=np.uint8), seq_ptr=seq_ptr,
+                        scale=np.array([r["scale"] for r in allreads], dtype=np.float32),
+                        shift=np.array([r["shift"] for r in allreads], dtype=np.float32),
+                        printed_sum=np.array([r["printed_sum"] for r in allreads]),
+                        printed_n=np.array([r["printed_n"] for r in allreads], dtype=np.int64),
+                        printed_avg=np.array([r["printed_avg"] for r in allreads]),
+                        oracle_sum=np.array([r["oracle_sum"] for r in allreads]),
+                        est=np.array([r["est"] for r in allreads]), rec=np.array([r["rec"] for r in allreads]),
+                        n_samples=np.array([r["n_samples"] for r in allreads], dtype=np.int64))
+    print("ecoli_events.npz: %d reads, %d events" % (len(allreads), ev_ptr[-1]))
     return 0 if ok_ada >= n - 1 else 1
 
 

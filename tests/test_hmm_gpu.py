@@ -1,7 +1,7 @@
 """Row N4 on the device: batches of profile_hmm_score() calls (src/hmm.c:689-735, call site meth.c:473) through
-abea_hmm_score_batch_host against the CPU restatement, bit for bit.  The oracle itself is UNPINNED (the reference's
-goldens for this path, meth.exp, need draft.fa, which the mount does not hold); it is checked against an independently
-written float32 twin in tests/test_hmm_oracle.py."""
+abea_hmm_score_batch_host against the CPU restatement, bit for bit.  The oracle is pinned to the reference's
+printed single_read/meth.exp scores (tests/test_hmm_pin.py, which also runs those 90 jobs on the GPU) and checked against
+an independently written float32 twin in tests/test_hmm_oracle.py."""
 import numpy as np
 import pytest
 

@@ -1,6 +1,6 @@
 """Row N4, oracle only (no device code yet): the restated profile-HMM forward score (oracle/abea_oracle.c,
-src/hmm.c:314-735) against an independently written float32 twin in Python, plus properties of the score.  UNPINNED:
-the reference's goldens for this path (meth.exp) need draft.fa, which the mount does not hold."""
+src/hmm.c:314-735) against an independently written float32 twin in Python, plus properties of the score.  The pin against
+the reference's own printed scores (single_read/meth_input.exp + meth.exp) is tests/test_hmm_pin.py."""
 import numpy as np
 import pytest
 
