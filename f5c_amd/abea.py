@@ -16,7 +16,8 @@ LIB_PATH = os.environ.get("ABEA_LIB_PATH", os.path.join(_HERE, "libabea_hip.so")
 EXPORTS = ["abea_init", "abea_init_multi", "abea_device_count", "abea_free", "abea_last_error", "abea_align_batch_host",
            "abea_align_batch_device", "abea_detect_events_device", "abea_get_stats", "abea_get_device_stats",
            "abea_device_info", "abea_selftest", "abea_rsq_format", "abea_lpt_split", "abea_hmm_score_batch_host", "abea_expand_walk_codes",
-           "abea_host_plan_chunks"]
+           "abea_host_plan_chunks", "abea_host_plan_threads", "abea_set_inflight", "abea_align_batch_host_submit",
+           "abea_align_batch_host_wait"]
 SHIM_EXPORTS = ["abea_f5c_init", "abea_f5c_align", "abea_f5c_align_scale", "abea_f5c_free"]      # include/abea_f5c_shim.h
 
 
@@ -108,6 +109,10 @@ class Stats(C.Structure):
 _LIB = None
 
 
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
 def load_library():
     """Load libabea_hip.so (built by __graft_entry__.build()). Raises if it is missing."""
     global _LIB
@@ -151,12 +156,33 @@ def load_library():
         L.abea_hmm_score_batch_host.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_uint32, C.c_void_p]
         L.abea_selftest.restype = C.c_int
         L.abea_selftest.argtypes = [C.c_void_p]
+        L.abea_set_inflight.restype = C.c_int
+        L.abea_set_inflight.argtypes = [C.c_void_p, C.c_int32]
+        L.abea_align_batch_host_submit.restype = C.c_int
+        L.abea_align_batch_host_submit.argtypes = [C.c_void_p, C.POINTER(_HostBatch), C.POINTER(C.c_int32)]
+        L.abea_align_batch_host_wait.restype = C.c_int
+        L.abea_align_batch_host_wait.argtypes = [C.c_void_p, C.c_int32]
+        L.abea_host_plan_threads.restype = C.c_int
+        L.abea_host_plan_threads.argtypes = [C.c_int32, C.c_char_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p,
+                                             C.c_void_p, C.c_void_p, C.c_size_t]
         _LIB = L
     return _LIB
 
 
-def _p(a):
-    return a.ctypes.data_as(C.c_void_p)
+def plan_host_threads(usable_cpus, n_devices, device_numa_node=None, node_cpulists=(), allowed=None):
+    """abea_host_plan_threads (host-only): worker threads per device context and the cpulist each pool binds to."""
+    lib = load_library()
+    thr = np.zeros(n_devices, dtype=np.int32)
+    cap = 1024
+    buf = C.create_string_buffer(cap * n_devices)
+    nodes = np.ascontiguousarray(device_numa_node, dtype=np.int32) if device_numa_node is not None else None
+    lists = (C.c_char_p * max(1, len(node_cpulists)))(*[x.encode() for x in node_cpulists])
+    rc = lib.abea_host_plan_threads(usable_cpus, allowed.encode() if allowed else None, n_devices,
+                                    _p(nodes) if nodes is not None else None, len(node_cpulists),
+                                    C.cast(lists, C.c_void_p), _p(thr), C.cast(buf, C.c_void_p), cap)
+    if rc != 0:
+        raise AbeaError(f"abea_host_plan_threads failed ({rc}): {lib.abea_last_error().decode()}")
+    return thr, [buf.raw[d * cap:(d + 1) * cap].split(b"\0", 1)[0].decode() for d in range(n_devices)]
 
 
 class AbeaContext:
@@ -312,6 +338,21 @@ class AbeaContext:
 
     def align_view(self, view):
         self._chk(self._lib.abea_align_batch_host(self._h, C.byref(view["hb"])), "abea_align_batch_host")
+
+    # ---- several host batches in flight (abea_align_batch_host_submit / _wait) ----
+    def set_inflight(self, n_lanes):
+        self._chk(self._lib.abea_set_inflight(self._h, n_lanes), "abea_set_inflight")
+
+    def submit_view(self, view):
+        """Start a host batch (a host_view) on a free lane; returns the ticket.  The view's arrays are the caller-owned
+        inputs and outputs: keep the view alive and untouched until wait()."""
+        t = C.c_int32(-1)
+        self._chk(self._lib.abea_align_batch_host_submit(self._h, C.byref(view["hb"]), C.byref(t)),
+                  "abea_align_batch_host_submit")
+        return t.value
+
+    def wait(self, ticket):
+        self._chk(self._lib.abea_align_batch_host_wait(self._h, ticket), "abea_align_batch_host_wait")
 
     # ---- row N4: profile-HMM forward scores ----
     def hmm_score_batch(self, jobs, cpgmodel, kmer_size):

@@ -6,7 +6,7 @@
  * dispatcher load-balances 1..50 kb mixes, splits a batch into arena-sized sub-batches and
  * launches the kernels of abea_kernels.hip (align-pre, the fused fill + traceback + expansion kernel, optionally
  * scaling_single) on the library's own stream, timed with HIP events on that stream.  The host-buffer entry cuts the
- * batch into chunks that rotate through three slot streams so that host copies, PCIe and kernels overlap; the raw-signal
+ * batch into chunks that rotate through eight slot streams so that host copies, PCIe and kernels overlap; the raw-signal
  * entry runs event detection (row N2).  No CPU alignment fallback exists in this library.
  */
 #include <numeric>
@@ -84,6 +84,7 @@ extern "C" int abea_init(abea_ctx** out, const abea_cfg* cfg) {
     memset(&c->stats, 0, sizeof c->stats);
     c->device = cfg->device_id;
     c->n_cu = prop.multiProcessorCount;
+    c->numa_node = abea_device_numa_node(cfg->device_id);
     snprintf(c->arch, sizeof c->arch, "%s", prop.gcnArchName);
     c->k = cfg->kmer_size;
     c->verbosity = cfg->verbosity;
@@ -147,6 +148,7 @@ extern "C" int32_t abea_device_count(abea_ctx* c) { return !c ? 0 : c->children.
 
 extern "C" void abea_free(abea_ctx* c) {
     if (!c) return;
+    abea_host_join_async(c);                    /* submitted batches still running use the children: let them finish first */
     for (abea_ctx* ch : c->children) abea_free(ch);
     c->children.clear();
     if (c->device >= 0) {
@@ -181,6 +183,7 @@ extern "C" int abea_get_stats(abea_ctx* c, abea_stats* out) {
 extern "C" int abea_selftest(abea_ctx* c) {
     if (!c) return abea_fail(ABEA_EINVAL, "null ctx");
     if (!c->children.empty()) { for (abea_ctx* ch : c->children) { int rc = abea_selftest(ch); if (rc) return rc; } return ABEA_OK; }
+    ABEA_API_ENTER(c, "abea_selftest");
     HIP_TRY(hipSetDevice(c->device));
     int* d = (int*)c->arena;
     int h[320];
@@ -242,6 +245,7 @@ int ensure_pinned(void** p, size_t* cap, size_t need) {
 extern "C" int abea_align_batch_device(abea_ctx* c, const abea_device_batch* B) {
     if (!c || !B) return abea_fail(ABEA_EINVAL, "null argument");
     if (!c->children.empty()) return abea_fail(ABEA_EINVAL, "abea_align_batch_device needs a single-device context");
+    ABEA_API_ENTER(c, "abea_align_batch_device");
     const int32_t n = B->n_reads;
     if (n < 0) return abea_fail(ABEA_EINVAL, "n_reads < 0");
     const double t_start = abea_now_ms();
@@ -352,6 +356,7 @@ extern "C" int abea_align_batch_device(abea_ctx* c, const abea_device_batch* B) 
 extern "C" int abea_detect_events_device(abea_ctx* c, const abea_signal_batch* B) {
     if (!c || !B) return abea_fail(ABEA_EINVAL, "null argument");
     if (!c->children.empty()) return abea_fail(ABEA_EINVAL, "abea_detect_events_device needs a single-device context");
+    ABEA_API_ENTER(c, "abea_detect_events_device");
     const int32_t n = B->n_reads;
     if (n < 0) return abea_fail(ABEA_EINVAL, "n_reads < 0");
     if (n == 0) return ABEA_OK;

@@ -34,15 +34,20 @@ extern "C" int abea_hmm_score_batch_host(abea_ctx* c, const abea_hmm_job_t* jobs
     if (!c->children.empty()) return abea_fail(ABEA_EINVAL, "abea_hmm_score_batch_host needs a single-device context");
     if (kmer_size < 1 || kmer_size > ABEA_MAX_KMER_SIZE) return abea_fail(ABEA_EINVAL, "kmer_size %u", kmer_size);
     if (n_jobs == 0) return ABEA_OK;
+    ABEA_API_ENTER(c, "abea_hmm_score_batch_host");
     const double t_start = abea_now_ms();
     HIP_TRY(hipSetDevice(c->device));
     if (!c->hmm) {
+        /* built aside and published only when complete: a failure half-way must not leave a state the next call
+         * would take for initialised (round-2 advisor finding) */
         c->hmm = new abea_hmm_state();
+        struct undo { abea_ctx* c; bool ok = false; ~undo() { if (!ok) abea_hmm_release(c); } } guard{c};
         std::vector<float> tbl(ABEA_HMM_TBL);
         for (int i = 0; i < ABEA_HMM_TBL; i++) tbl[(size_t)i] = (float)log(1. + exp((double)-i / 1000.f));   /* logsum.h:44 */
         HIP_TRY(hipMalloc(&c->hmm->d_tbl, ABEA_HMM_TBL * sizeof(float)));
         HIP_TRY(hipMemcpy(c->hmm->d_tbl, tbl.data(), ABEA_HMM_TBL * sizeof(float), hipMemcpyHostToDevice));
         HIP_TRY(hipEventCreate(&c->hmm->e0)); HIP_TRY(hipEventCreate(&c->hmm->e1));
+        guard.ok = true;
     }
     abea_hmm_state* S = c->hmm;
     size_t n_model = 1;
@@ -67,14 +72,18 @@ extern "C" int abea_hmm_score_batch_host(abea_ctx* c, const abea_hmm_job_t* jobs
             if (!J.m_seq || !J.m_rc_seq || !J.events) { bad_job.store((int32_t)j); continue; }
             const size_t L = strlen(J.m_seq);
             if (L < kmer_size || L > (1u << 20) ||
-                (J.rc && J.event_stride != -1) || (!J.rc && J.event_stride != 1)) { bad_job.store((int32_t)j); continue; }   /* hmm.c:331 assert */
+                (J.rc && J.event_stride != -1) || (!J.rc && J.event_stride != 1) ||                                 /* hmm.c:331 assert */
+                (J.event_stride == 1 && J.event_stop_idx < J.event_start_idx) ||      /* the window would be walked out of the */
+                (J.event_stride == -1 && J.event_stop_idx > J.event_start_idx)) {     /* event table (UB in the reference)     */
+                bad_job.store((int32_t)j); continue;
+            }
             seq_len[(size_t)j] = (int32_t)L;
             n_ev[(size_t)j] = (int32_t)(J.event_stop_idx > J.event_start_idx ? J.event_stop_idx - J.event_start_idx + 1
                                                                               : J.event_start_idx - J.event_stop_idx + 1);   /* hmm.c:649-654 */
         }
     });
     if (bad_job.load() >= 0)
-        return abea_fail(ABEA_EINVAL, "job %d: null pointer, sequence shorter than k or longer than 1 Mbase, or rc / event_stride mismatch", bad_job.load());
+        return abea_fail(ABEA_EINVAL, "job %d: null pointer, sequence shorter than k or longer than 1 Mbase, rc / event_stride mismatch, or event window against its stride", bad_job.load());
     for (int32_t j = 0; j < n_jobs; ++j) {
         max_ev = std::max(max_ev, n_ev[(size_t)j]);
         n16 += ((size_t)seq_len[(size_t)j] - kmer_size + 1) <= 16;
@@ -97,6 +106,8 @@ extern "C" int abea_hmm_score_batch_host(abea_ctx* c, const abea_hmm_job_t* jobs
         d.col_off = (int64_t)tot_col; if (nk > 64) tot_col += 3 * ((size_t)d.n_events + 1);
         d.out_idx = j;
     }
+    if (tot_seq > (size_t)INT32_MAX)                                 /* seq_off is 32-bit in the device descriptor */
+        return abea_fail(ABEA_EINVAL, "%d HMM jobs hold %zu bytes of sequence; at most 2 GiB per call", n_jobs, tot_seq);
     abea_parallel_for(c, n_jobs, 2048, [&](int64_t lo, int64_t hi) {
         for (int64_t q = lo; q < hi; ++q) {
             const abea_hmm_job_t& J = jobs[order[(size_t)q]];

@@ -27,6 +27,7 @@
 #include <queue>
 #include <string>
 #include <thread>
+#include <iterator>
 #include <sched.h>
 #include <immintrin.h>
 #include "abea_internal.h"
@@ -51,6 +52,130 @@ static int effective_cpus() {
     return std::max(1, n);
 }
 
+/* ------------------------------------------------------------------ thread / affinity plan (pure host logic) */
+static std::vector<int> parse_cpulist(const char* s) {                      /* "0-3,8,10-11" (sysfs cpulist format) */
+    std::vector<int> out;
+    if (!s) return out;
+    while (*s) {
+        while (*s == ',' || *s == ' ' || *s == '\n') ++s;
+        if (!*s) break;
+        char* e = nullptr;
+        long a = strtol(s, &e, 10);
+        if (e == s) break;
+        long b = a;
+        s = e;
+        if (*s == '-') { b = strtol(s + 1, &e, 10); s = e; }
+        for (long v = a; v <= b && v - a < 65536; ++v) out.push_back((int)v);
+    }
+    std::sort(out.begin(), out.end());
+    out.erase(std::unique(out.begin(), out.end()), out.end());
+    return out;
+}
+
+static std::string format_cpulist(const std::vector<int>& v) {
+    std::string out;
+    for (size_t i = 0; i < v.size();) {
+        size_t j = i;
+        while (j + 1 < v.size() && v[j + 1] == v[j] + 1) ++j;
+        if (!out.empty()) out += ",";
+        out += std::to_string(v[i]);
+        if (j > i) out += "-" + std::to_string(v[j]);
+        i = j + 1;
+    }
+    return out;
+}
+
+/* Worker threads per DEVICE context and the CPUs they bind to.
+ *   threads: (usable CPUs - 2) / n_devices, at least 1, at most 16 — two CPUs stay with the HIP runtime's own threads
+ *            (under a cgroup CPU quota a pool as wide as the quota gets the whole process throttled); 16
+ *            saturate one socket's DRAM bandwidth in the flatten loop.  Round 2 gave ALL devices 16 threads in total
+ *            (2 per GPU on an 8-GPU node); the pool is per device now.
+ *   binding: the CPUs of the device's NUMA node that the process may run on, when the machine has more than one node
+ *            and that set holds at least `threads` CPUs; otherwise unbound.  A device's flatten then reads the caller's
+ *            event tables from wherever they are but WRITES its pinned staging (allocated by hipHostMalloc on the node
+ *            nearest the current device) locally, and un-flatten reads it locally. */
+struct host_thread_plan { int threads; std::vector<int> cpus; };
+static std::vector<host_thread_plan> plan_host_threads(int usable_cpus, const std::vector<int>& allowed, int n_devices,
+                                                        const int32_t* dev_node, const std::vector<std::vector<int>>& node_cpus,
+                                                        int forced_threads, bool numa) {
+    std::vector<host_thread_plan> out((size_t)std::max(0, n_devices));
+    for (int d = 0; d < n_devices; ++d) {
+        int t = usable_cpus > 4 || n_devices > 1 ? (usable_cpus - 2) / n_devices : usable_cpus;
+        t = std::max(1, std::min(16, t));
+        if (forced_threads > 0) t = forced_threads;
+        out[(size_t)d].threads = t;
+        const int node = dev_node ? dev_node[d] : -1;
+        if (!numa || node < 0 || node >= (int)node_cpus.size() || node_cpus.size() < 2) continue;
+        std::vector<int> local;
+        if (allowed.empty()) local = node_cpus[(size_t)node];
+        else std::set_intersection(node_cpus[(size_t)node].begin(), node_cpus[(size_t)node].end(), allowed.begin(), allowed.end(),
+                                   std::back_inserter(local));
+        if ((int)local.size() >= t) out[(size_t)d].cpus = local;
+    }
+    return out;
+}
+
+/* host-only entry over the same rule, so that the plan can be tested without a GPU (cpulists in sysfs format) */
+extern "C" int abea_host_plan_threads(int32_t usable_cpus, const char* allowed_cpulist, int32_t n_devices,
+                                      const int32_t* device_numa_node, int32_t n_nodes, const char* const* node_cpulist,
+                                      int32_t* threads_per_device, char* bind_cpulists, size_t cap_each) {
+    if (usable_cpus < 1 || n_devices < 1 || !threads_per_device || n_nodes < 0 || (n_nodes && !node_cpulist) ||
+        (bind_cpulists && cap_each < 2))
+        return abea_fail(ABEA_EINVAL, "abea_host_plan_threads: bad argument");
+    std::vector<std::vector<int>> nodes;
+    for (int32_t i = 0; i < n_nodes; ++i) nodes.push_back(parse_cpulist(node_cpulist[i]));
+    const char* e = getenv("ABEA_HOST_THREADS");
+    const char* nu = getenv("ABEA_HOST_NUMA");
+    const std::vector<host_thread_plan> plan = plan_host_threads(usable_cpus, parse_cpulist(allowed_cpulist), n_devices, device_numa_node,
+                                                                 nodes, e ? std::max(1, atoi(e)) : 0, !(nu && nu[0] == '0'));
+    for (int32_t d = 0; d < n_devices; ++d) {
+        threads_per_device[d] = plan[(size_t)d].threads;
+        if (bind_cpulists) snprintf(bind_cpulists + (size_t)d * cap_each, cap_each, "%s", format_cpulist(plan[(size_t)d].cpus).c_str());
+    }
+    return ABEA_OK;
+}
+
+static void bind_this_thread(const std::vector<int>& cpus) {
+    if (cpus.empty()) return;
+    cpu_set_t set; CPU_ZERO(&set);
+    for (int cpu : cpus) if (cpu >= 0 && cpu < CPU_SETSIZE) CPU_SET(cpu, &set);
+    sched_setaffinity(0, sizeof set, &set);            /* best effort: a failure leaves the thread where it was */
+}
+
+/* the machine as the plan sees it: the process's affinity mask and the CPU list of every NUMA node */
+static std::vector<int> allowed_cpus() {
+    std::vector<int> out;
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0)
+        for (int i = 0; i < CPU_SETSIZE; ++i) if (CPU_ISSET(i, &set)) out.push_back(i);
+    return out;
+}
+static std::vector<std::vector<int>> numa_node_cpus() {
+    std::vector<std::vector<int>> out;
+    for (int n = 0; n < 64; ++n) {
+        char path[96], buf[4096];
+        snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", n);
+        FILE* f = fopen(path, "r");
+        if (!f) break;
+        const size_t got = fread(buf, 1, sizeof buf - 1, f);
+        buf[got] = 0;
+        fclose(f);
+        out.push_back(parse_cpulist(buf));
+    }
+    return out;
+}
+/* NUMA node of a HIP device: /sys/bus/pci/devices/<domain:bus:dev.fn>/numa_node; -1 when unknown */
+int abea_device_numa_node(int device) {
+    char bdf[64] = {0};
+    if (hipDeviceGetPCIBusId(bdf, (int)sizeof bdf, device) != hipSuccess) return -1;
+    for (char* p = bdf; *p; ++p) *p = (char)tolower(*p);
+    char path[160];
+    snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/numa_node", bdf);
+    int node = -1;
+    if (FILE* f = fopen(path, "r")) { if (fscanf(f, "%d", &node) != 1) node = -1; fclose(f); }
+    return node;
+}
+
 struct abea_host_pool {
     typedef std::function<void(int64_t, int64_t)> fn_t;       /* fn(lo, hi): items [lo, hi) */
     std::vector<std::thread> th;
@@ -63,8 +188,9 @@ struct abea_host_pool {
     uint64_t gen = 0;
     bool stop = false;
 
-    explicit abea_host_pool(int threads) {
-        for (int t = 1; t < threads; ++t) th.emplace_back([this]() { worker(); });
+    /* `cpus` (may be empty): the CPUs the workers bind to — the NUMA node of the pool's device (plan_host_threads) */
+    explicit abea_host_pool(int threads, const std::vector<int>& cpus = std::vector<int>()) {
+        for (int t = 1; t < threads; ++t) th.emplace_back([this, cpus]() { bind_this_thread(cpus); worker(); });
     }
     ~abea_host_pool() {
         { std::lock_guard<std::mutex> lk(mu); stop = true; }
@@ -136,18 +262,79 @@ static int slot_create(abea_host_slot** out) {
     return ABEA_OK;
 }
 
+/* the plan for the devices of a context (children of a multi-device parent, or the context itself) */
+static std::vector<host_thread_plan> context_thread_plan(abea_ctx* c) {
+    std::vector<int32_t> nodes;
+    if (c->children.empty()) nodes.push_back(c->numa_node);
+    else for (abea_ctx* ch : c->children) nodes.push_back(ch->numa_node);
+    const char* e = getenv("ABEA_HOST_THREADS");
+    const char* nu = getenv("ABEA_HOST_NUMA");
+    return plan_host_threads(effective_cpus(), allowed_cpus(), (int)nodes.size(), nodes.data(), numa_node_cpus(),
+                             e ? std::max(1, atoi(e)) : 0, !(nu && nu[0] == '0'));
+}
+
 int abea_default_host_threads() {
-    /* leave two of the CPUs this process may use to the HIP runtime's own threads: under a cgroup CPU quota a pool as
-     * wide as the quota gets the whole process throttled (measured on the GPU box) */
-    const int cpus = effective_cpus();
-    int threads = std::min(16, cpus > 4 ? cpus - 2 : cpus);
-    if (const char* e = getenv("ABEA_HOST_THREADS")) threads = std::max(1, atoi(e));
-    return threads;
+    const char* e = getenv("ABEA_HOST_THREADS");
+    return plan_host_threads(effective_cpus(), std::vector<int>(), 1, nullptr, std::vector<std::vector<int>>(),
+                             e ? std::max(1, atoi(e)) : 0, false)[0].threads;
+}
+
+/* ------------------------------------------------------------------ lanes: what one batch in flight owns */
+/* A lane is a disjoint set of stream slots, a share of the device arena and a worker pool.  The synchronous entry runs
+ * on the FULL lane (all slots, the whole arena, the whole pool); abea_align_batch_host_submit() runs each batch on one
+ * of n_lanes equal lanes, so that several host batches are in flight on one device at once (f5c's default batches are
+ * latency-bound: one lasts as long as its longest read and fills an eighth of the wave slots). */
+struct abea_host_lane {
+    int first_slot = 0, n_slots = 0;
+    size_t arena_off = 0, arena_bytes = 0;
+    abea_host_pool* pool = nullptr;
+};
+
+struct abea_async_job {
+    std::thread th;
+    abea_host_batch H;
+    abea_stats st;
+    int rc = ABEA_OK;
+    std::string err;
+    bool active = false;
+    uint32_t gen = 0;
+};
+
+struct abea_host_async {
+    int n_lanes = 2;
+    abea_host_lane full;                       /* per device context */
+    std::vector<abea_host_lane> lanes;         /* per device context */
+    abea_async_job jobs[ABEA_MAX_INFLIGHT];    /* top-level context only */
+    int n_active = 0;                          /* top-level context only */
+};
+
+static abea_host_async* async_of(abea_ctx* c) {
+    if (!c->async) c->async = new abea_host_async();
+    return c->async;
+}
+
+int abea_host_batches_in_flight(abea_ctx* c) { return c->async ? c->async->n_active : 0; }
+
+static void lanes_release(abea_ctx* c) {
+    if (!c->async) return;
+    for (abea_host_lane& l : c->async->lanes) delete l.pool;
+    c->async->lanes.clear();
+    delete c->async->full.pool;
+    c->async->full.pool = nullptr;
 }
 
 void abea_parallel_for(abea_ctx* c, int64_t n, int64_t grain, const std::function<void(int64_t, int64_t)>& f) {
-    if (!c->pool) c->pool = new abea_host_pool(abea_default_host_threads());
-    c->pool->run(n, grain, f);
+    abea_host_async* a = async_of(c);
+    if (!a->full.pool) {
+        const host_thread_plan pl = context_thread_plan(c)[0];
+        a->full.pool = new abea_host_pool(pl.threads, pl.cpus);
+    }
+    a->full.pool->run(n, grain, f);
+}
+
+void abea_host_join_async(abea_ctx* c) {
+    if (!c->async) return;
+    for (abea_async_job& j : c->async->jobs) if (j.th.joinable()) j.th.join();
 }
 
 void abea_host_release(abea_ctx* c) {
@@ -159,8 +346,12 @@ void abea_host_release(abea_ctx* c) {
         delete s;
     }
     c->slots.clear();
-    delete c->pool;
-    c->pool = nullptr;
+    if (c->async) {
+        for (abea_async_job& j : c->async->jobs) if (j.th.joinable()) j.th.join();
+        lanes_release(c);
+        delete c->async;
+        c->async = nullptr;
+    }
 }
 
 /* ------------------------------------------------------------------ un-flatten helpers */
@@ -207,7 +398,7 @@ static host_opts read_opts() {
     if (const char* e = getenv("ABEA_HOST_CHUNK_EVENTS")) o.chunk_events = std::max<size_t>(1, strtoull(e, nullptr, 10));
     if (const char* e = getenv("ABEA_HOST_CHUNK_READS")) o.chunk_reads_min = std::max(1, atoi(e));
     if (const char* e = getenv("ABEA_HOST_CHUNK_READS_MAX")) o.chunk_reads_max = std::max(1, atoi(e));
-    if (const char* e = getenv("ABEA_HOST_SLOTS")) o.n_slots = std::min(8, std::max(1, atoi(e)));
+    if (const char* e = getenv("ABEA_HOST_SLOTS")) o.n_slots = std::min(ABEA_MAX_SLOTS, std::max(1, atoi(e)));
     if (const char* e = getenv("ABEA_HOST_PAIRS")) o.device_pairs = strcmp(e, "device") == 0;
     o.sdma_d2h = getenv("ABEA_HOST_SDMA_D2H") != nullptr;
     o.chunk_reads_max = std::max(o.chunk_reads_max, o.chunk_reads_min);
@@ -301,6 +492,7 @@ struct host_run_state {
         if (trace) fprintf(stderr, "[abea host dev %d] %8.2f ms  chunk %2d  %-14s reads %d events %zu\n", c->device, abea_now_ms() - t_origin, chunk, what, m, ev);
     }
     abea_ctx* c;
+    abea_host_lane* lane;
     const abea_host_batch* H;
     host_opts opt;
     bool want_pairs, scaling, device_pairs;
@@ -350,7 +542,7 @@ static int slot_retire(host_run_state& S, abea_host_slot& sl) {
     const int32_t* nal = (const int32_t*)(sl.dn + sl.o_nal);
     t0 = abea_now_ms();
     const bool want_pairs = S.want_pairs, dev_pairs = sl.device_pairs, scaling = sl.scaling;
-    S.c->pool->run(sl.m, 1, [&](int64_t lo, int64_t hi) {
+    S.lane->pool->run(sl.m, 1, [&](int64_t lo, int64_t hi) {
         for (int64_t j = lo; j < hi; ++j) {
             const int32_t i = sl.rd[(size_t)j];
             const int32_t np = npairs[j];
@@ -384,22 +576,48 @@ static int slot_retire(host_run_state& S, abea_host_slot& sl) {
 /* on every exit, error or not, nothing of this call may stay in flight: the slots' bookkeeping and the pinned /
  * caller buffers they point at belong to this batch only */
 struct slot_guard {
-    abea_ctx* c;
+    abea_ctx* c; const abea_host_lane* lane;
     ~slot_guard() {
-        for (abea_host_slot* s : c->slots)
+        for (int q = lane->first_slot; q < lane->first_slot + lane->n_slots && q < (int)c->slots.size(); ++q) {
+            abea_host_slot* s = c->slots[(size_t)q];
             if (s && s->busy) { hipStreamSynchronize(s->stream); s->busy = false; }
+        }
     }
 };
 
-static int host_run(abea_ctx* c, const abea_host_batch* H, const int32_t* mine, int32_t n_mine, int host_threads,
+/* the lanes of a DEVICE context, built on first use: the full lane and n_lanes equal shares.  Slot objects (stream,
+ * events, pinned staging) are created on demand by host_run; a slot index belongs to exactly one share and the full lane
+ * is only used while no share is (the top-level context's bookkeeping guarantees it). */
+static void ensure_lanes(abea_ctx* c, const host_thread_plan& pl, int n_lanes, int n_slots) {
+    abea_host_async* a = async_of(c);
+    if (!a->full.pool || a->full.pool->threads() != pl.threads) {
+        delete a->full.pool;
+        a->full.pool = new abea_host_pool(pl.threads, pl.cpus);
+    }
+    a->full.first_slot = 0; a->full.n_slots = n_slots; a->full.arena_off = 0; a->full.arena_bytes = c->arena_bytes;
+    const int per_threads = std::max(1, pl.threads / std::max(1, n_lanes));
+    if ((int)a->lanes.size() != n_lanes || (n_lanes && a->lanes[0].pool->threads() != per_threads)) {
+        for (abea_host_lane& l : a->lanes) delete l.pool;
+        a->lanes.assign((size_t)n_lanes, abea_host_lane());
+        const int per_slots = std::max(1, n_slots / std::max(1, n_lanes));
+        const size_t per_arena = c->arena_bytes / (size_t)std::max(1, n_lanes) / 4096 * 4096;
+        for (int l = 0; l < n_lanes; ++l) {
+            a->lanes[(size_t)l].first_slot = l * per_slots; a->lanes[(size_t)l].n_slots = per_slots;
+            a->lanes[(size_t)l].arena_off = (size_t)l * per_arena; a->lanes[(size_t)l].arena_bytes = per_arena;
+            a->lanes[(size_t)l].pool = new abea_host_pool(per_threads, pl.cpus);
+        }
+    }
+}
+
+static int host_run(abea_ctx* c, const abea_host_batch* H, const int32_t* mine, int32_t n_mine, abea_host_lane& lane,
                     abea_stats* st_out) {
     const double t_start = abea_now_ms();
     HIP_TRY(hipSetDevice(c->device));          /* the caller's thread changes per batch (f5c.cu:692-694) */
     host_run_state S;
-    S.c = c; S.H = H; S.opt = read_opts();
+    S.c = c; S.lane = &lane; S.H = H; S.opt = read_opts();
     S.t_origin = t_start; S.trace = getenv("ABEA_HOST_TRACE") != nullptr;
     memset(&S.st, 0, sizeof S.st);
-    S.st.arena_bytes = c->arena_bytes;
+    S.st.arena_bytes = lane.arena_bytes;
     S.st.n_devices = 1;
     S.scaling = H->base_to_event_map != nullptr;
     S.want_pairs = H->pairs != nullptr;
@@ -408,17 +626,24 @@ static int host_run(abea_ctx* c, const abea_host_batch* H, const int32_t* mine, 
     const bool pairs_on_device = S.device_pairs || scaling;       /* the scaling kernel reads the pair lists in HBM */
 
     /* ---- worker pool and slots (persistent across calls) ---- */
-    if (!c->pool || c->pool->threads() != host_threads) { delete c->pool; c->pool = new abea_host_pool(host_threads); }
-    S.st.host_threads = c->pool->threads();
-    while ((int)c->slots.size() < S.opt.n_slots) {
-        abea_host_slot* s = nullptr;
-        const int rc = slot_create(&s);
-        c->slots.push_back(s);
-        if (rc) return rc;
+    S.st.host_threads = lane.pool->threads();
+    const int n_slots = lane.n_slots, slot0 = lane.first_slot;
+    {
+        std::lock_guard<std::mutex> lk(c->slots_mu);             /* sized once: lanes of one device index it concurrently */
+        if (c->slots.size() < (size_t)ABEA_MAX_SLOTS) c->slots.resize((size_t)ABEA_MAX_SLOTS, nullptr);
     }
-    const int n_slots = S.opt.n_slots;
-    for (abea_host_slot* s : c->slots) s->busy = false;          /* nothing survives a call (slot_guard) */
-    slot_guard guard{c};
+    for (int q = slot0; q < slot0 + n_slots; ++q) {
+        if (!c->slots[(size_t)q]) {
+            abea_host_slot* s = nullptr;
+            const int rc = slot_create(&s);
+            c->slots[(size_t)q] = s;
+            if (rc) return rc;
+        }
+        c->slots[(size_t)q]->busy = false;                       /* nothing survives a call (slot_guard) */
+    }
+    slot_guard guard{c, &lane};
+    uint8_t* const lane_arena = c->arena + lane.arena_off;
+    auto slot_at = [&](int q) -> abea_host_slot& { return *c->slots[(size_t)(slot0 + q)]; };
 
     /* ---- guards (align_single, f5c.c:811-830) and ordering ---- */
     S.reads.resize((size_t)n_mine);
@@ -455,11 +680,11 @@ static int host_run(abea_ctx* c, const abea_host_batch* H, const int32_t* mine, 
     /* check every read against the arena before anything is launched */
     for (int32_t q : order) {
         const plan_read& r = S.reads[(size_t)q];
-        if (scratch_bytes(r) + io_bytes(r) + 65536 > c->arena_bytes)
+        if (scratch_bytes(r) + io_bytes(r) + 65536 > lane.arena_bytes)
             return abea_fail(ABEA_ENOMEM, "read %d (L=%d, E=%d) needs more scratch than the %zu-byte arena", r.idx, r.L, r.E,
-                             c->arena_bytes);
+                             lane.arena_bytes);
     }
-    const size_t slot_arena = c->arena_bytes / (size_t)n_slots / 4096 * 4096;
+    const size_t slot_arena = lane.arena_bytes / (size_t)n_slots / 4096 * 4096;
     const int min_rescale = H->min_num_events_to_rescale > 0 ? H->min_num_events_to_rescale : 200;
 
     const std::vector<chunk_span> chunks = carve_chunks(S.reads, order, S.opt, slot_arena, pairs_on_device, scaling);
@@ -468,11 +693,11 @@ static int host_run(abea_ctx* c, const abea_host_batch* H, const int32_t* mine, 
         const size_t pos = chunks[(size_t)chunk_no].begin, end = chunks[(size_t)chunk_no].end, ev = chunks[(size_t)chunk_no].events;
         const bool whole_arena = chunks[(size_t)chunk_no].whole_arena;
         const int32_t m = (int32_t)(end - pos);
-        abea_host_slot& sl = *c->slots[(size_t)(whole_arena ? 0 : turn % n_slots)];
+        abea_host_slot& sl = slot_at(whole_arena ? 0 : turn % n_slots);
         int rc;
-        if (whole_arena) { for (abea_host_slot* o : c->slots) if ((rc = slot_retire(S, *o))) return rc; }
+        if (whole_arena) { for (int q = 0; q < n_slots; ++q) if ((rc = slot_retire(S, slot_at(q)))) return rc; }
         else if ((rc = slot_retire(S, sl))) return rc;
-        uint8_t* arena = whole_arena ? c->arena : c->arena + (size_t)(turn % n_slots) * slot_arena;
+        uint8_t* arena = whole_arena ? lane_arena : lane_arena + (size_t)(turn % n_slots) * slot_arena;
 
         /* ---- plan the chunk ---- */
         double t0 = abea_now_ms();
@@ -536,9 +761,9 @@ static int host_run(abea_ctx* c, const abea_host_batch* H, const int32_t* mine, 
         if (S.device_pairs || !S.want_pairs) { d_codes_scratch = (uint32_t*)p; p += align_up(lay.n_code * 4, 256); }
         abea_pair_t* d_pairs = nullptr;
         if (pairs_on_device) { d_pairs = (abea_pair_t*)p; p += align_up(n_pair * sizeof(abea_pair_t), 256); }
-        if ((size_t)(p - arena) > (whole_arena ? c->arena_bytes : slot_arena))
+        if ((size_t)(p - arena) > (whole_arena ? lane.arena_bytes : slot_arena))
             return abea_fail(ABEA_ENOMEM, "internal: chunk layout %zu exceeds its arena share %zu", (size_t)(p - arena),
-                             whole_arena ? c->arena_bytes : slot_arena);
+                             whole_arena ? lane.arena_bytes : slot_arena);
         const abea_read_desc* d_desc = (const abea_read_desc*)(d_up + u_desc);
         const char* d_reads = (const char*)(d_up + u_reads);
         float* d_evm = (float*)(d_up + u_evm);
@@ -553,7 +778,7 @@ static int host_run(abea_ctx* c, const abea_host_batch* H, const int32_t* mine, 
         char* h_reads = (char*)(sl.up + u_reads);
         float* h_evm = (float*)(sl.up + u_evm);
         S.log("flatten", chunk_no);
-        c->pool->run(m, 1, [&](int64_t lo, int64_t hi) {
+        lane.pool->run(m, 1, [&](int64_t lo, int64_t hi) {
             for (int64_t j = lo; j < hi; ++j) {
                 const abea_read_desc& d = descs[j];
                 const int32_t i = sl.rd[(size_t)j];
@@ -619,11 +844,11 @@ static int host_run(abea_ctx* c, const abea_host_batch* H, const int32_t* mine, 
         S.st.n_sub_batches += 1; S.st.fill_launches += 1;
         if (whole_arena) { if ((rc = slot_retire(S, sl))) return rc; }
         else ++turn;
-        for (abea_host_slot* o2 : c->slots) if ((rc = slot_stage(S, *o2, false))) return rc;
+        for (int q = 0; q < n_slots; ++q) if ((rc = slot_stage(S, slot_at(q), false))) return rc;
     }
     /* ---- drain, oldest chunk first ---- */
     for (int q = 0; q < n_slots; ++q) {
-        int rc = slot_retire(S, *c->slots[(size_t)((turn + q) % n_slots)]);
+        int rc = slot_retire(S, slot_at((turn + q) % n_slots));
         if (rc) return rc;
     }
     S.st.host_ms = S.st.flatten_ms + S.st.unflatten_ms;
@@ -635,7 +860,7 @@ static int host_run(abea_ctx* c, const abea_host_batch* H, const int32_t* mine, 
 /* ------------------------------------------------------------------ multi-device split */
 /* Longest-processing-time-first on the band count E + K (f5c_amd/synth.py shard_batch is the same rule):
  * reads in descending weight go to the currently lightest device; ties by lowest device index.  `weight[i] <= 0`
- * reads (guard failures) are dealt round-robin: they cost nothing. */
+ * reads (guard failures) come last and all land in whichever bin is lightest then: they cost nothing. */
 extern "C" int abea_lpt_split(const int64_t* weight, int32_t n, int32_t n_bins, int32_t* bin_of) {
     if (!weight || !bin_of || n < 0 || n_bins < 1) return abea_fail(ABEA_EINVAL, "abea_lpt_split: bad argument");
     std::vector<int32_t> order((size_t)n);
@@ -663,25 +888,49 @@ static void stats_add(abea_stats& a, const abea_stats& b) {
     a.h2d_bytes += b.h2d_bytes; a.d2h_bytes += b.d2h_bytes; a.host_threads += b.host_threads;
 }
 
-extern "C" int abea_align_batch_host(abea_ctx* c, const abea_host_batch* H) {
-    if (!c || !H) return abea_fail(ABEA_EINVAL, "null argument");
-    const int32_t n = H->n_reads;
-    if (n < 0) return abea_fail(ABEA_EINVAL, "n_reads < 0");
-    if (n == 0) { memset(&c->stats, 0, sizeof c->stats); return ABEA_OK; }
+static int check_host_batch(const abea_host_batch* H) {
+    if (!H) return abea_fail(ABEA_EINVAL, "null argument");
+    if (H->n_reads < 0) return abea_fail(ABEA_EINVAL, "n_reads < 0");
+    if (H->n_reads == 0) return ABEA_OK;
     if (!H->read || !H->read_len || !H->events || !H->n_events || !H->scalings || !H->n_pairs)
         return abea_fail(ABEA_EINVAL, "abea_align_batch_host: null array");
     if (!H->pairs && !H->base_to_event_map)
         return abea_fail(ABEA_EINVAL, "abea_align_batch_host: neither pairs nor base_to_event_map requested");
-    const double t_start = abea_now_ms();
-    const int threads = abea_default_host_threads();
-    if (c->children.empty()) {
-        abea_stats st;
-        const int rc = host_run(c, H, nullptr, n, threads, &st);
-        if (rc) return rc;
-        c->stats = st;
-        return ABEA_OK;
+    return ABEA_OK;
+}
+
+/* temporarily move the calling thread onto the CPUs of its device's NUMA node (it takes part in the host loops and
+ * first-touches what it allocates); restored on scope exit — the caller's thread is f5c's, not ours */
+struct affinity_scope {
+    cpu_set_t saved; bool active = false;
+    explicit affinity_scope(const std::vector<int>& cpus) {
+        if (cpus.empty() || sched_getaffinity(0, sizeof saved, &saved) != 0) return;
+        active = true;
+        bind_this_thread(cpus);
     }
-    /* ---- several devices: LPT split, one host thread (and its share of the workers) per device ---- */
+    ~affinity_scope() { if (active) sched_setaffinity(0, sizeof saved, &saved); }
+};
+
+/* One host batch on lane `lane_no` (-1 = the full lane) of every device of the context: single device, or LPT split over
+ * the children with one driver thread per device. */
+static int run_host_batch(abea_ctx* c, const abea_host_batch* H, int lane_no, int n_lanes, abea_stats* st_out) {
+    const int32_t n = H->n_reads;
+    const double t_start = abea_now_ms();
+    const host_opts opt = read_opts();
+    const std::vector<host_thread_plan> plan = context_thread_plan(c);
+    auto lane_of = [&](abea_ctx* dev, const host_thread_plan& pl) -> abea_host_lane& {
+        {
+            std::lock_guard<std::mutex> lk(dev->slots_mu);
+            ensure_lanes(dev, pl, n_lanes, opt.n_slots);
+        }
+        abea_host_async* a = async_of(dev);
+        return lane_no < 0 ? a->full : a->lanes[(size_t)lane_no];
+    };
+    if (c->children.empty()) {
+        affinity_scope bound(plan[0].cpus);
+        return host_run(c, H, nullptr, n, lane_of(c, plan[0]), st_out);
+    }
+    /* ---- several devices: LPT split, one driver thread and one worker pool per device ---- */
     const int32_t nd = (int32_t)c->children.size();
     std::vector<int64_t> weight((size_t)n);
     for (int32_t i = 0; i < n; ++i) {
@@ -698,25 +947,94 @@ extern "C" int abea_align_batch_host(abea_ctx* c, const abea_host_batch* H) {
     std::vector<int> rcs((size_t)nd, ABEA_OK);
     std::vector<abea_stats> sts((size_t)nd);
     std::vector<std::string> errs((size_t)nd);
-    const int per_dev = std::max(1, threads / nd);
     std::vector<std::thread> th;
     for (int32_t d = 0; d < nd; ++d)
         th.emplace_back([&, d]() {
+            bind_this_thread(plan[(size_t)d].cpus);                       /* this thread lives for one batch */
             memset(&sts[(size_t)d], 0, sizeof(abea_stats));
-            rcs[(size_t)d] = host_run(c->children[(size_t)d], H, share[(size_t)d].data(), (int32_t)share[(size_t)d].size(),
-                                      per_dev, &sts[(size_t)d]);
+            abea_ctx* dev = c->children[(size_t)d];
+            rcs[(size_t)d] = host_run(dev, H, share[(size_t)d].data(), (int32_t)share[(size_t)d].size(), lane_of(dev, plan[(size_t)d]),
+                                      &sts[(size_t)d]);
             if (rcs[(size_t)d]) errs[(size_t)d] = abea_last_error();       /* the message is thread-local */
         });
     for (auto& t : th) t.join();
     abea_stats st; memset(&st, 0, sizeof st);
     for (int32_t d = 0; d < nd; ++d) {
         if (rcs[(size_t)d]) return abea_fail(rcs[(size_t)d], "device %d: %s", c->children[(size_t)d]->device, errs[(size_t)d].c_str());
-        c->children[(size_t)d]->stats = sts[(size_t)d];
+        if (lane_no < 0) c->children[(size_t)d]->stats = sts[(size_t)d];
         stats_add(st, sts[(size_t)d]);
     }
     st.n_devices = nd;
     st.total_ms = abea_now_ms() - t_start;
+    *st_out = st;
+    return ABEA_OK;
+}
+
+extern "C" int abea_align_batch_host(abea_ctx* c, const abea_host_batch* H) {
+    if (!c) return abea_fail(ABEA_EINVAL, "null argument");
+    int rc = check_host_batch(H);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> api(c->api_mu);
+    if (async_of(c)->n_active) return abea_fail(ABEA_EBUSY, "abea_align_batch_host: %d submitted batch(es) still in flight", c->async->n_active);
+    if (H->n_reads == 0) { memset(&c->stats, 0, sizeof c->stats); return ABEA_OK; }
+    abea_stats st;
+    rc = run_host_batch(c, H, -1, async_of(c)->n_lanes, &st);
+    if (rc) return rc;
     c->stats = st;
+    return ABEA_OK;
+}
+
+/* ------------------------------------------------------------------ several host batches in flight */
+extern "C" int abea_set_inflight(abea_ctx* c, int32_t n_lanes) {
+    if (!c || n_lanes < 1 || n_lanes > ABEA_MAX_INFLIGHT) return abea_fail(ABEA_EINVAL, "abea_set_inflight: 1..%d lanes", ABEA_MAX_INFLIGHT);
+    std::lock_guard<std::mutex> api(c->api_mu);
+    abea_host_async* a = async_of(c);
+    if (a->n_active) return abea_fail(ABEA_EBUSY, "abea_set_inflight: %d batch(es) in flight", a->n_active);
+    a->n_lanes = n_lanes;
+    return ABEA_OK;
+}
+
+extern "C" int abea_align_batch_host_submit(abea_ctx* c, const abea_host_batch* H, int32_t* ticket) {
+    if (!c || !ticket) return abea_fail(ABEA_EINVAL, "null argument");
+    int rc = check_host_batch(H);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> api(c->api_mu);
+    abea_host_async* a = async_of(c);
+    int lane = -1;
+    for (int l = 0; l < a->n_lanes; ++l) if (!a->jobs[l].active) { lane = l; break; }
+    if (lane < 0) return abea_fail(ABEA_EBUSY, "abea_align_batch_host_submit: all %d lanes are busy (wait for a ticket first)", a->n_lanes);
+    abea_async_job& j = a->jobs[lane];
+    if (j.th.joinable()) j.th.join();
+    j.H = *H; j.rc = ABEA_OK; j.err.clear(); j.active = true; ++j.gen;
+    memset(&j.st, 0, sizeof j.st);
+    ++a->n_active;
+    const int n_lanes = a->n_lanes;
+    *ticket = (int32_t)((j.gen & 0xFFFFFFu) << 3) | lane;
+    abea_async_job* jp = &j;
+    j.th = std::thread([c, jp, lane, n_lanes]() {
+        if (jp->H.n_reads > 0) jp->rc = run_host_batch(c, &jp->H, lane, n_lanes, &jp->st);
+        if (jp->rc) jp->err = abea_last_error();
+    });
+    return ABEA_OK;
+}
+
+extern "C" int abea_align_batch_host_wait(abea_ctx* c, int32_t ticket) {
+    if (!c || ticket < 0) return abea_fail(ABEA_EINVAL, "abea_align_batch_host_wait: bad argument");
+    const int lane = ticket & 7;
+    abea_async_job* j = nullptr;
+    {
+        std::lock_guard<std::mutex> api(c->api_mu);
+        abea_host_async* a = async_of(c);
+        if (lane >= ABEA_MAX_INFLIGHT || !a->jobs[lane].active || (int32_t)((a->jobs[lane].gen & 0xFFFFFFu) << 3 | lane) != ticket)
+            return abea_fail(ABEA_EINVAL, "abea_align_batch_host_wait: ticket %d is not in flight", ticket);
+        j = &a->jobs[lane];
+    }
+    if (j->th.joinable()) j->th.join();                      /* outside the lock: other tickets can be submitted / waited meanwhile */
+    std::lock_guard<std::mutex> api(c->api_mu);
+    j->active = false;
+    --c->async->n_active;
+    if (j->rc) return abea_fail(j->rc, "%s", j->err.c_str());
+    c->stats = j->st;
     return ABEA_OK;
 }
 

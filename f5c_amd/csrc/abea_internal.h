@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <mutex>
 #include <vector>
 #include "abea_device.h"
 
@@ -39,6 +40,8 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 
 /* ------------------------------------------------------------------ context */
 struct abea_host_pool;      /* abea_host.cpp: persistent host worker threads */
+struct abea_host_async;     /* abea_host.cpp: lanes (slot set + arena share + pool) and the batches in flight */
+static const int ABEA_MAX_SLOTS = 8;        /* stream slots per device context */
 struct abea_host_slot;      /* abea_host.cpp: one chunk in flight (stream, pinned staging, arena share) */
 struct abea_hmm_state;      /* abea_hmm.cpp: log-sum table, CpG model copy, staging of the profile-HMM entry (row N4) */
 
@@ -55,20 +58,31 @@ struct abea_ctx {
     /* pinned staging for descriptors (device entry, event detection) */
     abea_read_desc* h_desc = nullptr; size_t h_desc_cap = 0;
     /* host-buffer entry (abea_host.cpp), created on first use */
-    abea_host_pool* pool = nullptr;
     std::vector<abea_host_slot*> slots;
+    std::mutex slots_mu;
+    abea_host_async* async = nullptr;
+    int numa_node = -1;                         /* of the device (sysfs), -1 unknown */
+    /* one caller at a time per context: every public entry that touches the arena / pool / staging holds this */
+    std::mutex api_mu;
     abea_hmm_state* hmm = nullptr;
     /* abea_init_multi: a parent context owns one child per device and no device state of its own */
     std::vector<abea_ctx*> children;
     abea_stats stats;
 };
 
+void abea_host_join_async(abea_ctx* c);     /* joins the threads of submitted host batches (abea_host.cpp) */
 void abea_host_release(abea_ctx* c);       /* frees pool + slots (abea_host.cpp); called by abea_free */
 void abea_hmm_release(abea_ctx* c);        /* abea_hmm.cpp */
 /* run f(lo, hi) over [0, n) in pieces of `grain` items on the context's persistent worker pool (created on first use;
  * the caller's thread takes part) — abea_host.cpp */
 void abea_parallel_for(abea_ctx* c, int64_t n, int64_t grain, const std::function<void(int64_t, int64_t)>& f);
 int abea_default_host_threads();
+int abea_host_batches_in_flight(abea_ctx* c);   /* abea_host.cpp: submitted and not yet waited for */
+/* the single-caller-per-context contract, enforced: a public entry that uses the arena / pool / staging holds api_mu for
+ * its duration and refuses to run while submitted host batches are in flight */
+#define ABEA_API_ENTER(c, name) std::lock_guard<std::mutex> api_lock_((c)->api_mu); \
+    if (abea_host_batches_in_flight(c)) return abea_fail(ABEA_EBUSY, name ": submitted host batches are still in flight")
+int abea_device_numa_node(int device);      /* abea_host.cpp: sysfs numa_node of a HIP device's PCI function */
 
 /* ------------------------------------------------------------------ batch planning */
 struct plan_read {

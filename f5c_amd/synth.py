@@ -125,10 +125,23 @@ def _chunk(idx, lengths, model, k, seed, bad_frac):
 _G = {}
 
 
+def _pool_init(args):
+    _G["args"] = args
+
+
 def _chunk_job(c):
     idx, L, model, k, seed, bad_frac, chunk_reads = _G["args"]
     sl = slice(c * chunk_reads, (c + 1) * chunk_reads)
     return _chunk(idx[sl], L[sl], model, k, seed, bad_frac)
+
+
+_TOOL_ENV = ("LD_PRELOAD", "HSA_TOOLS_LIB", "ROCP_TOOL_LIBRARIES", "ROCP_TOOL_LIB")
+
+
+def _under_profiler():
+    import os
+    return any(("rocprof" in os.environ.get(v, "").lower()) for v in _TOOL_ENV) or \
+        any(v.startswith("ROCPROF") for v in os.environ)
 
 
 def batch_lengths(n_reads, seed, law):
@@ -139,7 +152,9 @@ def batch_lengths(n_reads, seed, law):
 def make_batch(n_reads, model, k, seed, law="gamma8k", bad_frac=0.01, chunk_reads=256, lengths=None,
                workers=1, subset=None):
     """Build a flattened batch. `lengths` overrides the length law (array of read lengths).
-    `workers` > 1 generates chunks in forked processes (same result: every read has its own generator).
+    `workers` > 1 generates chunks in worker processes (same result: every read has its own generator): forked
+    normally; under rocprofv3 the workers are SPAWNED with the profiler's preload variables removed (forking a
+    process that carries the profiler's tool threads hung the 100k-read WRITE_SIZE pass of round 2).
     `subset`: indices of the reads to build (in that order) instead of the whole batch."""
     L = np.asarray(lengths, dtype=np.int64) if lengths is not None else batch_lengths(n_reads, seed, law)
     idx = np.arange(len(L), dtype=np.int64)
@@ -151,8 +166,18 @@ def make_batch(n_reads, model, k, seed, law="gamma8k", bad_frac=0.01, chunk_read
     _G["args"] = (idx, L, model, k, seed, bad_frac, chunk_reads)
     if workers > 1 and n_chunks > 1:
         import multiprocessing as mp
-        with mp.get_context("fork").Pool(min(workers, n_chunks)) as pool:
-            parts = pool.map(_chunk_job, range(n_chunks), chunksize=1)
+        import os
+        if _under_profiler() or os.environ.get("ABEA_SYNTH_SPAWN"):
+            saved = {v: os.environ.pop(v) for v in list(os.environ) if v in _TOOL_ENV or v.startswith("ROCPROF")}
+            try:
+                with mp.get_context("spawn").Pool(min(workers, n_chunks), initializer=_pool_init,
+                                                  initargs=(_G["args"],)) as pool:
+                    parts = pool.map(_chunk_job, range(n_chunks), chunksize=1)
+            finally:
+                os.environ.update(saved)
+        else:
+            with mp.get_context("fork").Pool(min(workers, n_chunks)) as pool:
+                parts = pool.map(_chunk_job, range(n_chunks), chunksize=1)
     else:
         parts = [_chunk_job(c) for c in range(n_chunks)]
     seqs = [p[0] for p in parts]; evs = [p[1] for p in parts]; Es = [p[2] for p in parts]

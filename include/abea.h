@@ -27,6 +27,7 @@ extern "C" {
 #define ABEA_EHIP         -2        /* HIP runtime error */
 #define ABEA_ENOMEM       -3        /* a single read does not fit the device arena */
 #define ABEA_ENODEV       -4        /* no usable gfx950 device */
+#define ABEA_EBUSY        -5        /* submitted host batches are in flight / no free lane */
 
 /* ---- POD mirrors of the f5c data contract (layout-identical, static_asserted in abea_capi.cpp) ---- */
 typedef struct { uint64_t start; float length; float mean; float stdv; } abea_event_t;          /* event_t     src/f5c.h:129-136 */
@@ -51,6 +52,12 @@ typedef struct {
 #define ABEA_RF_NO_END    0x2   /* no in-band end cell (max_score == -inf): n_pairs = 0 */
 #define ABEA_RF_QC_FAIL   0x4   /* align.c:534-543 */
 
+/* THREADING CONTRACT.  A context owns shared mutable state (device arena, stream slots with pinned staging, worker pool):
+ * it serves ONE call at a time, from any host thread (the thread may change between calls, as f5c's pthread_processor
+ * does, src/meth_main.c:668-689).  The library enforces it: every entry that touches that state holds a per-context
+ * mutex, so a second thread calling into the same context BLOCKS until the first call returns (it never corrupts the
+ * arena).  Callers that want concurrency — e.g. the methylation stage under pthread_db — use one context per thread, or
+ * abea_align_batch_host_submit()/_wait() below, the one sanctioned way to have several batches in flight on one context. */
 typedef struct abea_ctx abea_ctx;   /* opaque; owns the device arena, the model copy, a stream (cuda_data_t, src/f5c.h:356-386) */
 
 typedef struct {
@@ -116,6 +123,22 @@ typedef struct {
  * environment moves the expansion back to the GPU (pair lists compacted on the device, then copied down).
  * Results do not depend on the chunking, the mode or the number of devices. */
 int abea_align_batch_host(abea_ctx* ctx, const abea_host_batch* batch);
+
+/* ---- several host batches in flight on one context (f5c's default -K 512 / -B 2M batches are latency-bound: one lasts
+ * as long as its longest read and fills an eighth of the GPU's wave slots, so a drop-in at default flags leaves the
+ * device idle; the reference overlaps only I/O with processing, src/meth_main.c:668-689) ----
+ * abea_align_batch_host_submit() starts the batch on a free LANE — a disjoint share of the context's stream slots,
+ * device arena and worker threads — on a thread of the library, and returns a ticket at once;
+ * abea_align_batch_host_wait() blocks until that batch's outputs are complete and returns its status.  `batch` is copied;
+ * every array it points to (inputs AND outputs) must stay valid and untouched until the wait returns.  Up to
+ * abea_set_inflight() batches (default 2, at most ABEA_MAX_INFLIGHT) can be in flight; with all lanes busy submit returns
+ * ABEA_EBUSY.  Results are bit-identical to abea_align_batch_host().  While batches are in flight the synchronous entries
+ * of the same context return ABEA_EBUSY.  Works on multi-device contexts (every device runs lane l of each batch).
+ * abea_get_stats() reports the batch of the last successful wait. */
+#define ABEA_MAX_INFLIGHT 4
+int abea_set_inflight(abea_ctx* ctx, int32_t n_lanes);      /* only while nothing is in flight; a lane gets 1/n of slots, arena, threads */
+int abea_align_batch_host_submit(abea_ctx* ctx, const abea_host_batch* batch, int32_t* ticket);
+int abea_align_batch_host_wait(abea_ctx* ctx, int32_t ticket);
 
 /* ---- device-resident flattened batch: the layout of the reference's device arrays (src/f5c.cu:672-690) ---- */
 typedef struct {
@@ -251,6 +274,16 @@ int abea_expand_walk_codes(const uint32_t* codes, int32_t n_steps, int32_t last_
  * ABEA_HOST_SLOTS in the environment override the numbers. */
 int abea_host_plan_chunks(const int32_t* read_len, const int32_t* n_events, int32_t n_reads, uint32_t kmer_size,
                           uint64_t arena_bytes, int32_t* chunk_of, int32_t* n_chunks);
+
+/* The worker-thread / CPU-affinity plan of the host entry (host-only, pure): per DEVICE context
+ * threads = (usable_cpus - 2) / n_devices clamped to [1, 16] (ABEA_HOST_THREADS overrides, per device), bound to the CPUs of
+ * the device's NUMA node that the process may run on when the machine has several nodes and that set is at least as large
+ * (ABEA_HOST_NUMA=0 disables binding).  cpulists use the sysfs format ("0-63,128-191"); allowed_cpulist NULL or "" = all.
+ * bind_cpulists (may be NULL) receives n_devices strings of cap_each bytes, "" = not bound.  At run time the inputs come
+ * from sched_getaffinity, the cgroup CPU quota, /sys/bus/pci/devices/<bdf>/numa_node and /sys/devices/system/node. */
+int abea_host_plan_threads(int32_t usable_cpus, const char* allowed_cpulist, int32_t n_devices, const int32_t* device_numa_node,
+                           int32_t n_nodes, const char* const* node_cpulist, int32_t* threads_per_device, char* bind_cpulists,
+                           size_t cap_each);
 
 /* Library / device introspection: "gfx950", CU count; used by tests to assert the native path ran. */
 int abea_device_info(abea_ctx* ctx, char* arch, size_t arch_len, int32_t* n_cu, uint64_t* arena_bytes);

@@ -1,0 +1,154 @@
+"""The host entry's thread / affinity plan (pure function, CPU) and several host batches in flight on one context
+(abea_align_batch_host_submit / _wait, GPU): results bit-identical to the synchronous entry and to the oracle."""
+import threading
+import numpy as np
+import pytest
+
+NODES = ["0-63,128-191", "64-127,192-255"]          # a two-socket host, SMT siblings in the upper half
+
+
+def test_thread_plan_is_per_device(monkeypatch):
+    """Round-2 verdict: the pool was 16 threads in TOTAL (2 per GPU on 8 GPUs).  Now every device context gets
+    (usable CPUs - 2) / n_devices threads, clamped to [1, 16]."""
+    from f5c_amd import abea
+    monkeypatch.delenv("ABEA_HOST_THREADS", raising=False)
+    monkeypatch.delenv("ABEA_HOST_NUMA", raising=False)
+    for cpus in (8, 16, 64, 128, 256):
+        for nd in (1, 2, 4, 8):
+            thr, _ = abea.plan_host_threads(cpus, nd)
+            assert (thr == thr[0]).all()
+            assert thr[0] == max(1, min(16, (cpus - 2) // nd))
+            assert thr[0] >= min(16, (cpus - 2) // nd)                      # "8 contexts get >= (cpus-2)/8 workers each"
+            assert nd * thr[0] <= max(nd, cpus - 2) or thr[0] == 1          # never wider than the CPUs there are
+    thr, _ = abea.plan_host_threads(256, 8)
+    assert thr.sum() == 128                                                 # was 16 in round 2
+    assert abea.plan_host_threads(3, 1)[0][0] == 3 and abea.plan_host_threads(1, 1)[0][0] == 1
+    monkeypatch.setenv("ABEA_HOST_THREADS", "5")
+    assert (abea.plan_host_threads(256, 4)[0] == 5).all()
+
+
+def test_thread_plan_binds_to_the_devices_numa_node(monkeypatch):
+    from f5c_amd import abea
+    monkeypatch.delenv("ABEA_HOST_THREADS", raising=False)
+    monkeypatch.delenv("ABEA_HOST_NUMA", raising=False)
+    dev_node = [0, 0, 0, 0, 1, 1, 1, 1]
+    thr, bind = abea.plan_host_threads(256, 8, dev_node, NODES)
+    assert bind[:4] == [NODES[0]] * 4 and bind[4:] == [NODES[1]] * 4
+    # the process's affinity mask is honoured; a node with fewer allowed CPUs than threads is not bound to
+    thr, bind = abea.plan_host_threads(64, 2, [0, 1], NODES, allowed="0-31,64-71")
+    assert thr.tolist() == [16, 16] and bind == ["0-31", ""]
+    # unknown node, a single-node machine, or ABEA_HOST_NUMA=0: no binding
+    assert abea.plan_host_threads(64, 2, [-1, 5], NODES)[1] == ["", ""]
+    assert abea.plan_host_threads(64, 1, [0], NODES[:1])[1] == [""]
+    monkeypatch.setenv("ABEA_HOST_NUMA", "0")
+    assert abea.plan_host_threads(256, 8, dev_node, NODES)[1] == [""] * 8
+    with pytest.raises(abea.AbeaError):
+        abea.plan_host_threads(0, 1)
+
+
+# ------------------------------------------------------------------------------------------------ GPU
+def _views(ctx, r9, n_batches, seed0, n_reads=180, law=1500):
+    from f5c_amd import synth
+    k, model = r9
+    batches = [synth.make_batch(n_reads, model, k, seed=seed0 + j, law=law, bad_frac=0.05) for j in range(n_batches)]
+    return batches, [ctx.host_view(b, want_diag=True) for b in batches]
+
+
+def _check(view, batch, ora):
+    o_pairs, o_n, o_diag = ora
+    assert (view["n_pairs"] == o_n).all()
+    for i in range(len(o_n)):
+        s = int(batch["pair_ptr"][i])
+        assert (view["pairs"][s:s + o_n[i]] == o_pairs[s:s + o_n[i]]).all(), i
+    ok = o_n > 0
+    assert (view["diag"]["sum_emission"][ok] == o_diag["sum_emission"][ok]).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lanes", [2, 4])
+def test_submitted_batches_overlap_and_match_the_oracle(orc, r9, lanes, monkeypatch):
+    """`lanes` host batches in flight at once on one context: every output bit-equal to the oracle; tickets can be waited
+    for in any order; a full house returns ABEA_EBUSY; the synchronous entries refuse to run meanwhile."""
+    from f5c_amd import abea
+    k, model = r9
+    monkeypatch.setenv("ABEA_HOST_CHUNK_READS", "64")          # several chunks per batch, so lanes really interleave
+    monkeypatch.setenv("ABEA_HOST_CHUNK_EVENTS", "100000")
+    with abea.AbeaContext(model, k, max_arena_bytes=3 << 30) as c:
+        c.set_inflight(lanes)
+        batches, views = _views(c, r9, lanes + 2, 400)
+        oras = [orc.align_batch(b, model, k, n_threads=8) for b in batches]
+        tickets = [c.submit_view(v) for v in views[:lanes]]
+        assert len(set(tickets)) == lanes
+        with pytest.raises(abea.AbeaError, match="busy"):
+            c.submit_view(views[lanes])
+        with pytest.raises(abea.AbeaError, match="in flight"):
+            c.align_view(views[lanes])
+        with pytest.raises(abea.AbeaError, match="in flight"):
+            c.set_inflight(1)
+        for t in reversed(tickets):
+            c.wait(t)
+        with pytest.raises(abea.AbeaError, match="not in flight"):
+            c.wait(tickets[0])
+        for j in range(lanes):
+            _check(views[j], batches[j], oras[j])
+        assert c.stats()["n_reads_gpu"] > 0 and c.stats()["n_sub_batches"] >= 2
+        # a rolling window, as a caller overlapping process_db batches would run it
+        t_prev = c.submit_view(views[lanes])
+        t_next = c.submit_view(views[lanes + 1])
+        c.wait(t_prev); c.wait(t_next)
+        _check(views[lanes], batches[lanes], oras[lanes])
+        _check(views[lanes + 1], batches[lanes + 1], oras[lanes + 1])
+        # and the synchronous entry works again, on the full lane, with the same answer
+        views[0]["n_pairs"][:] = -1
+        c.align_view(views[0])
+        _check(views[0], batches[0], oras[0])
+
+
+@pytest.mark.gpu
+def test_submit_on_a_multi_device_context_and_fused_scaling(orc, r9):
+    """submit/wait on a two-context parent (one GPU listed twice) with scaling_single fused: the split, the lanes and the
+    scaling kernel compose; outputs equal the synchronous call's."""
+    from f5c_amd import abea, synth
+    k, model = r9
+    with abea.AbeaContext(model, k, device_ids=[0, 0], max_arena_bytes=2 << 30) as c:
+        batches = [synth.make_batch(90, model, k, seed=500 + j, law=1400, bad_frac=0.05) for j in range(2)]
+        va = [c.host_view(b, scaling=True) for b in batches]
+        vs = [c.host_view(b, scaling=True) for b in batches]
+        for v in vs:
+            c.align_view(v)
+        t = [c.submit_view(v) for v in va]
+        for x in t:
+            c.wait(x)
+        for a, s, b in zip(va, vs, batches):
+            ora = orc.align_batch(b, model, k, n_threads=8)
+            assert (a["n_pairs"] == s["n_pairs"]).all() and (a["n_pairs"] == ora[1]).all()
+            assert (a["pairs"] == s["pairs"]).all() and (a["b2e"] == s["b2e"]).all()
+            assert (a["scalings_out"] == s["scalings_out"]).all() and (a["events_per_base"] == s["events_per_base"]).all()
+            assert (a["read_stat_flag"] == s["read_stat_flag"]).all()
+
+
+@pytest.mark.gpu
+def test_two_threads_on_one_context_serialise(orc, r9):
+    """The threading contract of include/abea.h: a second thread calling into a busy context blocks, it does not corrupt
+    the arena (round-2 advisor finding: an integrator wiring one context under pthread_db)."""
+    from f5c_amd import abea
+    k, model = r9
+    with abea.AbeaContext(model, k, max_arena_bytes=2 << 30) as c:
+        batches, views = _views(c, r9, 4, 700, n_reads=120)
+        oras = [orc.align_batch(b, model, k, n_threads=8) for b in batches]
+        errs = []
+
+        def work(j):
+            try:
+                for _ in range(3):
+                    c.align_view(views[j])
+            except Exception as e:            # noqa: BLE001
+                errs.append(e)
+        th = [threading.Thread(target=work, args=(j,)) for j in range(4)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        assert not errs, errs
+        for j in range(4):
+            _check(views[j], batches[j], oras[j])
