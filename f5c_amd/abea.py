@@ -74,7 +74,7 @@ class _SigBatch(C.Structure):
     _fields_ = [("n_reads", C.c_int32), ("sig_ptr", C.c_void_p), ("n_samples", C.c_void_p), ("scaling", C.c_void_p),
                 ("event_ptr", C.c_void_p), ("event_cap", C.c_void_p), ("read_ptr", C.c_void_p), ("read_len", C.c_void_p),
                 ("signal", C.c_void_p), ("reads", C.c_void_p), ("events", C.c_void_p), ("n_events", C.c_void_p),
-                ("scalings", C.c_void_p)]
+                ("scalings", C.c_void_p), ("rna", C.c_int32), ("reserved", C.c_int32)]
 
 
 class _Scal(C.Structure):
@@ -427,7 +427,7 @@ class AbeaContext:
                        dbatch["n_pairs"].data_ptr(), dbatch["diag"].data_ptr() if want_diag else None, *sc)
         self._chk(self._lib.abea_align_batch_device(self._h, C.byref(db)), "abea_align_batch_device")
 
-    def _detect(self, signals, scaling, seqs, cap_div):
+    def _detect(self, signals, scaling, seqs, cap_div, rna=False):
         """Shared plumbing of the N2 entry: flatten + upload the signals, run abea_detect_events_device, keep every
         output in HBM.  Returns a dict of the device tensors and host index arrays."""
         import torch
@@ -459,7 +459,7 @@ class AbeaContext:
         sb = _SigBatch(n, _p(sig_ptr), _p(ns), _p(sc), _p(ev_ptr), _p(cap), _p(rp) if rp is not None else None,
                        _p(rl) if rl is not None else None, d_sig.data_ptr(),
                        d_reads.data_ptr() if d_reads is not None else None, d_ev.data_ptr(), d_ne.data_ptr(),
-                       d_scal.data_ptr() if d_scal is not None else None)
+                       d_scal.data_ptr() if d_scal is not None else None, 1 if rna else 0, 0)
         self._chk(self._lib.abea_detect_events_device(self._h, C.byref(sb)), "abea_detect_events_device")
         return dict(n=n, cap=cap, ev_ptr=ev_ptr, read_ptr=rp, read_len=rl, d_ev=d_ev, d_ne=d_ne, d_scal=d_scal,
                     d_reads=d_reads)
@@ -473,23 +473,24 @@ class AbeaContext:
             raise AbeaError(f"event detection found more events than event_cap on {len(over)} read(s) (first: read "
                             f"{int(over[0])}: {int(n_events[over[0]])} > {int(cap[over[0]])}); call again with a smaller cap_div")
 
-    def detect_events_device(self, signals, scaling, seqs=None, cap_div=4):
+    def detect_events_device(self, signals, scaling, seqs=None, cap_div=4, rna=False):
         """Row N2: raw ADC signals -> event tables (+ method-of-moments scalings when `seqs` is given) on the
-        device. signals: list of int16 arrays; scaling: float32 [n,3] (offset, range, digitisation).
+        device. signals: list of int16 arrays; scaling: float32 [n,3] (offset, range, digitisation); rna=True selects
+        the RNA detector parameters and returns the tables reversed 3'->5' as event_single does (f5c.c:711-719).
         Returns (list of EVENT_DT arrays, n_events int32[n], scalings SCAL_DT[n] or None)."""
-        r = self._detect(signals, scaling, seqs, cap_div)
+        r = self._detect(signals, scaling, seqs, cap_div, rna)
         ne = r["d_ne"].cpu().numpy()
         self._check_event_cap(ne, r["cap"])
         allev = r["d_ev"].cpu().numpy().view(EVENT_DT)
         evs = [allev[r["ev_ptr"][i]:r["ev_ptr"][i] + min(ne[i], r["cap"][i])] for i in range(r["n"])]
         return evs, ne, (r["d_scal"].cpu().numpy().view(SCAL_DT) if r["d_scal"] is not None else None)
 
-    def signals_to_device_batch(self, signals, scaling, seqs, cap_div=4):
+    def signals_to_device_batch(self, signals, scaling, seqs, cap_div=4, rna=False):
         """Rows N2 -> hot path without the event tables leaving HBM: run event detection and return a device batch
         for align_db_device whose `events` are the detector's output buffer.  Only the per-read n_events (4 B) and
         estimated scalings (16 B) cross to the host, because abea_device_batch takes them as host arrays."""
         import torch
-        r = self._detect(signals, scaling, seqs, cap_div)
+        r = self._detect(signals, scaling, seqs, cap_div, rna)
         n = r["n"]
         self._check_event_cap(r["d_ne"].cpu().numpy(), r["cap"])
         ne = np.minimum(r["d_ne"].cpu().numpy(), r["cap"]).astype(np.int32)

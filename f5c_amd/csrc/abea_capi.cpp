@@ -31,20 +31,20 @@ __global__ void abea_ev_pwrite_kernel(int, const int32_t*, const int16_t*, const
                                       const int64_t*, const int64_t*, const int32_t*, const double*, const int32_t*,
                                       double*, double*);
 __global__ void abea_ev_tstat_kernel(int, const int32_t*, const int32_t*, const int64_t*, const int32_t*, const double*,
-                                     const double*, float*, float*);
+                                     const double*, float*, float*, int);
 __global__ void abea_ev_detect_kernel(int, const int32_t*, const int32_t*, const int64_t*, const float*, const float*,
-                                      const int64_t*, const int32_t*, int32_t*, int32_t*, const int32_t*);
+                                      const int64_t*, const int32_t*, int32_t*, int32_t*, const int32_t*, int);
 __global__ void abea_ev_spec_kernel(int, const int32_t*, const int32_t*, const int64_t*, const float*, const float*,
-                                    const int64_t*, const int32_t*, uint16_t*, int32_t*);
+                                    const int64_t*, const int32_t*, uint16_t*, int32_t*, int);
 __global__ void abea_ev_fix_kernel(int, const int32_t*, const int32_t*, const int64_t*, const float*, const float*,
-                                   const int64_t*, const int32_t*, int32_t*, int32_t*, int32_t*);
+                                   const int64_t*, const int32_t*, int32_t*, int32_t*, int32_t*, int);
 __global__ void abea_ev_scan_kernel(int, const int32_t*, const int32_t*, const int64_t*, int32_t*, int32_t*);
 __global__ void abea_ev_gather_kernel(int, const int32_t*, const int32_t*, const int64_t*, const int32_t*,
                                       const uint16_t*, const int32_t*, const int32_t*, const int64_t*, const int32_t*,
                                       int32_t*);
 __global__ void abea_ev_create_kernel(int, const int32_t*, const int32_t*, const int64_t*, const double*, const double*,
                                       const int64_t*, const int32_t*, const int32_t*, const int32_t*, const int32_t*,
-                                      abea_event_t*, const int64_t*, float*);
+                                      abea_event_t*, const int64_t*, float*, int);
 __global__ void abea_ev_kmer_kernel(int, const int32_t*, const char*, const int64_t*, const int32_t*, const abea_model_t*,
                                     int, const int64_t*, const int32_t*, float*);
 __global__ void abea_ev_scalings_kernel(int, const int32_t*, const int64_t*, const float*, const int32_t*,
@@ -366,6 +366,7 @@ extern "C" int abea_detect_events_device(abea_ctx* c, const abea_signal_batch* B
     if (B->scalings && (!B->reads || !B->read_ptr || !B->read_len))
         return abea_fail(ABEA_EINVAL, "abea_detect_events_device: scalings need the read sequences");
     HIP_TRY(hipSetDevice(c->device));
+    const int rna = B->rna ? 1 : 0;            /* getevents(nsample, rawptr, rna), events.c:562-582; F5C_RNA, f5c.c:698-702 */
     /* lane-per-read passes: order reads by length so that the 64 reads of a wavefront finish together */
     std::vector<int32_t> order((size_t)n);
     std::iota(order.begin(), order.end(), 0);
@@ -457,19 +458,19 @@ extern "C" int abea_detect_events_device(abea_ctx* c, const abea_signal_batch* B
                            nr, (const int32_t*)(d + o_order), B->signal, (const int64_t*)(d + o_sig),
                            (const int32_t*)(d + o_ns), (const float*)(d + o_sc), (const int64_t*)(d + o_wb), dS, dQ,
                            seq_only ? (const int32_t*)nullptr : (const int32_t*)(d + o_need_s));
-        const unsigned tiles = (unsigned)std::min<int64_t>(1024, (wave_len[0] + 3) / 4);
+        const unsigned tiles = (unsigned)std::min<int64_t>(1024, (wave_len[0] + 3) / 4);   /* grid-stride: any tile count covers the wave */
         hipLaunchKernelGGL(abea_ev_tstat_kernel, dim3(tiles, (unsigned)nw), dim3(256), 0, c->stream,
                            nr, (const int32_t*)(d + o_order), (const int32_t*)(d + o_ns), (const int64_t*)(d + o_wb),
-                           (const int32_t*)(d + o_wl), dS, dQ, dT1, dT2);
+                           (const int32_t*)(d + o_wl), dS, dQ, dT1, dT2, rna);
         /* pass 3: the automaton over (read, segment) pairs, then the sequential one for reads whose segments never met */
         hipLaunchKernelGGL(abea_ev_spec_kernel, sgrid, dim3(256), 0, c->stream,
                            nr, (const int32_t*)(d + o_order), (const int32_t*)(d + o_ns), (const int64_t*)(d + o_wb),
-                           dT1, dT2, (const int64_t*)(d + o_sb), (const int32_t*)(d + o_wn), dSpec, dRec);
+                           dT1, dT2, (const int64_t*)(d + o_sb), (const int32_t*)(d + o_wn), dSpec, dRec, rna);
         if (max_nseg > 1)
             hipLaunchKernelGGL(abea_ev_fix_kernel, dim3((unsigned)((max_nseg - 1 + 3) / 4), (unsigned)nw), dim3(256), 0, c->stream,
                                nr, (const int32_t*)(d + o_order), (const int32_t*)(d + o_ns), (const int64_t*)(d + o_wb),
                                dT1, dT2, (const int64_t*)(d + o_sb), (const int32_t*)(d + o_wn), dFix, dRec,
-                               (int32_t*)(d + o_need));
+                               (int32_t*)(d + o_need), rna);
         hipLaunchKernelGGL(abea_ev_scan_kernel, dim3((unsigned)nw), dim3(64), 0, c->stream,
                            nr, (const int32_t*)(d + o_order), (const int32_t*)(d + o_ns), (const int64_t*)(d + o_sb), dRec,
                            B->n_events);
@@ -480,12 +481,12 @@ extern "C" int abea_detect_events_device(abea_ctx* c, const abea_signal_batch* B
         hipLaunchKernelGGL(abea_ev_detect_kernel, dim3((unsigned)nw), dim3(64), 0, c->stream,
                            nr, (const int32_t*)(d + o_order), (const int32_t*)(d + o_ns), (const int64_t*)(d + o_wb),
                            dT1, dT2, (const int64_t*)(d + o_pb), (const int32_t*)(d + o_ec), dPk, B->n_events,
-                           seq_only ? (const int32_t*)nullptr : (const int32_t*)(d + o_need));
+                           seq_only ? (const int32_t*)nullptr : (const int32_t*)(d + o_need), rna);
         const unsigned etiles = (unsigned)std::min<int64_t>(256, (wave_cap[0] + 3) / 4);
         hipLaunchKernelGGL(abea_ev_create_kernel, dim3(etiles, (unsigned)nw), dim3(256), 0, c->stream,
                            nr, (const int32_t*)(d + o_order), (const int32_t*)(d + o_ns), (const int64_t*)(d + o_wb),
                            dS, dQ, (const int64_t*)(d + o_pb), (const int32_t*)(d + o_wc), dPk, B->n_events,
-                           (const int32_t*)(d + o_ec), B->events, (const int64_t*)(d + o_ep), dMean);
+                           (const int32_t*)(d + o_ec), B->events, (const int64_t*)(d + o_ep), dMean, rna);
         if (B->scalings) {
             const unsigned ktiles = (unsigned)std::min<int64_t>(256, (*std::max_element(wave_k.begin(), wave_k.end()) + 3) / 4);
             hipLaunchKernelGGL(abea_ev_kmer_kernel, dim3(ktiles, (unsigned)nw), dim3(256), 0, c->stream,

@@ -996,8 +996,21 @@ void abea_ev_sums_kernel(int n_reads, const int32_t* __restrict__ order, const i
     for (; i < n; ++i) sample(i, sig[i]);
 }
 
-extern "C" __global__ __launch_bounds__(256)
-void abea_ev_tstat_kernel(int n_reads, const int32_t* __restrict__ order, const int32_t* __restrict__ n_samples,
+/* detector parameters (events.c:52-65): DNA event_detection_defaults, RNA event_detection_rna */
+struct abea_ev_par { int w1, w2, half1, half2; float thr1, thr2, h; };
+static __device__ __forceinline__ abea_ev_par ev_par(int rna) {
+    abea_ev_par P;
+    P.w1 = rna ? 7 : 3; P.w2 = rna ? 14 : 6;
+    P.half1 = P.w1 / 2; P.half2 = P.w2 / 2;                          /* window_length / 2, integer (events.c:441) */
+    P.thr1 = rna ? 2.5f : 1.4f; P.thr2 = 9.0f;
+    P.h = rna ? 1.0f : 0.2f;
+    return P;
+}
+
+/* windows W1 < W2; a thread makes POS consecutive positions of its read from one window of POS + 2*W2 prefix-sum rows
+ * (p0-W2 .. p0+POS-1+W2) */
+template <int W1, int W2, int POS>
+static __device__ __forceinline__ void tstat_body(int n_reads, const int32_t* __restrict__ order, const int32_t* __restrict__ n_samples,
                           const int64_t* __restrict__ wave_base, const int32_t* __restrict__ wave_len,
                           const double* __restrict__ S_all, const double* __restrict__ Q_all,
                           float* __restrict__ t1_all, float* __restrict__ t2_all) {
@@ -1008,24 +1021,26 @@ void abea_ev_tstat_kernel(int n_reads, const int32_t* __restrict__ order, const 
     const int n = slot < n_reads ? n_samples[order[slot]] : 0;
     const int64_t base = wave_base[w];
     const int len = wave_len[w];
-    /* a thread makes 8 consecutive positions of its read from one window of 20 prefix-sum rows (p0-6 .. p0+13) */
     const double* Sw = S_all + base + lane;
     const double* Qw = Q_all + base + lane;
-    for (int p0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 8; p0 < len; p0 += gridDim.x * 32) {
-        double sr[20], qr[20];
+    constexpr int ROWS = POS + 2 * W2;
+    for (int p0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * POS; p0 < len; p0 += gridDim.x * 4 * POS) {
+        double sr[ROWS], qr[ROWS];
         #pragma unroll
-        for (int i = 0; i < 20; ++i) {
-            const int row = min(max(p0 - 6 + i, 0), len - 1);
+        for (int i = 0; i < ROWS; ++i) {
+            const int row = min(max(p0 - W2 + i, 0), len - 1);
             sr[i] = Sw[(int64_t)row * 64]; qr[i] = Qw[(int64_t)row * 64];
         }
         #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < POS; ++i) {
             const int p = p0 + i;
             if (p >= len) break;
             float a = 0.f, b = 0.f;
-            if (p < n) {
-                if (n >= 6 && p >= 3 && p <= n - 3) a = abea_tstat(sr[i + 3], sr[i + 6], sr[i + 9], qr[i + 3], qr[i + 6], qr[i + 9], 3.0f);
-                if (n >= 12 && p >= 6 && p <= n - 6) b = abea_tstat(sr[i], sr[i + 6], sr[i + 12], qr[i], qr[i + 6], qr[i + 12], 6.0f);
+            if (p < n) {                                             /* events.c:336-347: zero at the boundaries */
+                if (n >= 2 * W1 && p >= W1 && p <= n - W1)
+                    a = abea_tstat(sr[i + W2 - W1], sr[i + W2], sr[i + W2 + W1], qr[i + W2 - W1], qr[i + W2], qr[i + W2 + W1], (float)W1);
+                if (n >= 2 * W2 && p >= W2 && p <= n - W2)
+                    b = abea_tstat(sr[i], sr[i + W2], sr[i + 2 * W2], qr[i], qr[i + W2], qr[i + 2 * W2], (float)W2);
             }
             t1_all[base + (int64_t)p * 64 + lane] = a;
             t2_all[base + (int64_t)p * 64 + lane] = b;
@@ -1033,10 +1048,23 @@ void abea_ev_tstat_kernel(int n_reads, const int32_t* __restrict__ order, const 
     }
 }
 
+extern "C" __global__ __launch_bounds__(256)
+void abea_ev_tstat_kernel(int n_reads, const int32_t* __restrict__ order, const int32_t* __restrict__ n_samples,
+                          const int64_t* __restrict__ wave_base, const int32_t* __restrict__ wave_len,
+                          const double* __restrict__ S_all, const double* __restrict__ Q_all,
+                          float* __restrict__ t1_all, float* __restrict__ t2_all, int rna) {
+    if (rna) tstat_body<7, 14, 4>(n_reads, order, n_samples, wave_base, wave_len, S_all, Q_all, t1_all, t2_all);
+    else tstat_body<3, 6, 8>(n_reads, order, n_samples, wave_base, wave_len, S_all, Q_all, t1_all, t2_all);
+}
+
 /* ---- pass 3: segment-parallel automaton ---- */
 #define ABEA_EV_SEG   512     /* samples per segment */
-#define ABEA_EV_FIX   64      /* a segment must meet its speculative replay within this many samples */
-#define ABEA_EV_FIXCAP 48     /* > 2 * (ABEA_EV_FIX / 3 + 1): a detector fires at most every third sample */
+#define ABEA_EV_FIX   64      /* DNA: a segment must meet its speculative replay within this many samples */
+#define ABEA_EV_FIX_RNA 128   /* RNA: longer dwells, rarer peaks, so the replay gets a longer window */
+#define ABEA_EV_FIXCAP 48     /* peaks the true prefix may emit inside the window.  DNA: the short detector fires at most
+                               * every 3rd sample, the long one every 5th: 64/3 + 64/5 + 2 = 36; RNA (half windows 3 / 7):
+                               * every 5th / 9th: 128/5 + 128/9 + 2 = 41.  More than the cap flags the read for the
+                               * sequential kernel, so the bound is a performance matter, not a correctness one. */
 
 struct abea_det2 { float pv0, pv1; int pp0, pp1; int v0, v1; int masked; };
 
@@ -1045,30 +1073,30 @@ static __device__ __forceinline__ void det2_reset(abea_det2& s) {
 }
 /* events.c:380-452 at position p for both detectors, with selects.  Returns bit 0 / bit 1 = short / long detector
  * fired; f0 / f1 = the peak positions they emit (short first, as in the reference's k loop). */
-static __device__ __forceinline__ int det2_step(abea_det2& s, int p, float c0, float c1, int& f0, int& f1) {
-    const float h = 0.2f;                                            /* peak_height, events.c:52-56 DNA */
+static __device__ __forceinline__ int det2_step(abea_det2& s, int p, float c0, float c1, int& f0, int& f1, const abea_ev_par& P) {
+    const float h = P.h;                                             /* peak_height, events.c:52-65 */
     int fired = 0;
-    {   /* short window: threshold 1.4, window 3; nothing ever masks it after position 0 */
+    {   /* short window (DNA: threshold 1.4, window 3); nothing ever masks it after position 0 */
         const bool srch = s.pp0 == -1;
         const bool lower = c0 < s.pv0;
         const bool rise = !lower && (c0 - s.pv0 > h);
         const bool higher = c0 > s.pv0;
         const float pv_i = higher ? c0 : s.pv0;
         const int pp_i = higher ? p : s.pp0;
-        const bool dom = !srch && (pv_i > 1.4f);                     /* masks the long detector (events.c:418-424) */
-        const bool valid_i = s.v0 || ((pv_i - c0 > h) && (pv_i > 1.4f));
-        const bool fire = !srch && valid_i && ((p - pp_i) > 1);
+        const bool dom = !srch && (pv_i > P.thr1);                   /* masks the long detector (events.c:418-424) */
+        const bool valid_i = s.v0 || ((pv_i - c0 > h) && (pv_i > P.thr1));
+        const bool fire = !srch && valid_i && ((p - pp_i) > P.half1);
         f0 = pp_i;
         fired |= fire ? 1 : 0;
         s.pv0 = srch ? ((lower || rise) ? c0 : s.pv0) : (fire ? c0 : pv_i);
         s.pp0 = srch ? (rise ? p : -1) : (fire ? -1 : pp_i);
         s.v0 = srch ? s.v0 : (fire ? 0 : (valid_i ? 1 : 0));
-        s.masked = dom ? pp_i + 3 : s.masked;
+        s.masked = dom ? pp_i + P.w1 : s.masked;
         s.pp1 = dom ? -1 : s.pp1;
         s.pv1 = dom ? 3.402823466e+38f : s.pv1;
         s.v1 = dom ? 0 : s.v1;
     }
-    {   /* long window: threshold 9.0, window 6 */
+    {   /* long window (DNA: threshold 9.0, window 6) */
         const bool active = s.masked < p;
         const bool srch = s.pp1 == -1;
         const bool lower = c1 < s.pv1;
@@ -1077,8 +1105,8 @@ static __device__ __forceinline__ int det2_step(abea_det2& s, int p, float c0, f
         const float pv_i = higher ? c1 : s.pv1;
         const int pp_i = higher ? p : s.pp1;
         const bool inpeak = active && !srch;
-        const bool valid_i = s.v1 || ((pv_i - c1 > h) && (pv_i > 9.0f));
-        const bool fire = inpeak && valid_i && ((p - pp_i) > 3);
+        const bool valid_i = s.v1 || ((pv_i - c1 > h) && (pv_i > P.thr2));
+        const bool fire = inpeak && valid_i && ((p - pp_i) > P.half2);
         f1 = pp_i;
         fired |= fire ? 2 : 0;
         const bool sr = active && srch;
@@ -1101,7 +1129,8 @@ void abea_ev_spec_kernel(int n_reads, const int32_t* __restrict__ order, const i
                          const int64_t* __restrict__ wave_base, const float* __restrict__ t1_all,
                          const float* __restrict__ t2_all, const int64_t* __restrict__ seg_base,
                          const int32_t* __restrict__ wave_nseg, uint16_t* __restrict__ spec_all,
-                         int32_t* __restrict__ segrec_all) {
+                         int32_t* __restrict__ segrec_all, int rna) {
+    const abea_ev_par P = ev_par(rna);
     const int w = blockIdx.y;
     const int lane = threadIdx.x & 63;
     const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -1132,7 +1161,7 @@ void abea_ev_spec_kernel(int n_reads, const int32_t* __restrict__ order, const i
         for (int q = 0; q < 8; ++q) {
             if (p0 + q < hi) {
                 int f0, f1;
-                const int fired = det2_step(s, p0 + q, a1[q], a2[q], f0, f1);
+                const int fired = det2_step(s, p0 + q, a1[q], a2[q], f0, f1, P);
                 if (fired & 1) { out[(size_t)cnt * 64] = (uint16_t)(f0 - j * ABEA_EV_SEG); ++cnt; }
                 if (fired & 2) { out[(size_t)cnt * 64] = (uint16_t)(f1 - j * ABEA_EV_SEG); ++cnt; }
             }
@@ -1152,7 +1181,8 @@ void abea_ev_fix_kernel(int n_reads, const int32_t* __restrict__ order, const in
                         const int64_t* __restrict__ wave_base, const float* __restrict__ t1_all,
                         const float* __restrict__ t2_all, const int64_t* __restrict__ seg_base,
                         const int32_t* __restrict__ wave_nseg, int32_t* __restrict__ fix_all,
-                        int32_t* __restrict__ segrec_all, int32_t* __restrict__ need_seq) {
+                        int32_t* __restrict__ segrec_all, int32_t* __restrict__ need_seq, int rna) {
+    const abea_ev_par P = ev_par(rna);
     const int w = blockIdx.y;
     const int lane = threadIdx.x & 63;
     const int j = blockIdx.x * 4 + (threadIdx.x >> 6) + 1;           /* segment 0 starts from the true state already */
@@ -1176,12 +1206,12 @@ void abea_ev_fix_kernel(int n_reads, const int32_t* __restrict__ order, const in
     det2_reset(sp);
     int nfix = 0, skip = 0, p = lo;
     bool met = det2_equal(tr, sp, lo - 1);
-    const int stop = min(hi, lo + ABEA_EV_FIX);
+    const int stop = min(hi, lo + (rna ? ABEA_EV_FIX_RNA : ABEA_EV_FIX));
     while (!met && p < stop) {
         const float c0 = t1[(size_t)p * 64], c1 = t2[(size_t)p * 64];
         int f0, f1, g0, g1;
-        const int ft = det2_step(tr, p, c0, c1, f0, f1);
-        const int fs = det2_step(sp, p, c0, c1, g0, g1);
+        const int ft = det2_step(tr, p, c0, c1, f0, f1, P);
+        const int fs = det2_step(sp, p, c0, c1, g0, g1, P);
         if (ft & 1) { if (nfix < ABEA_EV_FIXCAP) out[(size_t)nfix * 64] = f0; ++nfix; }
         if (ft & 2) { if (nfix < ABEA_EV_FIXCAP) out[(size_t)nfix * 64] = f1; ++nfix; }
         skip += (fs & 1) + ((fs >> 1) & 1);
@@ -1249,7 +1279,8 @@ void abea_ev_detect_kernel(int n_reads, const int32_t* __restrict__ order, const
                            const int64_t* __restrict__ wave_base, const float* __restrict__ t1_all,
                            const float* __restrict__ t2_all, const int64_t* __restrict__ peak_base,
                            const int32_t* __restrict__ event_cap, int32_t* __restrict__ peaks_all,
-                           int32_t* __restrict__ n_events, const int32_t* __restrict__ need_seq) {
+                           int32_t* __restrict__ n_events, const int32_t* __restrict__ need_seq, int rna) {
+    const abea_ev_par P = ev_par(rna);
     const int lane = threadIdx.x;
     const int slot = blockIdx.x * 64 + lane;
     if (slot >= n_reads) return;
@@ -1267,9 +1298,9 @@ void abea_ev_detect_kernel(int n_reads, const int32_t* __restrict__ order, const
     for (int k = 0; k < 2; ++k) {
         det[k].peak_value = 3.402823466e+38f; det[k].peak_pos = -1; det[k].masked_to = 0; det[k].valid = false;
     }
-    const float thr[2] = {1.4f, 9.0f};                               /* events.c:52-56, DNA */
-    const int win[2] = {3, 6};
-    const float peak_height = 0.2f;
+    const float thr[2] = {P.thr1, P.thr2};                           /* events.c:52-65 */
+    const int win[2] = {P.w1, P.w2};
+    const float peak_height = P.h;
     int n_pk = 0;
 
     /* events.c:380-452 at position p, written with selects instead of branches: the 64 reads of a wavefront are in
@@ -1340,7 +1371,7 @@ void abea_ev_create_kernel(int n_reads, const int32_t* __restrict__ order, const
                            const int32_t* __restrict__ wave_cap, const int32_t* __restrict__ peaks_all,
                            const int32_t* __restrict__ n_events, const int32_t* __restrict__ event_cap,
                            abea_event_t* __restrict__ events, const int64_t* __restrict__ event_ptr,
-                           float* __restrict__ mean_all) {
+                           float* __restrict__ mean_all, int rna) {
     const int w = blockIdx.y;
     const int lane = threadIdx.x & 63;
     const int slot = w * 64 + lane;
@@ -1378,7 +1409,11 @@ void abea_ev_create_kernel(int n_reads, const int32_t* __restrict__ order, const
             const float deltasqr = (float)(qb[i + 1] - qb[i]);
             const float var = deltasqr / e.length - e.mean * e.mean;
             e.stdv = sqrtf(fmaxf(var, 0.0f));
-            ev[j] = e;
+            /* RNA: event_single() reverses the table to 3'->5' AFTER the scalings are estimated (f5c.c:711-719): the
+             * table goes out reversed, mean_all (what the scalings kernel sums, in order) stays in detection order.  A
+             * truncated table (n_ev > cap, reported to the caller through n_events) holds the LAST cap events then. */
+            const int at = rna ? n_ev - 1 - j : j;
+            if (at < event_cap[r]) ev[at] = e;
             mean_all[peak_base[w] + (int64_t)j * 64 + lane] = e.mean;
         }
     }

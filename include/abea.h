@@ -181,9 +181,10 @@ int abea_align_batch_device(abea_ctx* ctx, const abea_device_batch* batch);
  * Index / scaling arrays are HOST pointers, bulk arrays DEVICE pointers.  Events of read i are written at
  * events[event_ptr[i] ...] up to event_cap[i] entries; n_events[i] is the true count (> cap means truncated: the caller
  * must re-run that read with a larger table, a truncated table is not a valid input of the alignment).
- * DNA only: the detector runs with event_detection_defaults (src/events.c:52-58: windows 3 / 6, thresholds 1.4 / 9.0,
- * peak height 0.2); getevents()'s RNA branch (event_detection_rna, events.c:59-65,575-577) and event_single()'s RNA event
- * reversal (f5c.c:711-719) are not implemented — RNA reads must keep using the host getevents(). */
+ * rna == 0: the detector runs with event_detection_defaults (src/events.c:52-58: windows 3 / 6, thresholds 1.4 / 9.0, peak
+ * height 0.2).  rna != 0 (opt.flag & F5C_RNA, f5c.c:698-702): event_detection_rna (events.c:59-65,575-577: windows 7 / 14,
+ * thresholds 2.5 / 9.0, peak height 1.0), the scalings are estimated on the table in detection order and the table is then
+ * written reversed, 3'->5', as event_single() does (f5c.c:711-719) — ready for the alignment with the RNA k-mer model. */
 typedef struct {
     int32_t n_reads;
     const int64_t* sig_ptr;        /* HOST: offset of read i in `signal` (samples); multiples of 8 are fastest (16-byte loads) */
@@ -198,6 +199,8 @@ typedef struct {
     abea_event_t*  events;         /* DEVICE out */
     int32_t*       n_events;       /* DEVICE out [n_reads] */
     abea_scalings_t* scalings;     /* DEVICE out [n_reads] (scale, shift, var = 1), optional */
+    int32_t        rna;            /* opt.flag & F5C_RNA */
+    int32_t        reserved;
 } abea_signal_batch;
 int abea_detect_events_device(abea_ctx* ctx, const abea_signal_batch* batch);
 

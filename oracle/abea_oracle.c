@@ -435,8 +435,14 @@ typedef struct {
     size_t window_length; size_t masked_to; int peak_pos; float peak_value; int valid_peak;
 } ev_detector;
 
-size_t orc_getevents(size_t nsample, const float* raw, orc_event_t* out) {
+/* getevents(nsample, rawptr, rna), events.c:562-582: detector parameters by molecule type (events.c:52-65).  The event
+ * table comes back in DETECTION order for RNA too; event_single() reverses it after the scalings (f5c.c:711-719):
+ * orc_reverse_events.  RNA is UNPINNED: the reference's RNA test sets are downloaded by test/test_eventalign.sh -e, none is
+ * in the mount; this is the same code path with the other parameter row. */
+size_t orc_getevents_rna(size_t nsample, const float* raw, orc_event_t* out, int rna) {
     const size_t n = nsample;
+    const size_t w1 = rna ? 7 : 3, w2 = rna ? 14 : 6;
+    const float thr1 = rna ? 2.5f : 1.4f, thr2 = 9.0f;
     if (n == 0) return 0;
     /* events.c:303-313: prefix sums; the square is a float product */
     double* sums = (double*)calloc(n + 1, sizeof(double));
@@ -445,12 +451,12 @@ size_t orc_getevents(size_t nsample, const float* raw, orc_event_t* out) {
         sums[i + 1] = sums[i] + raw[i];
         sumsqs[i + 1] = sumsqs[i] + raw[i] * raw[i];
     }
-    float* t1 = ev_tstat(sums, sumsqs, n, 3);                         /* events.c:52-56 DNA defaults */
-    float* t2 = ev_tstat(sums, sumsqs, n, 6);
+    float* t1 = ev_tstat(sums, sumsqs, n, w1);                        /* events.c:52-65 */
+    float* t2 = ev_tstat(sums, sumsqs, n, w2);
     ev_detector d[2] = {
-        { -1, FLT_MAX, t1, n, 1.4f, 3, 0, -1, FLT_MAX, 0 },
-        { -1, FLT_MAX, t2, n, 9.0f, 6, 0, -1, FLT_MAX, 0 } };
-    const float peak_height = 0.2f;
+        { -1, FLT_MAX, t1, n, thr1, w1, 0, -1, FLT_MAX, 0 },
+        { -1, FLT_MAX, t2, n, thr2, w2, 0, -1, FLT_MAX, 0 } };
+    const float peak_height = rna ? 1.0f : 0.2f;
     size_t* peaks = (size_t*)calloc(n, sizeof(size_t));
     size_t peak_count = 0;
     for (size_t i = 0; i < n; i++) {                                  /* events.c:380-452 */
@@ -503,6 +509,17 @@ size_t orc_getevents(size_t nsample, const float* raw, orc_event_t* out) {
     }
     free(peaks); free(t1); free(t2); free(sums); free(sumsqs);
     return ne;
+}
+
+size_t orc_getevents(size_t nsample, const float* raw, orc_event_t* out) { return orc_getevents_rna(nsample, raw, out, 0); }
+
+/* f5c.c:711-719: "If sequencing RNA, reverse the events to be 3'->5'" */
+void orc_reverse_events(orc_event_t* events, size_t n_events) {
+    for (size_t i = 0; i < n_events / 2; ++i) {
+        orc_event_t tmp = events[i];
+        events[i] = events[n_events - 1 - i];
+        events[n_events - 1 - i] = tmp;
+    }
 }
 
 /* ------------------------------------------------------------------------------------------------

@@ -63,6 +63,9 @@ void orc_align_batch(int32_t n_reads, const char* reads, const int64_t* read_ptr
  * detect_events on the whole signal (the trim result there is discarded), DNA parameters
  * (events.c:52-56).  Returns the number of events written (<= nsample); out must hold nsample entries. */
 size_t orc_getevents(size_t nsample, const float* raw_pa, orc_event_t* out);
+/* the same with the molecule type: rna != 0 selects event_detection_rna (events.c:59-65); table in detection order */
+size_t orc_getevents_rna(size_t nsample, const float* raw_pa, orc_event_t* out, int rna);
+void orc_reverse_events(orc_event_t* events, size_t n_events);          /* f5c.c:711-719 */
 /* ADC -> pA conversion of event_single (f5c.c:692-696), in place on a float copy of the int16 samples */
 void orc_raw_to_pa(float* raw, size_t nsample, float offset, float range, float digitisation);
 

@@ -97,18 +97,29 @@ def align_batch(batch, model, k, n_threads=1, want_diag=True):
     return pairs, n_pairs, diags
 
 
-def getevents(raw_adc, offset, rng, digitisation):
-    """int16 ADC samples + channel scaling -> (event table, pA signal) as event_single does (f5c.c:682-710)."""
+def getevents(raw_adc, offset, rng, digitisation, rna=False):
+    """int16 ADC samples + channel scaling -> (event table, pA signal) as event_single does (f5c.c:682-710).  The table is
+    in detection order for RNA too (getevents, events.c:562-582); reverse_events() is event_single's last step."""
     L = lib()
-    L.orc_getevents.restype = C.c_size_t
-    L.orc_getevents.argtypes = [C.c_size_t, C.c_void_p, C.c_void_p]
+    L.orc_getevents_rna.restype = C.c_size_t
+    L.orc_getevents_rna.argtypes = [C.c_size_t, C.c_void_p, C.c_void_p, C.c_int]
     L.orc_raw_to_pa.restype = None
     L.orc_raw_to_pa.argtypes = [C.c_void_p, C.c_size_t, C.c_float, C.c_float, C.c_float]
     pa = np.ascontiguousarray(raw_adc, dtype=np.float32).copy()
     L.orc_raw_to_pa(_p(pa), len(pa), np.float32(offset), np.float32(rng), np.float32(digitisation))
     ev = np.zeros(len(pa), dtype=EVENT_DT)
-    n = L.orc_getevents(len(pa), _p(pa), _p(ev))
+    n = L.orc_getevents_rna(len(pa), _p(pa), _p(ev), 1 if rna else 0)
     return ev[:n].copy(), pa
+
+
+def reverse_events(events):
+    """f5c.c:711-719 (RNA): the table reversed to 3'->5', in place on a copy."""
+    ev = np.ascontiguousarray(events).copy()
+    L = lib()
+    L.orc_reverse_events.restype = None
+    L.orc_reverse_events.argtypes = [C.c_void_p, C.c_size_t]
+    L.orc_reverse_events(_p(ev), len(ev))
+    return ev
 
 
 def rsq_format(fmt, read_id, seq_len, k, base_to_event_map, events, n_samples, scale, shift, rna=False):

@@ -50,14 +50,16 @@ def run(budget=60.0, seed=1, ctx=None, max_batches=None):
         seqs = None
         if nb % 2 == 1:                                                  # every other batch also asks for the scalings
             seqs = [bytes(rng.choice(list(b"ACGT"), int(rng.integers(k, 4000))).astype(np.uint8)) for _ in range(m)]
-        evs, ne, dsc = ctx.detect_events_device(list(sigs), scal, seqs=seqs, cap_div=1)
+        rna = bool(nb % 3 == 2)                                          # every third batch with the RNA detector (events.c:59-65) + reversal
+        evs, ne, dsc = ctx.detect_events_device(list(sigs), scal, seqs=seqs, cap_div=1, rna=rna)
         for i, sg in enumerate(sigs):
-            o_ev, _ = orc.getevents(sg, scal[i, 0], scal[i, 1], scal[i, 2])
+            o_ev, _ = orc.getevents(sg, scal[i, 0], scal[i, 1], scal[i, 2], rna=rna)
             tag = f"batch {nb} signal {i} n={len(sg)} scaling={scal[i]}"
             assert ne[i] == len(o_ev), (tag, int(ne[i]), len(o_ev))
+            o_out = orc.reverse_events(o_ev) if rna else o_ev            # f5c.c:711-719, after the scalings
             for f in ("start", "length", "mean", "stdv"):
-                a, b = evs[i][f], o_ev[f]
-                assert ((a == b) | ((a != a) & (b != b))).all(), (tag, f)
+                a, b = evs[i][f], o_out[f]
+                assert ((a == b) | ((a != a) & (b != b))).all(), (tag, f, rna)
             if seqs is not None:                                         # estimate_scalings_using_mom (align.c:58-106)
                 scale, shift = orc.estimate_scalings(seqs[i], model, k, o_ev)
                 got = (np.float32(dsc["scale"][i]), np.float32(dsc["shift"][i])); want = (np.float32(scale), np.float32(shift))
