@@ -243,6 +243,7 @@ def main():
                                "limiter": valu_issue(args.config, sum_events, fill_avg_ms, dev["launches_per_step"])}
         if world == 1 and not args.single_process and not args.no_small_batch and host_stats is not None:
             out["f5c_default_batch"] = small_batch(ctx, batch)
+            out["fused_scaling"] = fused_scaling(ctx, batch, view)
         if world == 1 and not args.single_process and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(batch, model, k, args.cpu_seconds, view if host_stats is not None else None,
                                                dev, ctx)
@@ -255,28 +256,81 @@ def main():
 
 def small_batch(ctx, batch):
     """What a drop-in does WITHOUT re-tuned flags: f5c's default batch is -K 512 reads / -B 2 Mbases (src/f5c.c:1178-1179).
-    One such batch fills 512 of the GPU's 4096 wave slots and lasts as long as its longest read."""
+    One such batch fills 512 of the GPU's 4096 wave slots and lasts as long as its longest read.  Measured one batch at a
+    time (as process_db issues them) and with 2 / 4 consecutive default batches in flight through
+    abea_align_batch_host_submit/_wait (what a caller overlapping process_db calls gets)."""
     import numpy as np
     from f5c_amd import synth
     L = batch["read_len"].astype(np.int64)
-    n = int(min(512, len(L), max(1, np.searchsorted(np.cumsum(L), 2_000_000) + 1)))
-    sub = synth.take_reads(batch, np.arange(n))
-    v = ctx.host_view(sub)
-    ctx.align_view(v)
+    cum = np.cumsum(L)
+    cuts, start = [], 0
+    while len(cuts) < 8 and start < len(L):                       # 8 consecutive default batches of the job
+        base = cum[start - 1] if start else 0
+        n = int(min(512, len(L) - start, max(1, np.searchsorted(cum[start:] - base, 2_000_000) + 1)))
+        cuts.append((start, n)); start += n
+    subs = [synth.take_reads(batch, np.arange(a, a + n)) for a, n in cuts]
+    views = [ctx.host_view(sb) for sb in subs]
+    ev_all = [int(sb["n_events"].sum()) for sb in subs]
+    ctx.align_view(views[0])
     t0 = time.perf_counter()
     reps = 5
     for _ in range(reps):
+        ctx.align_view(views[0])
+    t = (time.perf_counter() - t0) / reps
+    n0 = cuts[0][1]
+    out = {"reads": n0, "bases": int(L[:n0].sum()), "events": ev_all[0], "ms_per_batch": round(t * 1e3, 2),
+           "mevents_per_s": round(ev_all[0] / t / 1e6, 1), "longest_read_bases": int(L[:n0].max()),
+           "note": "host-to-host, one batch at a time as process_db issues them; INTEGRATION.md recommends -K 20000 -B 200M"}
+    ref_np = [v["n_pairs"].copy() for v in views[:1]]
+    over = {}
+    for lanes in (2, 4):
+        ctx.set_inflight(lanes)
+        for rep in range(2):                                       # first pass warms the lanes' slots and staging
+            t0 = time.perf_counter()
+            pending = []
+            for v in views:
+                if len(pending) == lanes:
+                    ctx.wait(pending.pop(0))
+                pending.append(ctx.submit_view(v))
+            for tk in pending:
+                ctx.wait(tk)
+            dt = time.perf_counter() - t0
+        assert (views[0]["n_pairs"] == ref_np[0]).all(), "submitted batch differs from the synchronous one"
+        over[str(lanes)] = {"mevents_per_s": round(sum(ev_all) / dt / 1e6, 1), "ms_per_batch": round(dt / len(views) * 1e3, 2)}
+    ctx.set_inflight(2)
+    out["in_flight"] = {"batches": len(views), "events": sum(ev_all), "lanes": over,
+                        "note": "the same consecutive default batches through abea_align_batch_host_submit/_wait, a rolling "
+                                "window of `lanes` batches in flight on one context"}
+    return out
+
+
+def fused_scaling(ctx, batch, view):
+    """align_db + scaling_db in one call (abea_f5c_align_scale's entry: process_db, src/f5c.c:924-936): base_to_event_map,
+    recalibrated scalings, events_per_base and flags come back, the pair lists do not (pairs = NULL).  Same batch, host
+    buffers in and out, outside the timed region."""
+    import numpy as np
+    v = ctx.host_view(batch, scaling=True, want_pairs=False)
+    ctx.align_view(v)
+    reps = 3
+    t0 = time.perf_counter()
+    for _ in range(reps):
         ctx.align_view(v)
     t = (time.perf_counter() - t0) / reps
-    ev = int(sub["n_events"].sum())
-    return {"reads": n, "bases": int(L[:n].sum()), "events": ev, "ms_per_batch": round(t * 1e3, 2),
-            "mevents_per_s": round(ev / t / 1e6, 1), "longest_read_bases": int(L[:n].max()),
-            "note": "host-to-host, one batch at a time as process_db issues them; INTEGRATION.md recommends -K 20000 -B 200M"}
+    st = ctx.stats()
+    ev = int(batch["n_events"].sum())
+    same = bool((v["n_pairs"] == view["n_pairs"]).all())
+    cal = int(((v["read_stat_flag"] & 1) == 0).sum())
+    return {"mevents_per_s": round(ev / t / 1e6, 1), "ms_per_step": round(t * 1e3, 2),
+            "scaling_kernels_ms_sum_over_chunks": round(st["trace_ms"], 2),
+            "pcie_bytes_per_step": {"h2d": int(st["h2d_bytes"]), "d2h": int(st["d2h_bytes"])},
+            "n_pairs_equal_alignment_only": same, "reads_calibrated": cal,
+            "note": "pairs = NULL; the walk (2 bit/step) crosses PCIe and the host expands it into base_to_event_map"}
 
 
 def pmc_traffic(config, sum_events, launches):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of `bench.py --mode device`
-    on the shipped kernel (profiles/pmc_traffic.json: bytes per event, FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM)."""
+    on the same workload (profiles/pmc_traffic.json: FETCH_SIZE and WRITE_SIZE both measured on this config, separate
+    passes, FETCH doubled per MI355X_MICROARCH.md §HBM)."""
     try:
         t = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))[config]
         return int(t["hbm_bytes_per_event"] * sum_events / max(1, launches))
@@ -285,14 +339,18 @@ def pmc_traffic(config, sum_events, launches):
 
 
 def valu_issue(config, sum_events, launch_ms, launches):
-    """What actually bounds the kernel: VALU issue.  wave64 VALU instructions per launch (rocprofv3 SQ_INSTS_VALU of
-    the same command, profiles/pmc_traffic.json) x measured issue cost per instruction per SIMD / (1024 SIMDs x time)."""
+    """What actually bounds the kernel: VALU issue.  `frac` is a MEASURED ratio on this config — the gfx9 VALUBusy formula,
+    SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs), from the committed rocprofv3 PMC pass of
+    `bench.py --mode device` on the same workload (profiles/pmc_traffic.json, built by profiles/make_pmc_traffic.py) — not an
+    instruction count times a cost constant (round 2's model gave 1.025, an impossible fraction)."""
     try:
         t = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))[config]
-        n_inst = t["valu_wave_instr_per_event"] * sum_events / max(1, launches)
-        busy_ms = n_inst * t["valu_issue_ns_per_instr"] * 1e-6 / 1024.0
-        return {"unit": "valu-issue", "frac": round(busy_ms / launch_ms, 3), "valu_wave_instr_per_launch": int(n_inst),
-                "source": t.get("source", "profiles/pmc_traffic.json")}
+        return {"unit": "valu-busy", "frac": round(t["valu_busy"], 4), "formula": t["valu_busy_formula"],
+                "valu_wave_instr_per_launch": int(t["valu_wave_instr_per_event"] * sum_events / max(1, launches)),
+                "wave_time_split": {k: round(v, 3) for k, v in t["wave_time_split"].items()},
+                "lds_bank_conflict_cycles": t.get("lds_bank_conflict_cycles"),
+                "kernel_ms_in_the_pmc_pass": t["kernel_ms_in_each_pass"].get("sqb"), "kernel_ms_this_run": round(launch_ms, 3),
+                "source": t["passes"].get("sqb")}
     except Exception:
         return None
 

@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("ABEA_LIB_PATH", os.path.join(_HERE, "libabea_hip.so")
 
 EXPORTS = ["abea_init", "abea_init_multi", "abea_device_count", "abea_free", "abea_last_error", "abea_align_batch_host",
            "abea_align_batch_device", "abea_detect_events_device", "abea_get_stats", "abea_get_device_stats",
-           "abea_device_info", "abea_selftest", "abea_rsq_format", "abea_lpt_split", "abea_hmm_score_batch_host", "abea_expand_walk_codes",
+           "abea_device_info", "abea_selftest", "abea_rsq_format", "abea_lpt_split", "abea_hmm_score_batch_host", "abea_expand_walk_codes", "abea_expand_walk_codes_to_map",
            "abea_host_plan_chunks", "abea_host_plan_threads", "abea_set_inflight", "abea_align_batch_host_submit",
            "abea_align_batch_host_wait"]
 SHIM_EXPORTS = ["abea_f5c_init", "abea_f5c_align", "abea_f5c_align_scale", "abea_f5c_free"]      # include/abea_f5c_shim.h

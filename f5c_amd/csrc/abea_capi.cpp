@@ -287,7 +287,7 @@ extern "C" int abea_align_batch_device(abea_ctx* c, const abea_device_batch* B) 
         size_t end = pos, bytes = 4096;
         while (end < seq.size()) {
             const plan_read& r = reads[(size_t)seq[end]];
-            size_t need = r.run ? scratch_bytes(r) : sizeof(abea_read_desc);
+            size_t need = r.run ? scratch_bytes(r) + (B->base_to_event_map ? (size_t)r.K * sizeof(abea_mrec) + 4 : 0) : sizeof(abea_read_desc) + 4;
             if (bytes + need + 65536 > c->arena_bytes) break;
             bytes += need; ++end;
         }
@@ -300,12 +300,15 @@ extern "C" int abea_align_batch_device(abea_ctx* c, const abea_device_batch* B) 
 
         /* ---- arena layout: [desc][kpar][evm][codes][trace] ---- */
         sub_layout lay;
+        size_t n_mrec = 0;
         for (size_t j = 0; j < m; ++j) {
             const plan_read& r = reads[(size_t)seq[pos + j]];
             abea_read_desc& d = c->h_desc[j];
             plan_desc(d, r, B->scalings[r.idx], lay, st);
             d.read_off = B->read_ptr[r.idx]; d.event_off = B->event_ptr[r.idx]; d.pair_off = B->pair_ptr[r.idx];
             d.kmer_off = B->kmer_ptr ? B->kmer_ptr[r.idx] : 0;
+            d.pad64 = (int64_t)n_mrec;
+            if (r.run && B->base_to_event_map) n_mrec += (size_t)r.K;
         }
         const size_t n_kpar = lay.n_kpar, n_evm = lay.n_evm, n_code = lay.n_code, n_trace = lay.n_trace;
         uint8_t* p = c->arena;
@@ -314,6 +317,8 @@ extern "C" int abea_align_batch_device(abea_ctx* c, const abea_device_batch* B) 
         float* d_evm = (float*)p;                           p += align_up(n_evm * 4 + 512, 256);
         uint32_t* d_codes = (uint32_t*)p;                   p += align_up(n_code * 4, 256);
         uint4* d_trace = (uint4*)p;                         p += n_trace * sizeof(uint4);
+        abea_mrec* d_mrec = (abea_mrec*)p;                  p += align_up(n_mrec * sizeof(abea_mrec), 256);
+        int32_t* d_nm = (int32_t*)p;                        p += align_up(m * 4, 256);
         if ((size_t)(p - c->arena) > c->arena_bytes)
             return abea_fail(ABEA_ENOMEM, "internal: sub-batch layout %zu exceeds arena %zu", (size_t)(p - c->arena), c->arena_bytes);
 
@@ -329,8 +334,9 @@ extern "C" int abea_align_batch_device(abea_ctx* c, const abea_device_batch* B) 
         if (B->base_to_event_map) {                          /* row N1: scaling_single on the device */
             hipLaunchKernelGGL(abea_scaling_kernel, dim3((unsigned)m), dim3(64), 0, c->stream,
                                d_desc, B->reads, c->d_model, (int)c->k, d_evm, B->pairs, B->n_pairs,
-                               B->base_to_event_map, B->scalings_io, B->events_per_base, B->read_stat_flag,
-                               B->n_event_alignment,
+                               B->base_to_event_map, B->events_per_base, B->read_stat_flag, B->n_event_alignment, d_mrec, d_nm);
+            hipLaunchKernelGGL(abea_recalib_kernel, dim3((unsigned)((m + 63) / 64)), dim3(64), 0, c->stream,
+                               d_desc, (int)m, d_mrec, d_nm, B->scalings_io, B->events_per_base, B->read_stat_flag,
                                B->min_num_events_to_rescale > 0 ? B->min_num_events_to_rescale : 200);
         }
         HIP_TRY(hipEventRecord(c->ev[3], c->stream));

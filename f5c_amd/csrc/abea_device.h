@@ -27,12 +27,15 @@ typedef struct __attribute__((aligned(16))) {
     int64_t trace_off;    /* uint4  into the trace scratch (n_groups * 64 uint4) */
     int64_t code_off;     /* uint32 into the traceback-code scratch */
     int64_t kmer_off;     /* abea_index_pair_t into base_to_event_map (optional scaling outputs) */
-    int64_t pad64;
+    int64_t pad64;        /* abea_mrec into the 'M'-state record scratch of the scaling kernels (n_kmers slots) */
     int32_t read_len, n_events, n_kmers, n_groups;
     float   scale, shift;
     int32_t out_idx;      /* index of the read in the caller's n_pairs[] / diag[] */
     int32_t pad;
     double  lp_skip, lp_stay, lp_step, lp_trim;   /* align.c:212-216 */
 } abea_read_desc;
+
+/* one 'M' state of recalibrate_model (align.c:688-753): what its sums read, in k order */
+struct __attribute__((aligned(16))) abea_mrec { float sd; float mu; float e; float pad; };
 
 #endif

@@ -247,7 +247,7 @@ struct abea_host_slot {
     std::vector<int32_t> rd;                            /* caller index of descriptor j */
     bool scaling = false, device_pairs = false, staged = false;
     size_t o_np = 0, o_diag = 0, o_codes = 0, o_poff = 0, o_cursor = 0, o_pairs = 0;      /* offsets in `dn` */
-    size_t o_b2e = 0, o_sc = 0, o_epb = 0, o_flag = 0, o_nal = 0;
+    size_t o_sc = 0, o_epb = 0, o_flag = 0, o_nal = 0;
     abea_pair_t* d_pairs = nullptr;                     /* device-pairs mode: compacted lists to copy at stage A */
     size_t pair_cap = 0;
 };
@@ -377,6 +377,41 @@ static void expand_codes(const uint32_t* codes, int32_t n, int32_t k, int32_t e,
     _mm_sfence();
 }
 
+/* The same walk -> db->base_to_event_map[i] (postalign, align.c:571-596), without going through the pair list: pair i is
+ * a NEW event iff its predecessor in the list has a different event, i.e. iff the step leaving it is not a "left"
+ * (k-mer only) step; a k-mer's entry is {first, last} new event of its run of pairs, {-1,-1} when the run has none.
+ * Every k-mer from the first pair's to the last pair's has a run (a step changes the k-mer by at most one); k-mers below
+ * the first pair's stay {-1,-1} (none for a list that passed QC: it spans k-mer 0, align.c:529). */
+static void expand_codes_to_map(const uint32_t* codes, int32_t n, int32_t k, int32_t e, abea_index_pair_t* map) {
+    int32_t start = -1, stop = -1;
+    long long* m64 = reinterpret_cast<long long*>(map);
+    for (int32_t j = 0; j < n; j += 16) {
+        uint32_t w = codes[j >> 4];
+        const int32_t lim = std::min(16, n - j);
+        for (int32_t t = 0; t < lim; ++t) {
+            const uint32_t cd = w & 3u;
+            w >>= 2;
+            const bool last = (j + t == n - 1);
+            if (last || cd != 2u) { if (stop == -1) stop = e; start = e; }
+            const int32_t dk = last ? 1 : (int32_t)(cd != 1u);
+            if (dk) {                                      /* leaving k-mer k: its entry is final (written once, never read back here) */
+                _mm_stream_si64(m64 + k, (long long)(((uint64_t)(uint32_t)stop << 32) | (uint32_t)start));
+                start = stop = -1;
+            }
+            k -= dk; e -= (cd != 2u);
+        }
+    }
+    for (; k >= 0; --k) _mm_stream_si64(m64 + k, -1ll);     /* {-1, -1} */
+    _mm_sfence();
+}
+
+extern "C" int abea_expand_walk_codes_to_map(const uint32_t* codes, int32_t n_steps, int32_t last_kmer, int32_t end_event,
+                                             abea_index_pair_t* map) {
+    if (n_steps < 1 || !codes || !map || last_kmer < 0) return abea_fail(ABEA_EINVAL, "abea_expand_walk_codes_to_map: bad argument");
+    expand_codes_to_map(codes, n_steps, last_kmer, end_event, map);
+    return ABEA_OK;
+}
+
 /* host-only entry over the same routine, so that the expansion can be unit-tested without a GPU */
 extern "C" int abea_expand_walk_codes(const uint32_t* codes, int32_t n_steps, int32_t last_kmer, int32_t end_event, abea_pair_t* out) {
     if (n_steps < 0 || (n_steps && (!codes || !out))) return abea_fail(ABEA_EINVAL, "abea_expand_walk_codes: bad argument");
@@ -412,7 +447,7 @@ struct chunk_span { size_t begin, end; size_t events; bool whole_arena; };
 static size_t chunk_io_bytes(const plan_read& r, bool pairs_on_device, bool scaling) {
     size_t b = align_up((size_t)r.L + 1, 16) + 4 + sizeof(abea_read_diag) + 8;
     if (pairs_on_device) b += ((size_t)r.E + (size_t)r.L) * sizeof(abea_pair_t);
-    if (scaling) b += (size_t)r.K * sizeof(abea_index_pair_t) + sizeof(abea_scalings_t) + 8 + 4 + 4;
+    if (scaling) b += (size_t)r.K * (sizeof(abea_index_pair_t) + 16) + sizeof(abea_scalings_t) + 8 + 4 + 4 + 4;   /* map + 'M' records (device scratch) */
     return b + 64;
 }
 
@@ -535,7 +570,6 @@ static int slot_retire(host_run_state& S, abea_host_slot& sl) {
     const uint32_t* codes = (const uint32_t*)(sl.dn + sl.o_codes);
     const int64_t* poff = (const int64_t*)(sl.dn + sl.o_poff);
     const abea_pair_t* pairs = (const abea_pair_t*)(sl.dn + sl.o_pairs);
-    const abea_index_pair_t* b2e = (const abea_index_pair_t*)(sl.dn + sl.o_b2e);
     const abea_scalings_t* sc = (const abea_scalings_t*)(sl.dn + sl.o_sc);
     const double* epb = (const double*)(sl.dn + sl.o_epb);
     const int32_t* flag = (const int32_t*)(sl.dn + sl.o_flag);
@@ -553,8 +587,8 @@ static int slot_retire(host_run_state& S, abea_host_slot& sl) {
                 else expand_codes(codes + descs[j].code_off, np, descs[j].n_kmers - 1, diag[j].best_event, H->pairs[i]);
             }
             if (scaling) {
-                if (np > 0 && H->base_to_event_map[i])
-                    memcpy(H->base_to_event_map[i], b2e + descs[j].kmer_off, (size_t)descs[j].n_kmers * sizeof(abea_index_pair_t));
+                if (np > 0 && H->base_to_event_map[i])        /* the map is expanded from the walk, like the pairs: 0.4 B per event on the wire */
+                    expand_codes_to_map(codes + descs[j].code_off, np, descs[j].n_kmers - 1, diag[j].best_event, H->base_to_event_map[i]);
                 if (H->scalings_out) H->scalings_out[i] = sc[j];
                 if (H->events_per_base) H->events_per_base[i] = epb[j];
                 if (H->read_stat_flag) H->read_stat_flag[i] = flag[j];
@@ -732,17 +766,17 @@ static int host_run(abea_ctx* c, const abea_host_batch* H, const int32_t* mine, 
                 plan_desc(descs[j], r, H->scalings[caller], lay, S.st);
                 descs[j].read_off = (int64_t)ro; ro += align_up((size_t)r.L + 1, 16);
                 descs[j].pair_off = (int64_t)po; po += (size_t)r.E + (size_t)r.L;
-                descs[j].kmer_off = (int64_t)ko; ko += (size_t)r.K;
+                descs[j].kmer_off = (int64_t)ko; descs[j].pad64 = (int64_t)ko;      /* map entries and 'M' records: at most one per k-mer */
+                ko += (size_t)r.K;
             }
         }
         /* `dn` = [npairs][diag][codes | poff, cursor][scaling outputs] mirrors the arena block behind the scratch */
         size_t o = 0;
         sl.o_np = o;      o = align_up(o + (size_t)m * 4, 256);
         sl.o_diag = o;    o = align_up(o + (size_t)m * sizeof(abea_read_diag), 256);
-        sl.o_codes = o;   if (!S.device_pairs && S.want_pairs) o = align_up(o + lay.n_code * 4, 256);
+        sl.o_codes = o;   if (!S.device_pairs && (S.want_pairs || scaling)) o = align_up(o + lay.n_code * 4, 256);
         sl.o_poff = o;    if (S.device_pairs) o = align_up(o + (size_t)m * 8, 256);
         sl.o_cursor = o;  if (S.device_pairs) o = align_up(o + 8, 256);
-        sl.o_b2e = o;     if (scaling) o = align_up(o + n_kmer * sizeof(abea_index_pair_t), 256);
         sl.o_sc = o;      if (scaling) o = align_up(o + (size_t)m * sizeof(abea_scalings_t), 256);
         sl.o_epb = o;     if (scaling) o = align_up(o + (size_t)m * 8, 256);
         sl.o_flag = o;    if (scaling) o = align_up(o + (size_t)m * 4, 256);
@@ -758,9 +792,15 @@ static int host_run(abea_ctx* c, const abea_host_batch* H, const int32_t* mine, 
         uint4* d_trace = (uint4*)p;                         p += align_up(lay.n_trace * sizeof(uint4), 256);
         uint8_t* d_dn = p;                                  p += dn_copy;
         uint32_t* d_codes_scratch = nullptr;                /* codes stay on the device when nobody wants them */
-        if (S.device_pairs || !S.want_pairs) { d_codes_scratch = (uint32_t*)p; p += align_up(lay.n_code * 4, 256); }
+        if (S.device_pairs) { d_codes_scratch = (uint32_t*)p; p += align_up(lay.n_code * 4, 256); }
         abea_pair_t* d_pairs = nullptr;
         if (pairs_on_device) { d_pairs = (abea_pair_t*)p; p += align_up(n_pair * sizeof(abea_pair_t), 256); }
+        abea_index_pair_t* d_b2e = nullptr; abea_mrec* d_mrec = nullptr; int32_t* d_nm = nullptr;
+        if (scaling) {                                      /* device-only scratch of the two scaling kernels */
+            d_b2e = (abea_index_pair_t*)p;  p += align_up(n_kmer * sizeof(abea_index_pair_t), 256);
+            d_mrec = (abea_mrec*)p;         p += align_up(n_kmer * sizeof(abea_mrec), 256);
+            d_nm = (int32_t*)p;             p += align_up((size_t)m * 4, 256);
+        }
         if ((size_t)(p - arena) > (whole_arena ? lane.arena_bytes : slot_arena))
             return abea_fail(ABEA_ENOMEM, "internal: chunk layout %zu exceeds its arena share %zu", (size_t)(p - arena),
                              whole_arena ? lane.arena_bytes : slot_arena);
@@ -813,7 +853,6 @@ static int host_run(abea_ctx* c, const abea_host_batch* H, const int32_t* mine, 
             }
             HIP_TRY(hipMemcpyAsync(d_dn + sl.o_sc, h_sc, (size_t)m * sizeof(abea_scalings_t), hipMemcpyHostToDevice, sl.stream));
             HIP_TRY(hipMemcpyAsync(d_dn + sl.o_flag, h_flag, (size_t)m * 4, hipMemcpyHostToDevice, sl.stream));
-            HIP_TRY(hipMemsetAsync(d_dn + sl.o_b2e, 0xFF, n_kmer * sizeof(abea_index_pair_t), sl.stream));   /* {-1,-1}: align.c:566-569 */
         }
         HIP_TRY(hipEventRecord(sl.k0, sl.stream));
         hipLaunchKernelGGL(abea_pre_kernel, dim3((unsigned)m), dim3(256), 0, sl.stream,
@@ -825,9 +864,11 @@ static int host_run(abea_ctx* c, const abea_host_batch* H, const int32_t* mine, 
         HIP_TRY(hipEventRecord(sl.k2, sl.stream));
         if (scaling) {
             hipLaunchKernelGGL(abea_scaling_kernel, dim3((unsigned)m), dim3(64), 0, sl.stream,
-                               d_desc, d_reads, c->d_model, (int)c->k, d_evm, d_pairs, d_np,
-                               (abea_index_pair_t*)(d_dn + sl.o_b2e), (abea_scalings_t*)(d_dn + sl.o_sc),
-                               (double*)(d_dn + sl.o_epb), (int32_t*)(d_dn + sl.o_flag), (int32_t*)(d_dn + sl.o_nal), min_rescale);
+                               d_desc, d_reads, c->d_model, (int)c->k, d_evm, d_pairs, d_np, d_b2e,
+                               (double*)(d_dn + sl.o_epb), (int32_t*)(d_dn + sl.o_flag), (int32_t*)(d_dn + sl.o_nal), d_mrec, d_nm);
+            hipLaunchKernelGGL(abea_recalib_kernel, dim3((unsigned)((m + 63) / 64)), dim3(64), 0, sl.stream,
+                               d_desc, (int)m, d_mrec, d_nm, (abea_scalings_t*)(d_dn + sl.o_sc),
+                               (const double*)(d_dn + sl.o_epb), (int32_t*)(d_dn + sl.o_flag), min_rescale);
             HIP_TRY(hipEventRecord(sl.k3, sl.stream));
         }
         /* the result block goes down by a kernel, not by an SDMA copy: a copy queued behind the alignment kernel would

@@ -470,7 +470,7 @@ void abea_align_kernel(const abea_read_desc* __restrict__ descs,
 #ifdef ABEA_NO_ASM
     int e = best_e, k = K - 1, llk = best_llk;
     int n = 0, gap = 0, max_gap = 0, last_k = k;
-    uint32_t cwd = 0, cv = 0;
+    uint32_t cwd = 0, cv = 0, walk_reloads = 0;
     {
         int b = e + k + 2;
         uint4 cw = trace[(size_t)(b >> 5) * 64 + lane];
@@ -518,14 +518,14 @@ void abea_align_kernel(const abea_read_desc* __restrict__ descs,
 #else
     /* hand-written scalar walk (tools/gen_fill_asm.py: gen_walk), same semantics as the loop above */
     int n, max_gap, last_k;
-    uint32_t cwd, cv;
+    uint32_t cwd, cv, walk_reloads;
     {
         uint32_t o_sh2, o_nfl;
         const uint4* u_trace = (const uint4*)uni_p(trace);
         uint32_t* u_codes = (uint32_t*)uni_p(codes);
         asm volatile(ABEA_WALK_ASM
             : [last_k] "=&s"(last_k), [o_cwd] "=&s"(cwd), [o_sh2] "=&s"(o_sh2), [o_nfl] "=&s"(o_nfl),
-              [o_maxgap] "=&s"(max_gap), [o_cv] "=&v"(cv)
+              [o_maxgap] "=&s"(max_gap), [o_reloads] "=&s"(walk_reloads), [o_cv] "=&v"(cv)
             : [k0] "s"(uni(K - 1)), [e0] "s"(uni(best_e)), [llk0] "s"(uni(best_llk)),
               [trace] "s"(u_trace), [codes] "s"(u_codes), [lane] "v"(lane)
             : ABEA_WALK_CLOBBERS);
@@ -601,6 +601,7 @@ void abea_align_kernel(const abea_read_desc* __restrict__ descs,
             dg.sum_emission = sum; dg.n_aligned = n; dg.best_event = best_e;
             dg.max_score = best; dg.max_gap = max_gap; dg.spanned = spanned;
             dg.flags = fail ? ABEA_RF_QC_FAIL : 0;
+            dg.pad = (int32_t)walk_reloads;              /* diagnostic: trace groups the walk had to load whole */
 #ifdef ABEA_PROFILE_PHASES   /* experiment build only: overwrite the diagnostics with a phase timeline (100 MHz ticks) */
             const unsigned long long t_end = wall_clock64();
             dg.sum_emission = (double)t_start; dg.best_event = (int)(t_fill - t_start);
@@ -629,26 +630,33 @@ void abea_copy_out_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst
 
 /* ================================================================ scaling_single on the device (row N1)
  * postalign (align.c:561-661) + recalibrate_model (align.c:666-773) + the QC flags of scaling_single
- * (f5c.c:736-807), one wavefront per read, run after abea_align_kernel while pairs/evm are still resident.
- *   base_to_event_map: every k-mer owns one contiguous run of pairs; its first pair repeats the previous
- *     event iff it was reached by a skip (FROM_L), all later pairs of the run are new events.
- *   'M' states = first event of each k-mer that has events and whose rank differs from the previous such
- *     k-mer; the five normal-equation sums and the variance sum are accumulated in k order, in fp64, by a
- *     uniform LDS loop (adding +0.0 for non-'M' k-mers), so they round exactly as the reference's loop. */
+ * (f5c.c:736-807), run after abea_align_kernel while pairs/evm are still resident.  Two kernels:
+ *   abea_scaling_kernel (one wavefront per read, parallel over pairs / k-mers)
+ *     base_to_event_map: every k-mer owns one contiguous run of pairs; its first pair repeats the previous
+ *       event iff it was reached by a skip (FROM_L), all later pairs of the run are new events.
+ *     'M' states = first event of each k-mer that has events and whose rank differs from the previous such
+ *       k-mer.  Each one becomes a 16-byte record {1/(stdv*stdv) fp64, level_mean, event mean} in k order.
+ *   abea_recalib_kernel (one LANE per read)
+ *     the five normal-equation sums and the variance sum are sequential fp64 chains in k order in the reference
+ *     (align.c:703-716, 738-751) and their terms are full-mantissa doubles, so no re-association is exact: the chains
+ *     stay sequential, but 64 reads run them side by side in one wavefront instead of one read serialising 64 lanes
+ *     through LDS (round 2: a 50 kb read held a wave slot for milliseconds). */
 extern "C" __global__ __launch_bounds__(64)
 void abea_scaling_kernel(const abea_read_desc* __restrict__ descs, const char* __restrict__ reads,
                          const abea_model_t* __restrict__ model, int kmer_size,
                          const float* __restrict__ evm_all, const abea_pair_t* __restrict__ pairs_all,
                          const int32_t* __restrict__ n_pairs, abea_index_pair_t* __restrict__ b2e_all,
-                         abea_scalings_t* __restrict__ sc_io, double* __restrict__ epb_out,
-                         int32_t* __restrict__ flag_io, int32_t* __restrict__ nalign_out, int min_rescale) {
-    __shared__ double acc_s[5][64];
+                         double* __restrict__ epb_out, int32_t* __restrict__ flag_io, int32_t* __restrict__ nalign_out,
+                         abea_mrec* __restrict__ mrec_all, int32_t* __restrict__ n_m_out) {
     const abea_read_desc* d = descs + blockIdx.x;
     const int lane = threadIdx.x;
     const int out_idx = d->out_idx;
     const int n = n_pairs[out_idx];
     if (d->n_groups == 0 || n <= 0) {                    /* f5c.c:786-794: could not align */
-        if (lane == 0) { flag_io[out_idx] |= ABEA_FAILED_ALIGNMENT; epb_out[out_idx] = 0.0; nalign_out[out_idx] = 0; }
+        if (lane == 0) {
+            flag_io[out_idx] |= ABEA_FAILED_ALIGNMENT; epb_out[out_idx] = 0.0; nalign_out[out_idx] = 0;
+            n_m_out[blockIdx.x] = -1;
+        }
         return;
     }
     const int K = d->n_kmers;
@@ -656,6 +664,7 @@ void abea_scaling_kernel(const abea_read_desc* __restrict__ descs, const char* _
     abea_index_pair_t* map = b2e_all + d->kmer_off;
     const float* __restrict__ evm = evm_all + d->evm_off;
     const char* __restrict__ seq = reads + d->read_off;
+    abea_mrec* __restrict__ mrec = mrec_all + d->pad64;   /* pad64 = record offset of this read (at most K records) */
 
     /* ---- base_to_event_map (align.c:571-596) ---- */
     for (int i = lane; i < n; i += 64) {
@@ -672,8 +681,7 @@ void abea_scaling_kernel(const abea_read_desc* __restrict__ descs, const char* _
     const double events_per_base = (double)(pairs[n - 1].read_pos - pairs[0].read_pos) / K;   /* align.c:602 */
     __syncthreads();
 
-    /* ---- recalibrate_model: normal equations over the 'M' states (align.c:677-723) ---- */
-    double A00 = 0, A01 = 0, A11 = 0, b0 = 0, b1 = 0;
+    /* ---- the 'M' states in k order (hmm_state, align.c:637; counted at align.c:677-686) ---- */
     int n_M = 0, n_align = 0, carry_rank = -1;
     for (int k0 = 0; k0 < K; k0 += 64) {
         const int k = k0 + lane;
@@ -690,81 +698,92 @@ void abea_scaling_kernel(const abea_read_desc* __restrict__ descs, const char* _
         const int below = __shfl(rank, src, 64);          /* every lane takes part: the source lane may have lower == 0 */
         const int prev_rank = lower ? below : carry_rank;
         const bool isM = valid && (rank != prev_rank);
-        double t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
+        const unsigned long long mm = __ballot(isM);
         if (isM) {
             const abea_model_t mo = model[rank];
-            const double e = evm[m.start], mu = mo.level_mean, sd = mo.level_stdv;
-            const double inv_var = 1. / (sd * sd);
-            t0 = inv_var; t1 = mu * inv_var; t2 = mu * mu * inv_var; t3 = e * inv_var; t4 = mu * e * inv_var;
+            abea_mrec r;
+            r.sd = mo.level_stdv; r.mu = mo.level_mean; r.e = evm[m.start]; r.pad = 0.f;
+            mrec[n_M + __popcll(mm & ((1ull << lane) - 1ull))] = r;     /* compacted: record m = the m-th 'M' state */
         }
-        acc_s[0][lane] = t0; acc_s[1][lane] = t1; acc_s[2][lane] = t2; acc_s[3][lane] = t3; acc_s[4][lane] = t4;
-        n_M += __popcll(__ballot(isM));
+        n_M += __popcll(mm);
         n_align += valid ? (m.stop - m.start + 1) : 0;
-        __syncthreads();
-        #pragma unroll 4
-        for (int l = 0; l < 64; ++l) {                   /* uniform, k order */
-            A00 += acc_s[0][l]; A01 += acc_s[1][l]; A11 += acc_s[2][l]; b0 += acc_s[3][l]; b1 += acc_s[4][l];
-        }
-        __syncthreads();
         if (vm) carry_rank = __shfl(rank, 63 - __clzll(vm), 64);
     }
     for (int off = 32; off > 0; off >>= 1) n_align += __shfl_xor(n_align, off, 64);
+    if (lane == 0) {
+        epb_out[out_idx] = events_per_base;
+        nalign_out[out_idx] = n_align;
+        n_m_out[blockIdx.x] = n_M;
+    }
+}
 
+/* recalibrate_model's arithmetic (align.c:688-765) and scaling_single's flags (f5c.c:770-805): lane = read.  Reads of a
+ * wavefront are neighbours in the launch order (longest first), so their chains have similar lengths. */
+extern "C" __global__ __launch_bounds__(64)
+void abea_recalib_kernel(const abea_read_desc* __restrict__ descs, int n_desc, const abea_mrec* __restrict__ mrec_all,
+                         const int32_t* __restrict__ n_m_in, abea_scalings_t* __restrict__ sc_io,
+                         const double* __restrict__ epb_in, int32_t* __restrict__ flag_io, int min_rescale) {
+    const int j = blockIdx.x * 64 + threadIdx.x;
+    if (j >= n_desc) return;
+    const abea_read_desc* d = descs + j;
+    const int n_M = n_m_in[j];
+    if (n_M < 0) return;                                 /* not aligned: flagged by abea_scaling_kernel */
+    const int out_idx = d->out_idx;
+    const float4* __restrict__ mrec = reinterpret_cast<const float4*>(mrec_all + d->pad64);
     bool calibrated = false;
     double shift = 0, scale = 0, var = 0;
     if (n_M >= min_rescale) {
+        double A00 = 0, A01 = 0, A11 = 0, b0 = 0, b1 = 0;
+        for (int m0 = 0; m0 < n_M; m0 += 4) {            /* a lane streams its own 64 bytes at a time */
+            float4 r[4];
+            #pragma unroll
+            for (int q = 0; q < 4; ++q) r[q] = mrec[min(m0 + q, n_M - 1)];
+            #pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (m0 + q < n_M) {
+                    const double sd = r[q].x, mu = r[q].y, e = r[q].z;
+                    const double inv_var = 1. / (sd * sd);   /* align.c:697-706, in this order */
+                    A00 += inv_var;
+                    A01 += mu * inv_var;
+                    A11 += mu * mu * inv_var;
+                    b0 += e * inv_var;
+                    b1 += mu * e * inv_var;
+                }
+            }
+        }
         const double A10 = A01;
         const double div = A00 * A11 - A01 * A10;
         shift = -(A01 * b1 - A11 * b0) / div;
         scale = (A00 * b1 - A10 * b0) / div;
-        carry_rank = -1;
-        for (int k0 = 0; k0 < K; k0 += 64) {             /* align.c:738-753 */
-            const int k = k0 + lane;
-            abea_index_pair_t m; m.start = -1; m.stop = -1;
-            int rank = 0;
-            if (k < K) {
-                m = map[k];
-                for (int j = 0; j < kmer_size; ++j) rank = (rank << 2) | (int)base_code(seq[k + j]);
+        for (int m0 = 0; m0 < n_M; m0 += 4) {            /* align.c:738-753 */
+            float4 r[4];
+            #pragma unroll
+            for (int q = 0; q < 4; ++q) r[q] = mrec[min(m0 + q, n_M - 1)];
+            #pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (m0 + q < n_M) {
+                    const double sd = r[q].x, mu = r[q].y, e = r[q].z;
+                    const double yi = (e - shift - scale * mu);
+                    var += yi * yi / (sd * sd);
+                }
             }
-            const bool valid = m.start != -1;
-            const unsigned long long vm = __ballot(valid);
-            const unsigned long long lower = vm & ((1ull << lane) - 1ull);
-            const int src = lower ? 63 - __clzll(lower) : 0;
-            const int below = __shfl(rank, src, 64);          /* every lane takes part: the source lane may have lower == 0 */
-        const int prev_rank = lower ? below : carry_rank;
-            double t = 0;
-            if (valid && rank != prev_rank) {
-                const abea_model_t mo = model[rank];
-                const double e = evm[m.start], mu = mo.level_mean, sd = mo.level_stdv;
-                const double yi = (e - shift - scale * mu);
-                t = yi * yi / (sd * sd);
-            }
-            acc_s[0][lane] = t;
-            __syncthreads();
-            #pragma unroll 8
-            for (int l = 0; l < 64; ++l) var += acc_s[0][l];
-            __syncthreads();
-            if (vm) carry_rank = __shfl(rank, 63 - __clzll(vm), 64);
         }
         var /= n_M;
         var = sqrt(var);
         calibrated = true;
     }
-    if (lane == 0) {
-        epb_out[out_idx] = events_per_base;
-        nalign_out[out_idx] = n_align;
-        int flag = 0;
-        float fvar = sc_io[out_idx].var;
-        if (calibrated) {
-            abea_scalings_t o = sc_io[out_idx];
-            o.shift = (float)shift; o.scale = (float)scale; o.var = (float)var;
-            sc_io[out_idx] = o;
-            fvar = o.var;
-        }
-        if (!calibrated || fvar > 2.5) flag |= ABEA_FAILED_CALIBRATION;       /* f5c.c:776-782 */
-        else if (events_per_base > 5.0) flag |= ABEA_FAILED_QUALITY_CHK;      /* f5c.c:799-805 */
-        flag_io[out_idx] |= flag;
+    const double events_per_base = epb_in[out_idx];
+    int flag = 0;
+    float fvar = sc_io[out_idx].var;
+    if (calibrated) {
+        abea_scalings_t o = sc_io[out_idx];
+        o.shift = (float)shift; o.scale = (float)scale; o.var = (float)var;
+        sc_io[out_idx] = o;
+        fvar = o.var;
     }
+    if (!calibrated || fvar > 2.5) flag |= ABEA_FAILED_CALIBRATION;       /* f5c.c:776-782 */
+    else if (events_per_base > 5.0) flag |= ABEA_FAILED_QUALITY_CHK;      /* f5c.c:799-805 */
+    flag_io[out_idx] |= flag;
 }
 
 

@@ -46,7 +46,7 @@ typedef struct {
     int32_t max_gap;        /* align.c:497 */
     int32_t spanned;        /* align.c:529-530 */
     int32_t flags;          /* ABEA_RF_* */
-    int32_t pad;
+    int32_t pad;            /* diagnostic, not part of the reference: trace groups the traceback had to re-load whole */
 } abea_read_diag;
 #define ABEA_RF_SKIPPED   0x1   /* failed the align_single guards (f5c.c:813-814) or shorter than k: n_pairs = 0 */
 #define ABEA_RF_NO_END    0x2   /* no in-band end cell (max_score == -inf): n_pairs = 0 */
@@ -101,7 +101,7 @@ typedef struct {
     abea_read_diag* diag;                  /* optional [n_reads], may be NULL */
     /* ---- optional: scaling_db() fused behind the alignment (src/f5c.c:736-807 scaling_single = postalign +
      *      recalibrate_model, src/align.c:561-773; row N1).  The pair lists have no other consumer in process_db
-     *      (src/f5c.c:907-960: align_db, then pthread_db(scaling_single), then meth_single reads only base_to_event_map / scalings / events_per_base), so with pairs == NULL only 8 B per k-mer come back instead of 8 B per pair.
+     *      (src/f5c.c:907-960: align_db, then pthread_db(scaling_single), then meth_single reads only base_to_event_map / scalings / events_per_base).  What crosses PCIe is still the 2-bit walk (0.4 B per event) plus 36 B of scalars per read: the host workers expand the walk into base_to_event_map (and into the pair lists when pairs != NULL), the device runs the recalibration.
      *      All NULL = alignment only. ---- */
     abea_index_pair_t* const* base_to_event_map;   /* db->base_to_event_map[i]: caller-allocated, read_len-k+1 entries;
                                                       written only for reads with n_pairs > 0 (the reference leaves NULL otherwise) */
@@ -270,6 +270,10 @@ int abea_lpt_split(const int64_t* weight, int32_t n, int32_t n_bins, int32_t* bi
  * step, 16 steps per word, step 0 = the end cell (last_kmer, end_event); 0 = diagonal, 1 = up (event only), 2 = left
  * (k-mer only) — expanded into the ascending (ref_pos, read_pos) list align() returns (src/align.c:452-513). */
 int abea_expand_walk_codes(const uint32_t* codes, int32_t n_steps, int32_t last_kmer, int32_t end_event, abea_pair_t* out);
+/* The same walk expanded straight into db->base_to_event_map[i] (postalign, src/align.c:571-596; last_kmer + 1 entries):
+ * what the host entry does when scaling_single is fused — the map never crosses PCIe either.  Host-only. */
+int abea_expand_walk_codes_to_map(const uint32_t* codes, int32_t n_steps, int32_t last_kmer, int32_t end_event,
+                                  abea_index_pair_t* map);
 /* The chunk plan abea_align_batch_host() uses for a batch on an arena of arena_bytes (host-only; pairs returned, no
  * fused scaling): chunk_of[i] = launch-order number of the chunk read i goes into, -1 for reads skipped by the
  * align_single guards (src/f5c.c:813-814).  Reads go longest first; a chunk holds >= 2048 reads and >= 48 M events (the

@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""profiles/pmc_traffic.json from the committed rocprofv3 PMC passes of `bench.py --mode device` (tools/profile_r03.sh):
+   python profiles/make_pmc_traffic.py profiles/r03/a_      (prefix of the *_counter_collection.csv files)
+Every number of the json is an average over the abea_align_kernel dispatches of one pass; nothing is inferred from another
+config.  Corrections / definitions (MI355X_MICROARCH.md, HBM and rocprofv3 sections):
+  hbm bytes   = FETCH_SIZE(KB) x 1024 x 2  (gfx950 tallies the 128-B requests of wide coalesced reads at 64 B)  +  WRITE_SIZE(KB) x 1024
+  valu_busy   = SQ_ACTIVE_INST_VALU x 4 / (n_simd x GRBM_GUI_ACTIVE / n_xcd)     the gfx9 VALUBusy formula: SQ_ACTIVE_INST_* count
+                quad-cycles summed over waves, GRBM_GUI_ACTIVE counts cycles summed over the 8 XCDs
+  wave-time split: SQ_ACTIVE_INST_ANY + SQ_WAIT_INST_ANY + SQ_WAIT_ANY = SQ_WAVE_CYCLES (issuing / issue-stalled / parked)"""
+import collections, csv, json, os, sys
+
+EVENTS = {"10k": ("r9_10k_8kb", 158727291), "100k": ("r9_100k_mixed", 2514312019)}
+N_SIMD, N_XCD = 1024, 8
+
+
+def avg(path, kernel="abea_align_kernel"):
+    acc, cnt, dur = collections.defaultdict(float), collections.Counter(), []
+    for r in csv.DictReader(open(path)):
+        if r["Kernel_Name"].startswith(kernel):
+            acc[r["Counter_Name"]] += float(r["Counter_Value"]); cnt[r["Counter_Name"]] += 1
+            dur.append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
+    return {c: acc[c] / cnt[c] for c in acc}, (sum(dur) / len(dur) if dur else None), max(cnt.values()) if cnt else 0
+
+
+def main(prefix):
+    out = {}
+    for tag, (config, events) in EVENTS.items():
+        c, src, kms = {}, {}, {}
+        for p in ("sqa", "sqb", "fetch", "write"):
+            path = f"{prefix}pmc_{p}{tag}_counter_collection.csv"
+            if not os.path.exists(path):
+                continue
+            v, ms, n = avg(path)
+            c.update(v); kms[p] = round(ms, 3); src[p] = f"{path} ({n} launches)"
+        if "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
+            continue
+        hbm = c["FETCH_SIZE"] * 1024 * 2 + c["WRITE_SIZE"] * 1024
+        e = {"kernel": "abea_align_kernel", "events_per_launch": events,
+             "FETCH_SIZE_KB": c["FETCH_SIZE"], "WRITE_SIZE_KB": c["WRITE_SIZE"],
+             "fetch_bytes_per_event_x2": c["FETCH_SIZE"] * 2048 / events, "write_bytes_per_event": c["WRITE_SIZE"] * 1024 / events,
+             "hbm_bytes_per_launch": hbm, "hbm_bytes_per_event": hbm / events,
+             "kernel_ms_in_each_pass": kms, "passes": src,
+             "sq_counters_per_launch": {k: v for k, v in sorted(c.items()) if k.startswith("SQ_") or k.startswith("GRBM")}}
+        if "SQ_ACTIVE_INST_VALU" in c and "GRBM_GUI_ACTIVE" in c:
+            e["valu_busy"] = c["SQ_ACTIVE_INST_VALU"] * 4 / (N_SIMD * c["GRBM_GUI_ACTIVE"] / N_XCD)
+            e["valu_busy_formula"] = "SQ_ACTIVE_INST_VALU*4 / (1024 SIMDs * GRBM_GUI_ACTIVE/8 XCDs), measured on this config"
+            e["shader_clock_ghz"] = c["GRBM_GUI_ACTIVE"] / N_XCD / (kms["sqb"] * 1e6)
+            w = c["SQ_WAVE_CYCLES"]
+            e["wave_time_split"] = {"issuing": c["SQ_ACTIVE_INST_ANY"] / w, "issue_stalled": c["SQ_WAIT_INST_ANY"] / w,
+                                    "parked_on_waitcnt": c["SQ_WAIT_ANY"] / w}
+        if "SQ_INSTS_VALU" in c:
+            e["valu_wave_instr_per_event"] = c["SQ_INSTS_VALU"] / events
+            e["salu_wave_instr_per_event"] = c["SQ_INSTS_SALU"] / events
+            e["lds_bank_conflict_cycles"] = c.get("SQ_LDS_BANK_CONFLICT")
+        out[config] = e
+    json.dump(out, open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "pmc_traffic.json"), "w"), indent=1)
+    for k, e in out.items():
+        print(k, {x: (round(v, 4) if isinstance(v, float) else v) for x, v in e.items() if not isinstance(v, dict)})
+
+
+if __name__ == "__main__":
+    main(sys.argv[1] if len(sys.argv) > 1 else "profiles/r03/a_")

@@ -89,6 +89,46 @@ def test_walk_code_expansion_matches_the_traceback(orc, r9):
             roundtrip(o_pairs[s:s + o_n[i]])
             done += 1
     assert done >= 8
+    # the same walk expanded straight into base_to_event_map == postalign on the pair list (align.c:571-596)
+    lib.abea_expand_walk_codes_to_map.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]
+
+    def map_roundtrip(pairs, seq, ev, scale, shift):
+        p = np.asarray(pairs).view(np.int32).reshape(-1, 2).astype(np.int64)
+        n = len(p)
+        dk = p[1:, 0] - p[:-1, 0]; de = p[1:, 1] - p[:-1, 1]
+        code = np.concatenate([np.where((dk == 1) & (de == 1), 0, np.where(de == 1, 1, 2))[::-1], [3]])
+        words = np.zeros((n + 15) // 16 + 1, dtype=np.uint32)
+        for j, c in enumerate(code):
+            words[j >> 4] |= np.uint32(int(c) << (2 * (j & 15)))
+        K = int(p[-1, 0]) + 1
+        out = np.full((K + 1, 2), -7, dtype=np.int32)
+        assert lib.abea_expand_walk_codes_to_map(words.ctypes.data, n, K - 1, int(p[-1, 1]), out.ctypes.data) == 0
+        want = orc.scaling_single(pairs, seq, ev, model, k, scale, shift)["base_to_event_map"]
+        assert len(want) == K and (out[:K, 0] == want["start"]).all() and (out[:K, 1] == want["stop"]).all()
+        assert (out[K] == -7).all()
+
+    n_maps = 0
+    for i in range(12):
+        if o_n[i] > 0:
+            s = int(batch["pair_ptr"][i]); rs, L = int(batch["read_ptr"][i]), int(batch["read_len"][i])
+            es, E = int(batch["event_ptr"][i]), int(batch["n_events"][i])
+            map_roundtrip(o_pairs[s:s + o_n[i]], batch["reads"][rs:rs + L].tobytes(), batch["events"][es:es + E],
+                          batch["scalings"]["scale"][i], batch["scalings"]["shift"][i])
+            n_maps += 1
+    assert n_maps >= 8
+    # skips (k-mers whose only pair repeats the previous event keep {-1,-1}) and stays, by hand
+    hand = np.array([[0, 0], [1, 0], [2, 0], [2, 1], [2, 2], [3, 3], [4, 3], [5, 4], [5, 5]], dtype=np.int32).view(PAIR_DT).ravel()
+    p = hand.view(np.int32).reshape(-1, 2)
+    dk = np.diff(p[:, 0]); de = np.diff(p[:, 1])
+    code = np.concatenate([np.where((dk == 1) & (de == 1), 0, np.where(de == 1, 1, 2))[::-1], [0]])
+    words = np.zeros(2, dtype=np.uint32)
+    for j, c in enumerate(code):
+        words[j >> 4] |= np.uint32(int(c) << (2 * (j & 15)))
+    out = np.zeros((6, 2), dtype=np.int32)
+    assert lib.abea_expand_walk_codes_to_map(words.ctypes.data, len(p), 5, 5, out.ctypes.data) == 0
+    assert out.tolist() == [[0, 0], [-1, -1], [1, 2], [3, 3], [-1, -1], [4, 5]]
+    assert lib.abea_expand_walk_codes_to_map(None, 3, 2, 2, out.ctypes.data) != 0
+
     for n in (1, 2, 15, 16, 17, 31, 32, 33, 1024, 1025):       # word boundaries
         steps = np.random.default_rng(n).integers(0, 3, n - 1)
         p = np.zeros((n, 2), dtype=np.int32)

@@ -356,8 +356,10 @@ def body(p, ml, m, rs):
     emit(f"v_cndmask_b32 {v(Q)}, {v(A0)}, {v(Q)}, %[m50]")
     emit(f"v_cndmask_b32 {v(Q+1)}, {v(A1)}, {v(Q+1)}, %[m50]")
     emit("s_nop 1")
+    emit("s_mov_b32 exec_hi, 0x7FFFF")                    # lanes 0..50 only: 25.5 B per band instead of 32 (lanes 51..63 hold nothing)
     emit(f"global_store_dwordx4 {v(TOFF)}, {vq(Q)}, %[trace]")
-    emit("s_nop 1")                                       # store data registers are rewritten by the next band
+    emit("s_mov_b32 exec_hi, -1")
+    emit("s_nop 0")                                       # store data registers are rewritten by the next band
     emit(f"v_add_u32 {v(TOFF)}, 0x400, {v(TOFF)}")
     emit("s_mov_b32 %[mvprev], %[mvacc]")
     emit(f"nostore_{tag}_%=:")
@@ -526,36 +528,53 @@ if __name__ == "__main__":
 
 # =====================================================================================================
 # Traceback walk (align.c:452-499) on the scalar unit: one inline-asm statement, ~40 SALU per step.
-# Fixed SGPRs s76..s99, VGPRs v64..v75 (the fill statement's range; the two statements never overlap).
+# Fixed SGPRs s72..s99, VGPRs v64..v75 (the fill statement's range; the two statements never overlap).
 # =====================================================================================================
+WALK_RADIUS = int(os.environ.get("ABEA_WALK_RADIUS", "4"))     # lane pairs either side of the path that a prefetch covers
+
+
 def gen_walk():
+    """Scalar-unit traceback walk.  Round 3: a trace group is no longer read back whole (1 KiB per 32 bands).  The
+    prefetch of the group below loads only the 64-byte sectors holding the lanes within WALK_RADIUS lane pairs of the
+    path's current lane pair, plus the sector of the move lane (lane 50); if the path leaves that window before the group
+    is done with (rare: the adaptive band keeps the path near its middle) the whole group is loaded again."""
     o = []
     e = o.append
     K, E, BI, LLK, G, GAP, MAXGAP, CWD, SH2, NFL, LP, DK = (f"s{i}" for i in range(76, 88))
     TLO, THI, MV, T64 = "s[88:89]", "s[90:91]", "s[92:93]", "s[94:95]"
     T64LO = "s94"
     T, U, X, Y = "s96", "s97", "s98", "s99"
+    WC, WR, NWC, RLD = "s72", "s73", "s74", "s75"      # window centre / radius of the current group, centre of the next, reload count
     CW = [f"v{i}" for i in range(VB, VB + 4)]      # current 32-band trace group: one uint4 per lane
     NXG = [f"v{i}" for i in range(VB + 4, VB + 8)] # prefetched group below
     CV, VT, L16, L4 = f"v{VB + 8}", f"v{VB + 9}", f"v{VB + 10}", f"v{VB + 11}"
+    W = WALK_RADIUS
     # ---- entry
     e(f"s_mov_b32 {K}, %[k0]"); e(f"s_mov_b32 {E}, %[e0]"); e(f"s_mov_b32 {LLK}, %[llk0]")
     e(f"s_add_u32 {T}, {K}, {E}"); e(f"s_add_u32 {T}, {T}, 2")           # b = e + k + 2
     e(f"s_lshr_b32 {G}, {T}, 5"); e(f"s_and_b32 {BI}, {T}, 31")
-    for r in (GAP, MAXGAP, CWD, SH2, NFL, DK):
+    for r in (GAP, MAXGAP, CWD, SH2, NFL, DK, RLD, WC):
         e(f"s_mov_b32 {r}, 0")
+    e(f"s_mov_b32 {WR}, 64")                                               # the first group is loaded whole
     e(f"v_mov_b32 {CV}, 0")
     e(f"v_lshlrev_b32 {L16}, 4, %[lane]"); e(f"v_lshlrev_b32 {L4}, 2, %[lane]")
     e(f"s_lshl_b32 {T}, {G}, 10")
-    e(f"global_load_dwordx4 v[{VB}:{VB + 3}], {L16}, %[trace]")                    # placeholder, patched below with soffset add
-    o.pop()
     # 64-bit base + (g << 10): trace groups are 1 KiB
     e(f"s_mov_b64 {T64}, %[trace]"); e(f"s_add_u32 s94, s94, {T}"); e("s_addc_u32 s95, s95, 0")
     e(f"global_load_dwordx4 v[{VB}:{VB + 3}], {L16}, {T64}")
     e("group_top_%=:")
     e(f"s_max_i32 {T}, {G}, 1"); e(f"s_sub_u32 {T}, {T}, 1"); e(f"s_lshl_b32 {T}, {T}, 10")
     e(f"s_mov_b64 {T64}, %[trace]"); e(f"s_add_u32 s94, s94, {T}"); e("s_addc_u32 s95, s95, 0")
+    # window of the prefetch: lanes [(c - W) & ~3, (c + W) | 3] clamped to [0, 51], c = lane pair of the path now
+    e(f"s_sub_u32 {NWC}, {K}, {LLK}"); e(f"s_lshr_b32 {NWC}, {NWC}, 1")
+    e(f"s_sub_i32 {X}, {NWC}, {W}"); e(f"s_max_i32 {X}, {X}, 0"); e(f"s_andn2_b32 {X}, {X}, 3")      # first lane
+    e(f"s_add_u32 {Y}, {NWC}, {W}"); e(f"s_min_u32 {Y}, {Y}, 51"); e(f"s_or_b32 {Y}, {Y}, 3")        # last lane
+    e(f"s_sub_u32 {Y}, {Y}, {X}"); e(f"s_add_u32 {Y}, {Y}, 1")                                       # lane count (<= 2W + 7)
+    e(f"s_bfm_b64 {TLO}, {Y}, {X}")                                          # TLO/THI are reloaded at the first step of the group
+    e("s_or_b32 s89, s89, 0xF0000")                                         # lanes 48..51: the sector of the move lane
+    e(f"s_mov_b64 exec, {TLO}")
     e(f"global_load_dwordx4 v[{VB + 4}:{VB + 7}], {L16}, {T64}")                       # prefetch the group below
+    e("s_mov_b64 exec, -1")
     e("s_waitcnt vmcnt(1)")                                                 # the current group has landed
     e(f"v_readlane_b32 s92, {CW[0]}, 50")                                  # band moves of this group ...
     e(f"v_readlane_b32 s93, {CW[1]}, 50")                                  # ... and of the group below
@@ -599,13 +618,26 @@ def gen_walk():
     e("s_waitcnt vmcnt(0)")
     for a, b in zip(CW, NXG):
         e(f"v_mov_b32 {a}, {b}")
+    e(f"s_mov_b32 {WC}, {NWC}"); e(f"s_mov_b32 {WR}, {W}")                  # the group just entered holds lanes WC +- W only
     e("s_branch group_top_%=")
     # ---- out of line
     e("reload_lp_%=:")
     e(f"s_mov_b32 {LP}, {U}")
+    e(f"s_sub_i32 {X}, {U}, {WC}"); e(f"s_abs_i32 {X}, {X}")
+    e(f"s_cmp_le_u32 {X}, {WR}")
+    e("s_cbranch_scc0 full_reload_%=")
+    e("reload_ret_%=:")
     e(f"v_readlane_b32 s88, {CW[0]}, {U}"); e(f"v_readlane_b32 s89, {CW[1]}, {U}")
     e(f"v_readlane_b32 s90, {CW[2]}, {U}"); e(f"v_readlane_b32 s91, {CW[3]}, {U}")
     e("s_branch step_cont_%=")
+    e("full_reload_%=:")                                                    # the path left the prefetched window: load group G whole
+    e(f"s_lshl_b32 {X}, {G}, 10")
+    e(f"s_mov_b64 {T64}, %[trace]"); e(f"s_add_u32 s94, s94, {X}"); e("s_addc_u32 s95, s95, 0")
+    e("s_waitcnt vmcnt(0)")                                                 # the prefetch of G-1 (other registers) is in, nothing else in flight
+    e(f"global_load_dwordx4 v[{VB}:{VB + 3}], {L16}, {T64}")
+    e(f"s_mov_b32 {WR}, 64"); e(f"s_add_u32 {RLD}, {RLD}, 1")
+    e("s_waitcnt vmcnt(0)")
+    e("s_branch reload_ret_%=")
     e("flush_%=:")                                                          # 16 codes complete: dword nfl -> lane nfl & 63
     e(f"s_and_b32 {X}, {NFL}, 63")
     e(f"v_cmp_eq_u32 vcc, {X}, %[lane]")
@@ -624,10 +656,10 @@ def gen_walk():
     e("s_waitcnt vmcnt(0)")
     e(f"s_add_u32 %[last_k], {K}, {DK}")
     e(f"s_mov_b32 %[o_cwd], {CWD}"); e(f"s_mov_b32 %[o_sh2], {SH2}"); e(f"s_mov_b32 %[o_nfl], {NFL}")
-    e(f"s_mov_b32 %[o_maxgap], {MAXGAP}")
+    e(f"s_mov_b32 %[o_maxgap], {MAXGAP}"); e(f"s_mov_b32 %[o_reloads], {RLD}")
     e(f"v_mov_b32 %[o_cv], {CV}")
     text = "\n".join(f'    "{ln}\\n\\t"' for ln in o)
-    clob = ", ".join([f'"s{i}"' for i in range(76, 100)] + [f'"v{i}"' for i in range(VB, VB + 12)])
+    clob = ", ".join([f'"s{i}"' for i in range(72, 100)] + [f'"v{i}"' for i in range(VB, VB + 12)])
     inc = f"""/* GENERATED by tools/gen_fill_asm.py — do not edit. Scalar-unit traceback walk. */
 #define ABEA_WALK_ASM \\
 {text.replace(chr(10), " " + chr(92) + chr(10))}
