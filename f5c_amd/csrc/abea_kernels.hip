@@ -131,7 +131,9 @@ static __device__ __forceinline__ void abea_cell(float x, float gpm, float ck, d
                                                  float& m, uint32_t& from) {
     float dx = __fsub_rn(x, gpm);
     float a  = (float)((double)dx * istd);                     /* == dx / stdv, correctly rounded */
-    float lp = __fadd_rn(ck, __fmul_rn(__fmul_rn(-0.5f, a), a));   /* align.c:113 */
+    /* align.c:113: ck + (-0.5f*a)*a.  Halving is exact, so RN((-0.5a)*a) = -0.5*RN(a*a) and one fma adds that product to ck
+     * with the single rounding of the reference's add (identical unless a*a underflows and ck == 0: one subnormal ulp) */
+    float lp = __fmaf_rn(-0.5f, __fmul_rn(a, a), ck);
     double lpd = (double)lp;
     float sd = (float)((D + lp_step) + lpd);                   /* align.c:382 */
     float su = (float)((U + lp_stay) + lpd);                   /* align.c:383 */
@@ -189,9 +191,12 @@ void abea_align_kernel(const abea_read_desc* __restrict__ descs,
     /* pairs_all == nullptr: the pair lists are not materialised on the device (the host entry expands them from the
      * walk codes).  pair_cursor != nullptr: pair lists are packed back to back in completion order (atomic bump
      * allocation of n entries per read, offset reported in pair_off_out[]) instead of at desc.pair_off. */
-    __shared__ uint4 smem[256];                        /* 4 KiB: phase 1 rings, phase 3 emission buffer */
-    abea_kpar_t* const k_ring = reinterpret_cast<abea_kpar_t*>(smem);        /* 128 x 16 B */
-    float* const e_ring = reinterpret_cast<float*>(smem + 128);              /* 128 x 4 B  */
+    /* 8 KiB: [0, 4096) phase 3 emission buffer; [4096, 6144) k-mer ring; [6144, 6656) event ring.  The rings sit above
+     * offset 252 because the fill loop reads them with ds_read_addtid_b32 (address = M0 + 4*lane, M0 >= 0) and the
+     * k-mer ring's reader is lane 63; their bases are 4 KiB / 1 KiB aligned for the s_bitset0 wrap. */
+    __shared__ __attribute__((aligned(4096))) uint4 smem[512];
+    abea_kpar_t* const k_ring = reinterpret_cast<abea_kpar_t*>(smem + 256);  /* 128 x 16 B */
+    float* const e_ring = reinterpret_cast<float*>(smem + 384);              /* 128 x 4 B  */
     float* const lp_s = reinterpret_cast<float*>(smem);                      /* 1024 x 4 B */
 
     const abea_read_desc* d = descs + blockIdx.x;
@@ -400,9 +405,9 @@ void abea_align_kernel(const abea_read_desc* __restrict__ descs,
                               : uni(min(nb_pad, b + max(max(-ll_k, 99 - ll_e), 256)));   /* chunk: re-check for the interior variant later */
             uint32_t s_k_addr = (uint32_t)uni((int)(kring_a + ((uint32_t)k_next & 127u) * 16u));
             uint32_t s_e_addr = (uint32_t)uni((int)(ering_a + ((uint32_t)e_next & 127u) * 4u));
-            if ((kring_a & 4095u) != 0u || (ering_a & 1023u) != 0u) __builtin_trap();   /* ring wrap uses s_bitset0 */
+            if ((kring_a & 4095u) != 0u || (ering_a & 1023u) != 0u || kring_a < 252u) __builtin_trap();   /* ring wrap uses s_bitset0; M0 = k_addr - 252 */
             const int Km1 = K - 1, Em1 = E - 1;
-            const uint64_t hi_mask = 0xFFFC000000000000ull, m50 = 1ull << ABEA_MOVE_LANE;
+            const uint64_t m50 = 1ull << ABEA_MOVE_LANE;
             uint32_t s_mvacc = (uint32_t)uni((int)mvacc), s_mvprev = (uint32_t)uni((int)mvprev);
             const double u_step = uni_d(lp_step), u_stay = uni_d(lp_stay), u_skip = uni_d(lp_skip), u_trim = uni_d(lp_trim);
             const float* u_evm = (const float*)uni_p(evm);
@@ -432,11 +437,12 @@ void abea_align_kernel(const abea_read_desc* __restrict__ descs,
 #define ABEA_FILL_INS \
                   ABEA_FILL_VINS, [lp_step] "s"(u_step), [lp_stay] "s"(u_stay), [lp_skip] "s"(u_skip), \
                   [Km1] "s"(uni(Km1)), [Em1] "s"(uni(Em1)), [kring] "s"(kring_a), [ering] "s"(ering_a), \
-                  [b_end] "s"(s_b_end), [m50] "s"(m50), [evm] "s"(u_evm), [kpar] "s"(u_kpar), [trace] "s"(u_trace)
+                  [b_end] "s"(s_b_end), [m50] "s"(m50), [evm] "s"(u_evm), [kpar] "s"(u_kpar), [trace] "s"(u_trace), \
+                  [ninf] "s"(0xff800000u)
             asm volatile(ABEA_FILL_ASM
                 : ABEA_FILL_OUTS, [t2] "=&s"(t2), [t3] "=&s"(t3), [t4] "=&s"(t4), [cv0] "=&s"(cv0), [cv1] "=&s"(cv1),
                   [best] "+s"(s_best), [best_e] "+s"(s_best_e), [best_llk] "+s"(s_best_llk)
-                : ABEA_FILL_INS, [hi_mask] "s"(hi_mask), [lp_trim] "s"(u_trim), [mode] "s"(uni(interior ? 0 : 1))
+                : ABEA_FILL_INS, [lp_trim] "s"(u_trim), [mode] "s"(uni(interior ? 0 : 1))
                 : ABEA_FILL_CLOBBERS);
             best = __uint_as_float(s_best); best_e = s_best_e; best_llk = s_best_llk;
             ll_e = s_ll_e; ll_k = s_ll_k; e_next = ll_e + 1; k_next = ll_k + 128; b = s_b; run = 0;

@@ -116,9 +116,12 @@ def cell_ops(j, D, U, L, quad):
         f"v_cvt_f64_f32 {vp(lpd)}, {v(t32)}",
         f"v_mul_f64 {vp(lpd)}, {vp(lpd)}, {vp(i)}",
         f"v_cvt_f32_f64 {v(t32)}, {vp(lpd)}",
-        f"v_mul_f32 {v(tu)}, -0.5, {v(t32)}",
-        f"v_mul_f32 {v(tu)}, {v(tu)}, {v(t32)}",
-        f"v_add_f32 {v(tu)}, {v(ck)}, {v(tu)}",
+        # lp = ck + (-0.5f*a)*a (align.c:113) in two instructions: halving is exact, so RN((-0.5a)*a) = -0.5*RN(a*a), and the
+        # fma adds that exact product to ck with the ONE rounding the reference's add performs.  (Differs from the three-
+        # instruction form only when a*a underflows AND ck == 0: by one subnormal ulp, 1e-45, of a term that is added to
+        # scores in fp64 — DESIGN.md §4.3.)
+        f"v_mul_f32 {v(tu)}, {v(t32)}, {v(t32)}",
+        f"v_fma_f32 {v(tu)}, -0.5, {v(tu)}, {v(ck)}",
         f"v_cvt_f64_f32 {vp(lpd)}, {v(tu)}",
         f"v_add_f64 {vp(td)}, {vp(D)}, %[lp_step]",
         f"v_add_f64 {vp(tu)}, {vp(U)}, %[lp_stay]",
@@ -200,6 +203,10 @@ def body(p, ml, m, rs):
         rs = (rs + 1) % 3                                    # roles after the move: cell 0 = old cell 1, cell 1 = old incoming
         emit("s_add_u32 %[ll_k], %[ll_k], 1")
         emit(f"v_mov_b32_dpp {v(SHR)}, {v(MF0)} {DPP_SHL}")
+        # lanes >= 50 are the k-mer FIFO and their "scores" are garbage; the only one a band cell ever reads is lane 50's
+        # slot 0 = offset 100, through this shift into lane 49: pin THAT to -inf (the band ends at offset 99).  Round 2
+        # masked slot 0 of every band with a v_cndmask; a down move never looks at it.
+        emit(f"v_writelane_b32 {v(SHR)}, %[ninf], 49")
         emit("s_waitcnt lgkmcnt(1)" if ml == 'D' else "s_waitcnt lgkmcnt(0)")     # incoming k-mer landed
         # every offset takes the k-mer of the offset above: cell 0's quad slides down one lane INTO the incoming quad,
         # whose lane 63 keeps the pre-read incoming k-mer (DPP `old`); cell 1's quad becomes cell 0's by renaming
@@ -211,16 +218,20 @@ def body(p, ml, m, rs):
         emit("s_and_b32 %[t0], %[k_addr], 1023")            # entering a new 64-entry chunk?
         emit(f"s_cbranch_scc0 krefill_{tag}_%=")
         emit(f"kcont_{tag}_%=:")
-        emit(f"v_mov_b32 {v(TMP)}, %[k_addr]")
+        # the next incoming k-mer lands in the old cell-0 quad (dead now); only LANE 63 of it matters (the DPP `old` lane of
+        # the next right move), so it is read with ds_read_addtid_b32 (LDS address = M0 + offset + 4*lane, no address VGPR,
+        # no VALU): M0 = k_addr - 252
+        emit("s_sub_u32 m0, %[k_addr], 252")
         emit(f"v_cvt_f64_f32 {vp(T['c0'])}, {v(MF0)}")
-        emit(f"ds_read_b128 {vq(KQ[(rs + 2) % 3])}, {v(TMP)}")    # the next incoming k-mer lands in the old cell-0 quad (dead now)
+        for j in range(4):
+            emit(f"ds_read_addtid_b32 {v(KQ[(rs + 2) % 3] + j)} offset:{4 * j}")
         sh = SHR
         U = (T['c1'], T['cs']); L = (T['c0'], T['c1'])
         D = (Tp['c1'], Tp['cs']) if ml == 'R' else (Tp['c0'], Tp['c1'])
     else:
         emit("s_add_u32 %[ll_e], %[ll_e], 1")
         emit(f"v_mov_b32_dpp {v(SHD)}, {v(MF1)} {DPP_SHR}")
-        emit("s_waitcnt lgkmcnt(1)" if ml == 'R' else "s_waitcnt lgkmcnt(0)")     # incoming event landed
+        emit("s_waitcnt lgkmcnt(4)" if ml == 'R' else "s_waitcnt lgkmcnt(0)")     # incoming event landed (a right move's four k-mer reads may still be out)
         emit(f"v_mov_b32_dpp {v(NX)}, {v(X1)} {DPP_SHR}")
         emit(f"v_mov_b32 {v(X1)}, {v(X0)}")
         emit("s_lshl_b32 %[mvacc], %[mvacc], 1")
@@ -230,9 +241,9 @@ def body(p, ml, m, rs):
         emit("s_and_b32 %[t0], %[e_addr], 255")
         emit(f"s_cbranch_scc0 erefill_{tag}_%=")
         emit(f"econt_{tag}_%=:")
-        emit(f"v_mov_b32 {v(TMP)}, %[e_addr]")
+        emit("s_mov_b32 m0, %[e_addr]")                     # lane 0 (the DPP `old` lane of the next down move) reads ring[e_addr]
         emit(f"v_cvt_f64_f32 {vp(T['c0'])}, {v(MF0)}")
-        emit(f"ds_read_b32 {v(NX)}, {v(TMP)}")
+        emit(f"ds_read_addtid_b32 {v(NX)}")
         sh = SHD
         U = (T['c0'], T['c1']); L = (T['cs'], T['c0'])
         D = (Tp['c0'], Tp['c1']) if ml == 'R' else (Tp['cs'], Tp['c0'])
@@ -327,9 +338,6 @@ def body(p, ml, m, rs):
         emit("s_add_u32 %[b], %[b], 1")
         emit(f"v_lshl_or_b32 {v(ACC)}, {v(ACC)}, 4, {v(F[0])}")
     else:
-        # lanes >= 50 are the k-mer FIFO; the only one of their scores a band cell ever reads is lane 50's slot 0
-        # (lane 49's right-move shift), so only slot 0 is pinned to -inf
-        emit(f"v_cndmask_b32 {v(MF0)}, {v(MF0)}, {v(NINF)}, %[hi_mask]")
         # trace bits, oldest first: cell 1 [sl<max], cell 1 [su<sd], cell 0 [sl<max], cell 0 [su<sd]; each v_alignbit
         # is acc = acc << 1 | sign(difference).  Complemented per dword they read f = 2*[sl==max] + [su>=sd]:
         # 0 FROM_D, 1 FROM_U, 2 or 3 FROM_L (align.c:386-392 priority).
@@ -530,7 +538,7 @@ if __name__ == "__main__":
 # Traceback walk (align.c:452-499) on the scalar unit: one inline-asm statement, ~40 SALU per step.
 # Fixed SGPRs s72..s99, VGPRs v64..v75 (the fill statement's range; the two statements never overlap).
 # =====================================================================================================
-WALK_RADIUS = int(os.environ.get("ABEA_WALK_RADIUS", "4"))     # lane pairs either side of the path that a prefetch covers
+WALK_RADIUS = int(os.environ.get("ABEA_WALK_RADIUS", "26"))     # lane pairs either side of the path that a prefetch covers
 
 
 def gen_walk():
