@@ -29,12 +29,36 @@ extern "C" void abea_f5c_init(abea_f5c_core* core) {
     core->align_cuda_postprocess = core->align_cuda_total_kernel = 0;
 }
 
+/* what a submitted batch keeps alive until its wait: the pointer / count arrays the host batch points into */
+struct shim_pending {
+    std::vector<const abea_event_t*> ev;
+    std::vector<uint64_t> n_ev;
+    abea_f5c_db* db = nullptr;
+    int32_t ticket = -1;
+    bool scale = false;
+};
+
+static void shim_fill(abea_f5c_core* core, abea_f5c_db* db, bool scale, const char* who, std::vector<const abea_event_t*>& ev,
+                      std::vector<uint64_t>& n_ev, abea_host_batch& hb);
+static void shim_finish(abea_f5c_core* core, abea_f5c_db* db, bool scale, const char* who);
+
 static void shim_run(abea_f5c_core* core, abea_f5c_db* db, bool scale, const char* who) {
-    const int32_t n = db->n_bam_rec;
-    std::vector<const abea_event_t*> ev((size_t)n);
-    std::vector<uint64_t> n_ev((size_t)n);
-    for (int32_t i = 0; i < n; ++i) { ev[(size_t)i] = db->et[i].event; n_ev[(size_t)i] = db->et[i].n; }
+    std::vector<const abea_event_t*> ev;
+    std::vector<uint64_t> n_ev;
     abea_host_batch hb;
+    shim_fill(core, db, scale, who, ev, n_ev, hb);
+    if (abea_align_batch_host((abea_ctx*)core->cuda, &hb) != ABEA_OK) {
+        fprintf(stderr, "[%s::ERROR]\033[1;31m abea_align_batch_host: %s\033[0m\n", who, abea_last_error());
+        exit(EXIT_FAILURE);
+    }
+    shim_finish(core, db, scale, who);
+}
+
+static void shim_fill(abea_f5c_core* core, abea_f5c_db* db, bool scale, const char* who, std::vector<const abea_event_t*>& ev,
+                      std::vector<uint64_t>& n_ev, abea_host_batch& hb) {
+    const int32_t n = db->n_bam_rec;
+    ev.resize((size_t)n); n_ev.resize((size_t)n);
+    for (int32_t i = 0; i < n; ++i) { ev[(size_t)i] = db->et[i].event; n_ev[(size_t)i] = db->et[i].n; }
     memset(&hb, 0, sizeof hb);
     hb.n_reads = n;
     hb.read = db->read;
@@ -62,10 +86,10 @@ static void shim_run(abea_f5c_core* core, abea_f5c_db* db, bool scale, const cha
         hb.n_event_alignment = db->n_event_alignment;
         hb.min_num_events_to_rescale = core->min_num_events_to_rescale;
     }
-    if (abea_align_batch_host((abea_ctx*)core->cuda, &hb) != ABEA_OK) {
-        fprintf(stderr, "[%s::ERROR]\033[1;31m abea_align_batch_host: %s\033[0m\n", who, abea_last_error());
-        exit(EXIT_FAILURE);
-    }
+}
+
+static void shim_finish(abea_f5c_core* core, abea_f5c_db* db, bool scale, const char* who) {
+    const int32_t n = db->n_bam_rec;
     if (scale)
         for (int32_t i = 0; i < n; ++i)
             if (db->n_event_align_pairs[i] <= 0 && db->base_to_event_map[i]) { free(db->base_to_event_map[i]); db->base_to_event_map[i] = nullptr; }
@@ -94,6 +118,26 @@ extern "C" void abea_f5c_align_scale(abea_f5c_core* core, abea_f5c_db* db) {
         exit(EXIT_FAILURE);
     }
     shim_run(core, db, true, __func__);
+}
+
+/* Two process_db batches in flight (src/meth_main.c:668-689 overlaps only I/O with processing): submit starts the batch
+ * on a free lane of the context and returns; wait blocks until db's outputs are complete.  db (and everything it points
+ * to) must stay untouched in between.  At most ABEA_MAX_INFLIGHT handles outstanding; same results as abea_f5c_align. */
+extern "C" void* abea_f5c_align_submit(abea_f5c_core* core, abea_f5c_db* db) {
+    shim_pending* p = new shim_pending();
+    p->db = db;
+    abea_host_batch hb;
+    shim_fill(core, db, false, __func__, p->ev, p->n_ev, hb);
+    if (abea_align_batch_host_submit((abea_ctx*)core->cuda, &hb, &p->ticket) != ABEA_OK) SHIM_DIE("abea_align_batch_host_submit");
+    return p;
+}
+
+extern "C" void abea_f5c_align_wait(abea_f5c_core* core, void* handle) {
+    shim_pending* p = (shim_pending*)handle;
+    if (!p) return;
+    if (abea_align_batch_host_wait((abea_ctx*)core->cuda, p->ticket) != ABEA_OK) SHIM_DIE("abea_align_batch_host_wait");
+    shim_finish(core, p->db, false, __func__);
+    delete p;
 }
 
 extern "C" void abea_f5c_free(abea_f5c_core* core) {

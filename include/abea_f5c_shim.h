@@ -62,6 +62,11 @@ void abea_f5c_align(abea_f5c_core* core, abea_f5c_db* db);
  * base_to_event_map / recalibrated db->scalings / events_per_base / read_stat_flag come back.  db->event_align_pairs
  * may be NULL (or given, then it is filled as well, e.g. for --print-banded-aln). */
 void abea_f5c_align_scale(abea_f5c_core* core, abea_f5c_db* db);
+/* abea_f5c_align split in two, so that a caller can keep two (up to ABEA_MAX_INFLIGHT) process_db batches in flight —
+ * f5c's default -K 512 / -B 2M batches are latency-bound on a GPU.  submit returns a handle at once;
+ * wait blocks until db->event_align_pairs / n_event_align_pairs are complete.  db must stay valid and untouched between. */
+void* abea_f5c_align_submit(abea_f5c_core* core, abea_f5c_db* db);
+void abea_f5c_align_wait(abea_f5c_core* core, void* handle);
 void abea_f5c_free(abea_f5c_core* core);
 
 #ifdef __cplusplus

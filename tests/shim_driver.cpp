@@ -75,6 +75,19 @@ int main(int argc, char** argv) {
         for (int32_t i = 0; i < n; ++i) { free(b2e[i]); b2e[i] = nullptr; flag[i] = 0; }
         sc = sc0; db.scalings = sc.data();
         abea_f5c_align_scale(&core, &db);                    /* a second batch through the same context */
+    } else if (getenv("SHIM_ASYNC")) {
+        /* two process_db batches in flight on one context: the first and the second half of the reads as two db views */
+        const int32_t h = n / 2;
+        abea_f5c_db a = db, b = db;
+        a.n_bam_rec = h; b.n_bam_rec = n - h;
+        b.read += h; b.read_len += h; b.et += h; b.scalings += h; b.event_align_pairs += h; b.n_event_align_pairs += h;
+        if (b.nsample) b.nsample += h;
+        for (int rep = 0; rep < 2; ++rep) {                  /* twice: lanes are reused */
+            void* ha = abea_f5c_align_submit(&core, &a);
+            void* hb = abea_f5c_align_submit(&core, &b);
+            abea_f5c_align_wait(&core, hb);
+            abea_f5c_align_wait(&core, ha);
+        }
     } else {
         abea_f5c_align(&core, &db);
         const int reps = getenv("SHIM_REPS") ? atoi(getenv("SHIM_REPS")) : 1;   /* more batches through the same context */

@@ -372,6 +372,9 @@ def test_cpp_caller_nsample_multi_device_and_fused(orc, r9, tmp_path):
     got = _run_shim(tmp_path, batch, model, k, {"SHIM_NSAMPLE0": "1,5", "SHIM_DEVS": "0,0"})
     for i in range(24):
         assert got[i] == ([] if i in (1, 5) else expect(i)), i
+    got = _run_shim(tmp_path, batch, model, k, {"SHIM_ASYNC": "1", "SHIM_NSAMPLE0": "3"})      # abea_f5c_align_submit / _wait
+    for i in range(24):
+        assert got[i] == ([] if i == 3 else expect(i)), i
     got = _run_shim(tmp_path, batch, model, k, {"SHIM_FUSED": "1"})
     for i in range(24):
         assert got[i] == expect(i), i
