@@ -191,12 +191,13 @@ void abea_align_kernel(const abea_read_desc* __restrict__ descs,
     /* pairs_all == nullptr: the pair lists are not materialised on the device (the host entry expands them from the
      * walk codes).  pair_cursor != nullptr: pair lists are packed back to back in completion order (atomic bump
      * allocation of n entries per read, offset reported in pair_off_out[]) instead of at desc.pair_off. */
-    /* 8 KiB: [0, 4096) phase 3 emission buffer; [4096, 6144) k-mer ring; [6144, 6656) event ring.  The rings sit above
-     * offset 252 because the fill loop reads them with ds_read_addtid_b32 (address = M0 + 4*lane, M0 >= 0) and the
-     * k-mer ring's reader is lane 63; their bases are 4 KiB / 1 KiB aligned for the s_bitset0 wrap. */
-    __shared__ __attribute__((aligned(4096))) uint4 smem[512];
-    abea_kpar_t* const k_ring = reinterpret_cast<abea_kpar_t*>(smem + 256);  /* 128 x 16 B */
-    float* const e_ring = reinterpret_cast<float*>(smem + 384);              /* 128 x 4 B  */
+    /* 4 KiB: [1024, 1536) event ring, [2048, 4096) k-mer ring; phase 3 reuses all of it as its emission buffer.  The
+     * rings sit above offset 252 because the fill loop reads them with ds_read_addtid_b32 (address = M0 + 4*lane, M0 >= 0)
+     * and the k-mer ring's reader is lane 63.  4 KiB per
+     * wavefront keeps LDS from capping the occupancy (160 KiB per CU). */
+    __shared__ __attribute__((aligned(4096))) uint4 smem[256];
+    abea_kpar_t* const k_ring = reinterpret_cast<abea_kpar_t*>(smem + 128);  /* 128 x 16 B */
+    float* const e_ring = reinterpret_cast<float*>(smem + 64);               /* 128 x 4 B  */
     float* const lp_s = reinterpret_cast<float*>(smem);                      /* 1024 x 4 B */
 
     const abea_read_desc* d = descs + blockIdx.x;
@@ -393,7 +394,7 @@ void abea_align_kernel(const abea_read_desc* __restrict__ descs,
              * scan = step(true)): the first ~100 bands until ll_k >= 0 and ll_e >= 99, and everything after the
              * band has touched the bottom/right edge of the matrix (never interior again: ll_e, ll_k only grow) */
             uint32_t toff = (uint32_t)lane * 16u + (uint32_t)(b >> 5) * 1024u;
-            uint32_t t0, t1, t2, t3, t4; uint64_t cm0a, cm0b, cm1a, cm1b, cv0, cv1;
+            uint32_t t0, t1, t2, t3, t4, cnt, per; uint64_t cm0a, cm0b, cm1a, cm1b, cv0, cv1;
             const uint32_t kring_a = (uint32_t)(uintptr_t)k_ring, ering_a = (uint32_t)(uintptr_t)e_ring;
             /* "s" operands must be provably wave-uniform */
             int s_ll_e = uni(ll_e), s_ll_k = uni(ll_k);
@@ -403,9 +404,11 @@ void abea_align_kernel(const abea_read_desc* __restrict__ descs,
             const int s_b_end = interior ? uni(b + run)
                               : past_edge ? uni(nb_pad)
                               : uni(min(nb_pad, b + max(max(-ll_k, 99 - ll_e), 256)));   /* chunk: re-check for the interior variant later */
-            uint32_t s_k_addr = (uint32_t)uni((int)(kring_a + ((uint32_t)k_next & 127u) * 16u));
-            uint32_t s_e_addr = (uint32_t)uni((int)(ering_a + ((uint32_t)e_next & 127u) * 4u));
-            if ((kring_a & 4095u) != 0u || (ering_a & 1023u) != 0u || kring_a < 252u) __builtin_trap();   /* ring wrap uses s_bitset0; M0 = k_addr - 252 */
+            /* ring addresses carry the entry's position in its 64-entry chunk in bits 31:26: the loop's add carries out when
+             * a new chunk is entered (refill + ring wrap), see gen_fill_asm.py */
+            uint32_t s_k_addr = (uint32_t)uni((int)((kring_a + ((uint32_t)k_next & 127u) * 16u) | (((uint32_t)k_next & 63u) << 26)));
+            uint32_t s_e_addr = (uint32_t)uni((int)((ering_a + ((uint32_t)e_next & 127u) * 4u) | (((uint32_t)e_next & 63u) << 26)));
+            if (kring_a < 252u || kring_a + 2048u > 65536u) __builtin_trap();                /* M0 = k_addr - 252, 16-bit LDS addresses */   /* ring wrap uses s_bitset0; M0 = k_addr - 252 */
             const int Km1 = K - 1, Em1 = E - 1;
             const uint64_t m50 = 1ull << ABEA_MOVE_LANE;
             uint32_t s_mvacc = (uint32_t)uni((int)mvacc), s_mvprev = (uint32_t)uni((int)mvprev);
@@ -432,7 +435,7 @@ void abea_align_kernel(const abea_read_desc* __restrict__ descs,
 #define ABEA_FILL_OUTS ABEA_FILL_VOUTS, \
                   [ll_e] "+s"(s_ll_e), [ll_k] "+s"(s_ll_k), [e_addr] "+s"(s_e_addr), [k_addr] "+s"(s_k_addr), \
                   [mvacc] "+s"(s_mvacc), [mvprev] "+s"(s_mvprev), [b] "+s"(s_b), \
-                  [t0] "=&s"(t0), [t1] "=&s"(t1), [cm0a] "=&s"(cm0a), [cm0b] "=&s"(cm0b), \
+                  [t0] "=&s"(t0), [t1] "=&s"(t1), [cnt] "=&s"(cnt), [per] "=&s"(per), [cm0a] "=&s"(cm0a), [cm0b] "=&s"(cm0b), \
                   [cm1a] "=&s"(cm1a), [cm1b] "=&s"(cm1b)
 #define ABEA_FILL_INS \
                   ABEA_FILL_VINS, [lp_step] "s"(u_step), [lp_stay] "s"(u_stay), [lp_skip] "s"(u_skip), \

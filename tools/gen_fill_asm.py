@@ -167,12 +167,23 @@ def interleave(a, b):
     return res
 
 
-def decide(p_next, m_last, rs):
+def countdown():
+    """%[per] = bands to the next tick = min(8 - (b & 7), b_end - b); %[cnt] = %[per] - 1.  Needs b < b_end."""
+    emit("s_and_b32 %[t1], %[b], 7")
+    emit("s_sub_u32 %[t1], 8, %[t1]")
+    emit("s_sub_u32 %[per], %[b_end], %[b]")
+    emit("s_min_u32 %[per], %[per], %[t1]")
+    emit("s_sub_u32 %[cnt], %[per], 1")
+
+
+def decide(p_next, m_last, rs, entry=False):
     """Tail of a band (or the entry stub): pick the move of the NEXT band and jump to its body.
     Expects: %[t0] = readlane(mf0, lane 0) already issued, vcc = (t0 < mf1) per lane already issued."""
     tag = f"{p_next}{m_last}"
-    emit("s_cmp_eq_u32 %[b], %[b_end]")
-    emit(f"s_cbranch_scc1 exit_{tag}{rs}_%=")
+    if entry:                                              # inside the loop the end-of-run test lives in the tick
+        emit("s_cmp_eq_u32 %[b], %[b_end]")
+        emit(f"s_cbranch_scc1 exit_{tag}{rs}_%=")
+        countdown()
     emit("s_bitcmp1_b32 vcc_hi, 17")                     # lane 49: ll < ur  -> right (align.c:313); -inf < finite too
     emit(f"s_cbranch_scc1 body_{tag}R{rs}_%=")
     emit("s_cmp_eq_u32 %[t0], 0xff800000")               # not (ll < ur): both may be -inf
@@ -188,7 +199,10 @@ def llinf_block(lbl, p_next, m_last, rs):
     emit(f"v_readlane_b32 %[t1], {v(MF1)}, 49")
     emit("s_cmp_eq_u32 %[t1], 0xff800000")
     emit(f"s_cbranch_scc0 body_{tag}R{rs}_%=")           # ll = -inf < finite ur
-    emit("s_bitcmp1_b32 %[b], 0")                         # both -inf: alternate, right on odd bands (align.c:311)
+    emit("s_sub_u32 %[t1], %[per], %[cnt]")              # index of the band about to be computed = b + (per - 1 - cnt)
+    emit("s_add_u32 %[t1], %[t1], %[b]")
+    emit("s_sub_u32 %[t1], %[t1], 1")
+    emit("s_bitcmp1_b32 %[t1], 0")                        # both -inf: alternate, right on odd bands (align.c:311)
     emit(f"s_cbranch_scc1 body_{tag}R{rs}_%=")
     emit(f"s_branch body_{tag}D{rs}_%=")
 
@@ -213,10 +227,11 @@ def body(p, ml, m, rs):
         for j in range(4):
             emit(f"v_mov_b32_dpp {v(inq + j)}, {v(c0q + j)} {DPP_SHL}")
         emit("s_lshl1_add_u32 %[mvacc], %[mvacc], 1")       # band-move bits, oldest band in the top bit
-        emit("s_add_u32 %[k_addr], %[k_addr], 16")          # LDS address of the next incoming k-mer (2 KiB ring at 0)
-        emit("s_bitset0_b32 %[k_addr], 11")
-        emit("s_and_b32 %[t0], %[k_addr], 1023")            # entering a new 64-entry chunk?
-        emit(f"s_cbranch_scc0 krefill_{tag}_%=")
+        # k_addr = LDS address of the next incoming k-mer (bits 15:0) | its position in the 64-entry chunk (bits 31:26):
+        # the add carries out exactly when a new chunk is entered, and the ring wrap is done there too — two scalar
+        # instructions per move instead of four (every instruction of the loop costs one issue slot, SALU included)
+        emit("s_add_u32 %[k_addr], %[k_addr], 0x04000010")
+        emit(f"s_cbranch_scc1 krefill_{tag}_%=")
         emit(f"kcont_{tag}_%=:")
         # the next incoming k-mer lands in the old cell-0 quad (dead now); only LANE 63 of it matters (the DPP `old` lane of
         # the next right move), so it is read with ds_read_addtid_b32 (LDS address = M0 + offset + 4*lane, no address VGPR,
@@ -236,10 +251,8 @@ def body(p, ml, m, rs):
         emit(f"v_mov_b32 {v(X1)}, {v(X0)}")
         emit("s_lshl_b32 %[mvacc], %[mvacc], 1")
         emit(f"v_mov_b32 {v(X0)}, {v(NX)}")
-        emit("s_add_u32 %[e_addr], %[e_addr], 4")           # LDS address of the next incoming event (512 B ring at 2048)
-        emit("s_bitset0_b32 %[e_addr], 9")
-        emit("s_and_b32 %[t0], %[e_addr], 255")
-        emit(f"s_cbranch_scc0 erefill_{tag}_%=")
+        emit("s_add_u32 %[e_addr], %[e_addr], 0x04000004")  # LDS address of the next incoming event | position in chunk << 26
+        emit(f"s_cbranch_scc1 erefill_{tag}_%=")
         emit(f"econt_{tag}_%=:")
         emit("s_mov_b32 m0, %[e_addr]")                     # lane 0 (the DPP `old` lane of the next down move) reads ring[e_addr]
         emit(f"v_cvt_f64_f32 {vp(T['c0'])}, {v(MF0)}")
@@ -335,7 +348,6 @@ def body(p, ml, m, rs):
         # trace nibble f0 | f1 << 2, stored inverted: the accumulator is complemented when its dword completes
         emit(f"v_lshl_or_b32 {v(F[0])}, {v(F[1])}, 2, {v(F[0])}")
         emit(f"v_xor_b32 {v(F[0])}, 15, {v(F[0])}")
-        emit("s_add_u32 %[b], %[b], 1")
         emit(f"v_lshl_or_b32 {v(ACC)}, {v(ACC)}, 4, {v(F[0])}")
     else:
         # trace bits, oldest first: cell 1 [sl<max], cell 1 [su<sd], cell 0 [sl<max], cell 0 [su<sd]; each v_alignbit
@@ -347,14 +359,18 @@ def body(p, ml, m, rs):
         emit(f"v_alignbit_b32 {v(ACC)}, {v(ACC)}, {v(TD[0])}, 31")
         emit(f"v_alignbit_b32 {v(ACC)}, {v(ACC)}, {v(F[0])}, 31")
         emit(f"v_cmp_lt_f32 vcc, %[t0], {v(MF1)}")          # t0 written 3 instructions ago
-        emit("s_add_u32 %[b], %[b], 1")
-    emit("s_and_b32 %[t1], %[b], 7")
-    emit(f"s_cbranch_scc0 rot_{tag}_%=")                 # band b-1 completed a dword: every 8th band, out of line
+    # %[cnt] counts the bands to the next "tick" (a trace dword completes every 8th band; the run ends at b_end): the
+    # band index itself is only brought up to date there
+    emit("s_sub_u32 %[cnt], %[cnt], 1")
+    emit(f"s_cbranch_scc1 rot_{tag}_%=")                 # borrow: this was the last band before the tick
     emit(f"rotret_{tag}_%=:")
     lbl = decide(p ^ 1, m, rs)
     llinf_block(lbl, p ^ 1, m, rs)
-    # ---- out-of-line: dword rotation / group store
+    # ---- out-of-line tick: band index, dword rotation / group store, end of run, next countdown
     emit(f"rot_{tag}_%=:")
+    emit("s_add_u32 %[b], %[b], %[per]")
+    emit("s_and_b32 %[t1], %[b], 7")
+    emit(f"s_cbranch_scc1 norot_{tag}_%=")               # not on a dword boundary: the run ends here
     emit("s_and_b32 %[t1], %[b], 31")
     emit(f"s_cbranch_scc1 nostore_{tag}_%=")             # group complete only when the new b is a multiple of 32
     emit(f"v_mov_b32 {v(Q)}, %[mvacc]")
@@ -374,6 +390,10 @@ def body(p, ml, m, rs):
     emit(f"v_mov_b32 {v(A0)}, {v(A1)}")
     emit(f"v_mov_b32 {v(A1)}, {v(A2)}")
     emit(f"v_not_b32 {v(A2)}, {v(ACC)}")                   # the accumulator collects complemented bits
+    emit(f"norot_{tag}_%=:")
+    emit("s_cmp_eq_u32 %[b], %[b_end]")
+    emit(f"s_cbranch_scc1 exit_{p ^ 1}{m}{rs}_%=")
+    countdown()
     emit(f"s_branch rotret_{tag}_%=")
     # ---- out-of-line: ring refills
     if m == 'R':
@@ -381,6 +401,9 @@ def body(p, ml, m, rs):
         emit("s_waitcnt vmcnt(0)")
         emit("s_add_u32 %[t0], %[ll_k], 128")               # k_next = ll_k + 128 (k-mer entering at offset 127)
         emit("s_lshr_b32 %[t0], %[t0], 6")
+        emit("s_and_b32 %[t1], %[t0], 1")                   # the chunk being entered: its half of the ring (this is the wrap)
+        emit("s_lshl_b32 %[t1], %[t1], 10")
+        emit("s_add_u32 %[k_addr], %[t1], %[kring]")
         emit("s_add_u32 %[t1], %[t0], 1")
         emit("s_and_b32 %[t1], %[t1], 1")
         emit("s_lshl_b32 %[t1], %[t1], 10")
@@ -402,6 +425,9 @@ def body(p, ml, m, rs):
         emit("s_waitcnt vmcnt(0)")
         emit("s_add_u32 %[t0], %[ll_e], 1")                 # e_next = ll_e + 1 (event entering at offset 0)
         emit("s_lshr_b32 %[t0], %[t0], 6")
+        emit("s_and_b32 %[t1], %[t0], 1")
+        emit("s_lshl_b32 %[t1], %[t1], 8")
+        emit("s_add_u32 %[e_addr], %[t1], %[ering]")
         emit("s_add_u32 %[t1], %[t0], 1")
         emit("s_and_b32 %[t1], %[t1], 1")
         emit("s_lshl_b32 %[t1], %[t1], 8")
@@ -459,7 +485,7 @@ def variant_code(border):
     emit(f"v_readlane_b32 %[t0], {v(MF0)}, 0")
     emit("s_nop 1")
     emit(f"v_cmp_lt_f32 vcc, %[t0], {v(MF1)}")
-    lbl = decide(0, 'R', 0)
+    lbl = decide(0, 'R', 0, entry=True)
     llinf_block(lbl, 0, 'R', 0)
     for rs in (0, 1, 2):
         for p in (0, 1):
