@@ -285,11 +285,24 @@ extern "C" int abea_align_batch_device(abea_ctx* c, const abea_device_batch* B) 
     while (pos < seq.size()) {
         /* ---- carve a sub-batch that fits the arena ---- */
         size_t end = pos, bytes = 4096;
+        size_t mr_done = 0; int32_t mr_in = 0, mr_kmax = 0;   /* 'M' records: 64 consecutive reads interleaved, padded to the longest */
         while (end < seq.size()) {
             const plan_read& r = reads[(size_t)seq[end]];
-            size_t need = r.run ? scratch_bytes(r) + (B->base_to_event_map ? (size_t)r.K * sizeof(abea_mrec) + 4 : 0) : sizeof(abea_read_desc) + 4;
-            if (bytes + need + 65536 > c->arena_bytes) break;
+            size_t need = (r.run ? scratch_bytes(r) : sizeof(abea_read_desc)) + 4;
+            size_t mr = 0;
+            if (B->base_to_event_map) {
+                const int32_t k = std::max(r.run ? r.K : 0, 1);
+                mr = (mr_in == 64 || mr_in == 0) ? mr_done + (mr_in == 64 ? (size_t)mr_kmax * 64 : 0) + (size_t)k * 64
+                                                 : mr_done + (size_t)std::max(mr_kmax, k) * 64;
+                mr = mr * sizeof(abea_mrec) + 256;
+            }
+            if (bytes + need + mr + 65536 > c->arena_bytes) break;
             bytes += need; ++end;
+            if (B->base_to_event_map) {
+                const int32_t k = std::max(r.run ? r.K : 0, 1);
+                if (mr_in == 64) { mr_done += (size_t)mr_kmax * 64; mr_in = 0; mr_kmax = 0; }
+                mr_kmax = std::max(mr_kmax, k); ++mr_in;
+            }
         }
         if (end == pos)
             return abea_fail(ABEA_ENOMEM, "read %d (L=%d, E=%d) needs more scratch than the %zu-byte arena",
@@ -307,9 +320,14 @@ extern "C" int abea_align_batch_device(abea_ctx* c, const abea_device_batch* B) 
             plan_desc(d, r, B->scalings[r.idx], lay, st);
             d.read_off = B->read_ptr[r.idx]; d.event_off = B->event_ptr[r.idx]; d.pair_off = B->pair_ptr[r.idx];
             d.kmer_off = B->kmer_ptr ? B->kmer_ptr[r.idx] : 0;
-            d.pad64 = (int64_t)n_mrec;
-            if (r.run && B->base_to_event_map) n_mrec += (size_t)r.K;
         }
+        if (B->base_to_event_map)                            /* 'M'-state records: 64 consecutive descriptors interleaved */
+            for (size_t j0 = 0; j0 < m; j0 += 64) {
+                int32_t kmax = 1;
+                for (size_t j = j0; j < std::min(m, j0 + 64); ++j) kmax = std::max(kmax, c->h_desc[j].n_groups ? c->h_desc[j].n_kmers : 1);
+                for (size_t j = j0; j < std::min(m, j0 + 64); ++j) c->h_desc[j].pad64 = (int64_t)(n_mrec + (j - j0));
+                n_mrec += (size_t)kmax * 64;
+            }
         const size_t n_kpar = lay.n_kpar, n_evm = lay.n_evm, n_code = lay.n_code, n_trace = lay.n_trace;
         uint8_t* p = c->arena;
         abea_read_desc* d_desc = (abea_read_desc*)p;        p += align_up(m * sizeof(abea_read_desc), 256);

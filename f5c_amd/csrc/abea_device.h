@@ -35,7 +35,10 @@ typedef struct __attribute__((aligned(16))) {
     double  lp_skip, lp_stay, lp_step, lp_trim;   /* align.c:212-216 */
 } abea_read_desc;
 
-/* one 'M' state of recalibrate_model (align.c:688-753): what its sums read, in k order */
-struct __attribute__((aligned(16))) abea_mrec { float sd; float mu; float e; float pad; };
+/* one 'M' state of recalibrate_model (align.c:688-753): what its sums read, in k order.  Records of the 64 reads that
+ * share a wavefront of abea_recalib_kernel are INTERLEAVED: record m of the read in lane l sits at index
+ * desc.pad64 + 64 * m (desc.pad64 = 64 * wave base + l), so the lane-per-read kernel's loads are coalesced. */
+struct __attribute__((aligned(16))) abea_mrec { double inv_var; float mu; float e; float sd; float pad0; float pad1; float pad2; };
+#define ABEA_MREC_STRIDE 64
 
 #endif

@@ -268,9 +268,14 @@ static std::vector<host_thread_plan> context_thread_plan(abea_ctx* c) {
     if (c->children.empty()) nodes.push_back(c->numa_node);
     else for (abea_ctx* ch : c->children) nodes.push_back(ch->numa_node);
     const char* e = getenv("ABEA_HOST_THREADS");
+    /* Binding is OPT-IN at run time (ABEA_HOST_NUMA=1).  Measured on the MI355X box (2 sockets, bench.py, 100 k reads): with
+     * the workers of the one device bound to its node, flatten went from 217 to 602 ms per step — the loop READS 24 B per
+     * event from the caller's tables, which live wherever the caller's threads first touched them (both nodes), and only
+     * WRITES 4 B per event to the local pinned staging; binding trades the small local write for remote reads through one
+     * socket.  It pays only when the caller places each device's share of the batch on that device's node. */
     const char* nu = getenv("ABEA_HOST_NUMA");
     return plan_host_threads(effective_cpus(), allowed_cpus(), (int)nodes.size(), nodes.data(), numa_node_cpus(),
-                             e ? std::max(1, atoi(e)) : 0, !(nu && nu[0] == '0'));
+                             e ? std::max(1, atoi(e)) : 0, nu && nu[0] == '1');
 }
 
 int abea_default_host_threads() {
@@ -383,25 +388,40 @@ static void expand_codes(const uint32_t* codes, int32_t n, int32_t k, int32_t e,
  * Every k-mer from the first pair's to the last pair's has a run (a step changes the k-mer by at most one); k-mers below
  * the first pair's stay {-1,-1} (none for a list that passed QC: it spans k-mer 0, align.c:529). */
 static void expand_codes_to_map(const uint32_t* codes, int32_t n, int32_t k, int32_t e, abea_index_pair_t* map) {
-    int32_t start = -1, stop = -1;
+    /* One iteration per K-MER, not per step (a first version walked the steps with two data-dependent branches each and
+     * took 740 ms per 100 k reads against 110 ms for the pair expansion).  In walk order a k-mer's pairs are (k, e_hi),
+     * (k, e_hi - 1), ..., (k, e_lo), joined by "up" steps (code 1) and left by a diagonal (0) or a "left" (2) step.  All but
+     * the last are new events; the last is new iff it is left diagonally (or is pair 0).  So
+     *   left diagonally:  {e_lo, e_hi}      left by a skip:  {e_lo + 1, e_hi} if the run has an up step, else {-1, -1}
+     * and the next k-mer starts at e_lo - 1 (diagonal) or e_lo (skip).  Runs of code 1 are counted with tzcnt over a mask
+     * of the non-1 codes, 32 codes per 64-bit word. */
     long long* m64 = reinterpret_cast<long long*>(map);
-    for (int32_t j = 0; j < n; j += 16) {
-        uint32_t w = codes[j >> 4];
-        const int32_t lim = std::min(16, n - j);
-        for (int32_t t = 0; t < lim; ++t) {
-            const uint32_t cd = w & 3u;
-            w >>= 2;
-            const bool last = (j + t == n - 1);
-            if (last || cd != 2u) { if (stop == -1) stop = e; start = e; }
-            const int32_t dk = last ? 1 : (int32_t)(cd != 1u);
-            if (dk) {                                      /* leaving k-mer k: its entry is final (written once, never read back here) */
-                _mm_stream_si64(m64 + k, (long long)(((uint64_t)(uint32_t)stop << 32) | (uint32_t)start));
-                start = stop = -1;
-            }
-            k -= dk; e -= (cd != 2u);
+    const uint64_t ONES = 0x5555555555555555ull;
+    int32_t nu = 0;                                          /* up steps of the current k-mer so far */
+    for (int32_t j0 = 0; j0 < n; j0 += 32) {
+        const int32_t cnt = std::min(32, n - j0);
+        uint64_t w = (uint64_t)codes[j0 >> 4];
+        if (cnt > 16) w |= (uint64_t)codes[(j0 >> 4) + 1] << 32;
+        if (j0 + cnt == n) w &= ~(3ull << (2 * (cnt - 1)));  /* the last step's code is never applied: pair 0 is new, like a diagonal leave */
+        const uint64_t x = w ^ ONES;
+        uint64_t non_up = (x | (x >> 1)) & ONES;             /* bit 2t: code t is not "up" */
+        if (cnt < 32) non_up &= (1ull << (2 * cnt)) - 1;
+        int32_t pos = 0;
+        while (non_up) {
+            const int32_t t = (int32_t)(__builtin_ctzll(non_up) >> 1);
+            nu += t - pos;
+            const uint32_t skip = (uint32_t)(w >> (2 * t + 1)) & 1u;      /* code 2 = left by a skip, 0 = diagonally */
+            const int32_t e_lo = e - nu;
+            const int32_t start = skip ? (nu ? e_lo + 1 : -1) : e_lo;
+            const int32_t stop = (skip && !nu) ? -1 : e;
+            _mm_stream_si64(m64 + k, (long long)(((uint64_t)(uint32_t)stop << 32) | (uint32_t)start));
+            --k; e = e_lo - (int32_t)(skip ^ 1u);
+            nu = 0; pos = t + 1;
+            non_up &= non_up - 1;
         }
+        nu += cnt - pos;                                     /* trailing up steps run on into the next word */
     }
-    for (; k >= 0; --k) _mm_stream_si64(m64 + k, -1ll);     /* {-1, -1} */
+    for (; k >= 0; --k) _mm_stream_si64(m64 + k, -1ll);     /* k-mers below the first pair's: {-1, -1} */
     _mm_sfence();
 }
 
@@ -447,7 +467,8 @@ struct chunk_span { size_t begin, end; size_t events; bool whole_arena; };
 static size_t chunk_io_bytes(const plan_read& r, bool pairs_on_device, bool scaling) {
     size_t b = align_up((size_t)r.L + 1, 16) + 4 + sizeof(abea_read_diag) + 8;
     if (pairs_on_device) b += ((size_t)r.E + (size_t)r.L) * sizeof(abea_pair_t);
-    if (scaling) b += (size_t)r.K * (sizeof(abea_index_pair_t) + 16) + sizeof(abea_scalings_t) + 8 + 4 + 4 + 4;   /* map + 'M' records (device scratch) */
+    /* map (device scratch) + per-read scalars; the 'M' records are charged per 64-read wave by mrec_wave_bytes() */
+    if (scaling) b += (size_t)r.K * sizeof(abea_index_pair_t) + sizeof(abea_scalings_t) + 8 + 4 + 4 + 4;
     return b + 64;
 }
 
@@ -455,6 +476,23 @@ static size_t chunk_io_bytes(const plan_read& r, bool pairs_on_device, bool scal
  * chunk_reads_min reads AND chunk_events events (the first two chunks a quarter / half of that, so the GPU starts
  * early), at chunk_reads_max reads, or when the next read would not fit the slot's share of the arena; a read that
  * does not fit a share on its own gets the whole arena, alone. */
+/* 'M'-state records of the scaling kernels: the reads of a chunk are taken 64 at a time (one abea_recalib_kernel
+ * wavefront) and each group's records are interleaved, padded to the group's longest read.  Running cost of a chunk while
+ * reads are appended: */
+struct mrec_meter {
+    size_t done = 0; int32_t in_wave = 0, kmax = 0;
+    size_t with(int32_t K) const {                       /* bytes if a read of K k-mers were appended */
+        const int32_t k = std::max(K, 1);
+        if (in_wave == 64 || in_wave == 0) return done + (in_wave == 64 ? (size_t)kmax * 64 * sizeof(abea_mrec) : 0) + (size_t)k * 64 * sizeof(abea_mrec);
+        return done + (size_t)std::max(kmax, k) * 64 * sizeof(abea_mrec);
+    }
+    void add(int32_t K) {
+        const int32_t k = std::max(K, 1);
+        if (in_wave == 64) { done += (size_t)kmax * 64 * sizeof(abea_mrec); in_wave = 0; kmax = 0; }
+        kmax = std::max(kmax, k); ++in_wave;
+    }
+};
+
 static std::vector<chunk_span> carve_chunks(const std::vector<plan_read>& reads, const std::vector<int32_t>& order,
                                             const host_opts& opt, size_t slot_arena, bool pairs_on_device, bool scaling) {
     std::vector<chunk_span> out;
@@ -465,14 +503,16 @@ static std::vector<chunk_span> carve_chunks(const std::vector<plan_read>& reads,
         const int32_t want_reads = std::max(1, opt.chunk_reads_min / ramp);
         size_t bytes = 65536, ev = 0, end = pos;
         bool whole_arena = false;
+        mrec_meter mm;
         while (end < order.size()) {
             const plan_read& r = reads[(size_t)order[end]];
             const size_t need = scratch_bytes(r) + chunk_io_bytes(r, pairs_on_device, scaling);
-            if (bytes + need > slot_arena) {
+            if (bytes + need + (scaling ? mm.with(r.K) + 256 : 0) > slot_arena) {
                 if (end > pos) break;
                 whole_arena = true;                      /* an over-long read: give it the whole arena, alone */
             }
             bytes += need; ev += (size_t)r.E; ++end;
+            if (scaling) mm.add(r.K);
             const int32_t cnt = (int32_t)(end - pos);
             if (whole_arena || (cnt >= want_reads && ev >= want_ev) || cnt >= opt.chunk_reads_max) break;
         }
@@ -714,7 +754,7 @@ static int host_run(abea_ctx* c, const abea_host_batch* H, const int32_t* mine, 
     /* check every read against the arena before anything is launched */
     for (int32_t q : order) {
         const plan_read& r = S.reads[(size_t)q];
-        if (scratch_bytes(r) + io_bytes(r) + 65536 > lane.arena_bytes)
+        if (scratch_bytes(r) + io_bytes(r) + (scaling ? (size_t)r.K * 64 * sizeof(abea_mrec) : 0) + 65536 > lane.arena_bytes)
             return abea_fail(ABEA_ENOMEM, "read %d (L=%d, E=%d) needs more scratch than the %zu-byte arena", r.idx, r.L, r.E,
                              lane.arena_bytes);
     }
@@ -766,10 +806,19 @@ static int host_run(abea_ctx* c, const abea_host_batch* H, const int32_t* mine, 
                 plan_desc(descs[j], r, H->scalings[caller], lay, S.st);
                 descs[j].read_off = (int64_t)ro; ro += align_up((size_t)r.L + 1, 16);
                 descs[j].pair_off = (int64_t)po; po += (size_t)r.E + (size_t)r.L;
-                descs[j].kmer_off = (int64_t)ko; descs[j].pad64 = (int64_t)ko;      /* map entries and 'M' records: at most one per k-mer */
+                descs[j].kmer_off = (int64_t)ko;
                 ko += (size_t)r.K;
             }
         }
+        /* 'M'-state records of the scaling kernels: the 64 reads of one abea_recalib_kernel wavefront interleaved */
+        size_t n_mrec = 0;
+        if (scaling)
+            for (int32_t j0 = 0; j0 < m; j0 += 64) {
+                int32_t kmax = 1;
+                for (int32_t j = j0; j < std::min(m, j0 + 64); ++j) kmax = std::max(kmax, descs[j].n_kmers);
+                for (int32_t j = j0; j < std::min(m, j0 + 64); ++j) descs[j].pad64 = (int64_t)(n_mrec + (size_t)(j - j0));
+                n_mrec += (size_t)kmax * 64;
+            }
         /* `dn` = [npairs][diag][codes | poff, cursor][scaling outputs] mirrors the arena block behind the scratch */
         size_t o = 0;
         sl.o_np = o;      o = align_up(o + (size_t)m * 4, 256);
@@ -798,7 +847,7 @@ static int host_run(abea_ctx* c, const abea_host_batch* H, const int32_t* mine, 
         abea_index_pair_t* d_b2e = nullptr; abea_mrec* d_mrec = nullptr; int32_t* d_nm = nullptr;
         if (scaling) {                                      /* device-only scratch of the two scaling kernels */
             d_b2e = (abea_index_pair_t*)p;  p += align_up(n_kmer * sizeof(abea_index_pair_t), 256);
-            d_mrec = (abea_mrec*)p;         p += align_up(n_kmer * sizeof(abea_mrec), 256);
+            d_mrec = (abea_mrec*)p;         p += align_up(n_mrec * sizeof(abea_mrec), 256);
             d_nm = (int32_t*)p;             p += align_up((size_t)m * 4, 256);
         }
         if ((size_t)(p - arena) > (whole_arena ? lane.arena_bytes : slot_arena))

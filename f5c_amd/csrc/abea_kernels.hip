@@ -673,7 +673,7 @@ void abea_scaling_kernel(const abea_read_desc* __restrict__ descs, const char* _
     abea_index_pair_t* map = b2e_all + d->kmer_off;
     const float* __restrict__ evm = evm_all + d->evm_off;
     const char* __restrict__ seq = reads + d->read_off;
-    abea_mrec* __restrict__ mrec = mrec_all + d->pad64;   /* pad64 = record offset of this read (at most K records) */
+    abea_mrec* __restrict__ mrec = mrec_all + d->pad64;   /* record m of this read at mrec[64 * m] (interleaved, abea_device.h) */
 
     /* ---- base_to_event_map (align.c:571-596) ---- */
     for (int i = lane; i < n; i += 64) {
@@ -711,8 +711,10 @@ void abea_scaling_kernel(const abea_read_desc* __restrict__ descs, const char* _
         if (isM) {
             const abea_model_t mo = model[rank];
             abea_mrec r;
-            r.sd = mo.level_stdv; r.mu = mo.level_mean; r.e = evm[m.start]; r.pad = 0.f;
-            mrec[n_M + __popcll(mm & ((1ull << lane) - 1ull))] = r;     /* compacted: record m = the m-th 'M' state */
+            const double sd = mo.level_stdv;
+            r.inv_var = 1. / (sd * sd);                      /* align.c:697: the division is done here, in parallel */
+            r.mu = mo.level_mean; r.e = evm[m.start]; r.sd = mo.level_stdv; r.pad0 = r.pad1 = r.pad2 = 0.f;
+            mrec[(size_t)(n_M + __popcll(mm & ((1ull << lane) - 1ull))) * ABEA_MREC_STRIDE] = r;   /* compacted: record m = the m-th 'M' state */
         }
         n_M += __popcll(mm);
         n_align += valid ? (m.stop - m.start + 1) : 0;
@@ -738,44 +740,34 @@ void abea_recalib_kernel(const abea_read_desc* __restrict__ descs, int n_desc, c
     const int n_M = n_m_in[j];
     if (n_M < 0) return;                                 /* not aligned: flagged by abea_scaling_kernel */
     const int out_idx = d->out_idx;
-    const float4* __restrict__ mrec = reinterpret_cast<const float4*>(mrec_all + d->pad64);
+    const abea_mrec* __restrict__ mrec = mrec_all + d->pad64;
     bool calibrated = false;
     double shift = 0, scale = 0, var = 0;
     if (n_M >= min_rescale) {
+        /* the loads of record m + 1 are issued before record m is consumed: the chain is the five adds, not the memory */
         double A00 = 0, A01 = 0, A11 = 0, b0 = 0, b1 = 0;
-        for (int m0 = 0; m0 < n_M; m0 += 4) {            /* a lane streams its own 64 bytes at a time */
-            float4 r[4];
-            #pragma unroll
-            for (int q = 0; q < 4; ++q) r[q] = mrec[min(m0 + q, n_M - 1)];
-            #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                if (m0 + q < n_M) {
-                    const double sd = r[q].x, mu = r[q].y, e = r[q].z;
-                    const double inv_var = 1. / (sd * sd);   /* align.c:697-706, in this order */
-                    A00 += inv_var;
-                    A01 += mu * inv_var;
-                    A11 += mu * mu * inv_var;
-                    b0 += e * inv_var;
-                    b1 += mu * e * inv_var;
-                }
-            }
+        abea_mrec nx = mrec[0];
+        for (int m = 0; m < n_M; ++m) {
+            const abea_mrec r = nx;
+            nx = mrec[(size_t)min(m + 1, n_M - 1) * ABEA_MREC_STRIDE];
+            const double inv_var = r.inv_var, mu = r.mu, e = r.e;   /* align.c:697-706, in this order */
+            A00 += inv_var;
+            A01 += mu * inv_var;
+            A11 += mu * mu * inv_var;
+            b0 += e * inv_var;
+            b1 += mu * e * inv_var;
         }
         const double A10 = A01;
         const double div = A00 * A11 - A01 * A10;
         shift = -(A01 * b1 - A11 * b0) / div;
         scale = (A00 * b1 - A10 * b0) / div;
-        for (int m0 = 0; m0 < n_M; m0 += 4) {            /* align.c:738-753 */
-            float4 r[4];
-            #pragma unroll
-            for (int q = 0; q < 4; ++q) r[q] = mrec[min(m0 + q, n_M - 1)];
-            #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                if (m0 + q < n_M) {
-                    const double sd = r[q].x, mu = r[q].y, e = r[q].z;
-                    const double yi = (e - shift - scale * mu);
-                    var += yi * yi / (sd * sd);
-                }
-            }
+        nx = mrec[0];
+        for (int m = 0; m < n_M; ++m) {                  /* align.c:738-753 */
+            const abea_mrec r = nx;
+            nx = mrec[(size_t)min(m + 1, n_M - 1) * ABEA_MREC_STRIDE];
+            const double sd = r.sd, mu = r.mu, e = r.e;
+            const double yi = (e - shift - scale * mu);
+            var += yi * yi / (sd * sd);
         }
         var /= n_M;
         var = sqrt(var);

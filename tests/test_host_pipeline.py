@@ -129,6 +129,34 @@ def test_walk_code_expansion_matches_the_traceback(orc, r9):
     assert out.tolist() == [[0, 0], [-1, -1], [1, 2], [3, 3], [-1, -1], [4, 5]]
     assert lib.abea_expand_walk_codes_to_map(None, 3, 2, 2, out.ctypes.data) != 0
 
+    def postalign_map(p):                                     # align.c:571-596 on an ascending pair list
+        K = int(p[-1, 0]) + 1
+        m = np.full((K, 2), -1, dtype=np.int32)
+        prev = -1
+        for kk, ee in p:
+            if ee != prev:
+                if m[kk, 0] == -1:
+                    m[kk, 0] = ee
+                m[kk, 1] = ee
+            prev = ee
+        return m
+
+    rr = np.random.default_rng(77)
+    for n in list(range(1, 40)) + [63, 64, 65, 95, 96, 97, 1000, 3001]:      # 32-code word boundaries of the per-k-mer scan
+        for pw in ((0.6, 0.3, 0.1), (0.2, 0.1, 0.7), (0.1, 0.85, 0.05)):       # mostly diagonal / skips / long stays
+            steps = rr.choice(3, size=n - 1, p=pw)
+            p = np.zeros((n, 2), dtype=np.int64)
+            for j, c in enumerate(steps):
+                p[j + 1] = p[j] + [(1, 1), (0, 1), (1, 0)][c]
+            code = np.concatenate([steps[::-1], [int(rr.integers(0, 4))]])     # the last code is never applied
+            words = np.zeros((n + 15) // 16 + 2, dtype=np.uint32)
+            for j, c in enumerate(code):
+                words[j >> 4] |= np.uint32(int(c) << (2 * (j & 15)))
+            K = int(p[-1, 0]) + 1
+            out = np.full((K + 1, 2), -7, dtype=np.int32)
+            assert lib.abea_expand_walk_codes_to_map(words.ctypes.data, n, K - 1, int(p[-1, 1]), out.ctypes.data) == 0
+            assert (out[:K] == postalign_map(p)).all() and (out[K] == -7).all(), (n, pw)
+
     for n in (1, 2, 15, 16, 17, 31, 32, 33, 1024, 1025):       # word boundaries
         steps = np.random.default_rng(n).integers(0, 3, n - 1)
         p = np.zeros((n, 2), dtype=np.int32)

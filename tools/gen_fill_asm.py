@@ -168,12 +168,15 @@ def interleave(a, b):
 
 
 def countdown():
-    """%[per] = bands to the next tick = min(8 - (b & 7), b_end - b); %[cnt] = %[per] - 1.  Needs b < b_end."""
+    """%[per] = bands to the next tick = min(8 - (b & 7), b_end - b); %[cnt] = 1 << (32 - per): a sentinel bit that the
+    per-band `s_lshl1_add_u32 cnt, cnt, move` pushes out (carry -> SCC) at the per-th band, with the moves of the bands
+    since the tick collecting below it (1 = right).  One instruction per band counts AND records the move.  Needs b < b_end."""
     emit("s_and_b32 %[t1], %[b], 7")
     emit("s_sub_u32 %[t1], 8, %[t1]")
     emit("s_sub_u32 %[per], %[b_end], %[b]")
     emit("s_min_u32 %[per], %[per], %[t1]")
-    emit("s_sub_u32 %[cnt], %[per], 1")
+    emit("s_sub_u32 %[t1], 32, %[per]")
+    emit("s_lshl_b32 %[cnt], 1, %[t1]")
 
 
 def decide(p_next, m_last, rs, entry=False):
@@ -199,9 +202,10 @@ def llinf_block(lbl, p_next, m_last, rs):
     emit(f"v_readlane_b32 %[t1], {v(MF1)}, 49")
     emit("s_cmp_eq_u32 %[t1], 0xff800000")
     emit(f"s_cbranch_scc0 body_{tag}R{rs}_%=")           # ll = -inf < finite ur
-    emit("s_sub_u32 %[t1], %[per], %[cnt]")              # index of the band about to be computed = b + (per - 1 - cnt)
+    emit("s_flbit_i32_b32 %[t1], %[cnt]")                 # leading zeros of the sentinel = per - 1 - bands done since the tick
+    emit("s_sub_u32 %[t1], %[per], %[t1]")
     emit("s_add_u32 %[t1], %[t1], %[b]")
-    emit("s_sub_u32 %[t1], %[t1], 1")
+    emit("s_sub_u32 %[t1], %[t1], 1")                     # index of the band about to be computed
     emit("s_bitcmp1_b32 %[t1], 0")                        # both -inf: alternate, right on odd bands (align.c:311)
     emit(f"s_cbranch_scc1 body_{tag}R{rs}_%=")
     emit(f"s_branch body_{tag}D{rs}_%=")
@@ -226,7 +230,6 @@ def body(p, ml, m, rs):
         # whose lane 63 keeps the pre-read incoming k-mer (DPP `old`); cell 1's quad becomes cell 0's by renaming
         for j in range(4):
             emit(f"v_mov_b32_dpp {v(inq + j)}, {v(c0q + j)} {DPP_SHL}")
-        emit("s_lshl1_add_u32 %[mvacc], %[mvacc], 1")       # band-move bits, oldest band in the top bit
         # k_addr = LDS address of the next incoming k-mer (bits 15:0) | its position in the 64-entry chunk (bits 31:26):
         # the add carries out exactly when a new chunk is entered, and the ring wrap is done there too — two scalar
         # instructions per move instead of four (every instruction of the loop costs one issue slot, SALU included)
@@ -244,12 +247,12 @@ def body(p, ml, m, rs):
         U = (T['c1'], T['cs']); L = (T['c0'], T['c1'])
         D = (Tp['c1'], Tp['cs']) if ml == 'R' else (Tp['c0'], Tp['c1'])
     else:
-        emit("s_add_u32 %[ll_e], %[ll_e], 1")
+        if BORDER:                                          # the border masks need ll_e every band; the interior loop brings
+            emit("s_add_u32 %[ll_e], %[ll_e], 1")           # it up to date at the tick (popcount of the recorded moves)
         emit(f"v_mov_b32_dpp {v(SHD)}, {v(MF1)} {DPP_SHR}")
         emit("s_waitcnt lgkmcnt(4)" if ml == 'R' else "s_waitcnt lgkmcnt(0)")     # incoming event landed (a right move's four k-mer reads may still be out)
         emit(f"v_mov_b32_dpp {v(NX)}, {v(X1)} {DPP_SHR}")
         emit(f"v_mov_b32 {v(X1)}, {v(X0)}")
-        emit("s_lshl_b32 %[mvacc], %[mvacc], 1")
         emit(f"v_mov_b32 {v(X0)}, {v(NX)}")
         emit("s_add_u32 %[e_addr], %[e_addr], 0x04000004")  # LDS address of the next incoming event | position in chunk << 26
         emit(f"s_cbranch_scc1 erefill_{tag}_%=")
@@ -361,13 +364,19 @@ def body(p, ml, m, rs):
         emit(f"v_cmp_lt_f32 vcc, %[t0], {v(MF1)}")          # t0 written 3 instructions ago
     # %[cnt] counts the bands to the next "tick" (a trace dword completes every 8th band; the run ends at b_end): the
     # band index itself is only brought up to date there
-    emit("s_sub_u32 %[cnt], %[cnt], 1")
-    emit(f"s_cbranch_scc1 rot_{tag}_%=")                 # borrow: this was the last band before the tick
+    emit(f"s_lshl1_add_u32 %[cnt], %[cnt], {1 if m == 'R' else 0}")
+    emit(f"s_cbranch_scc1 rot_{tag}_%=")                 # the sentinel fell out: this was the last band before the tick
     emit(f"rotret_{tag}_%=:")
     lbl = decide(p ^ 1, m, rs)
     llinf_block(lbl, p ^ 1, m, rs)
     # ---- out-of-line tick: band index, dword rotation / group store, end of run, next countdown
     emit(f"rot_{tag}_%=:")
+    emit("s_lshl_b32 %[mvacc], %[mvacc], %[per]")         # band-move bits, oldest band in the top bit: append the last `per`
+    emit("s_or_b32 %[mvacc], %[mvacc], %[cnt]")
+    if not BORDER:
+        emit("s_bcnt1_i32_b32 %[t1], %[cnt]")             # right moves among them; the others advanced ll_e
+        emit("s_sub_u32 %[t1], %[per], %[t1]")
+        emit("s_add_u32 %[ll_e], %[ll_e], %[t1]")
     emit("s_add_u32 %[b], %[b], %[per]")
     emit("s_and_b32 %[t1], %[b], 7")
     emit(f"s_cbranch_scc1 norot_{tag}_%=")               # not on a dword boundary: the run ends here
@@ -423,7 +432,17 @@ def body(p, ml, m, rs):
     else:
         emit(f"erefill_{tag}_%=:")
         emit("s_waitcnt vmcnt(0)")
-        emit("s_add_u32 %[t0], %[ll_e], 1")                 # e_next = ll_e + 1 (event entering at offset 0)
+        if BORDER:
+            emit("s_add_u32 %[t0], %[ll_e], 1")             # e_next = ll_e + 1 (event entering at offset 0)
+        else:
+            # ll_e is as of the last tick: add the down moves since, this band included.  cnt = sentinel at bit
+            # (32 - per + done) over `done` recorded moves: done = per - 1 - leading zeros, rights = popcount - 1
+            emit("s_flbit_i32_b32 %[t0], %[cnt]")
+            emit("s_sub_u32 %[t0], %[per], %[t0]")          # done + 1
+            emit("s_bcnt1_i32_b32 %[t1], %[cnt]")           # rights + 1
+            emit("s_sub_u32 %[t0], %[t0], %[t1]")           # downs before this band
+            emit("s_add_u32 %[t0], %[t0], %[ll_e]")
+            emit("s_add_u32 %[t0], %[t0], 2")               # + this band's down move, + 1 for e_next
         emit("s_lshr_b32 %[t0], %[t0], 6")
         emit("s_and_b32 %[t1], %[t0], 1")
         emit("s_lshl_b32 %[t1], %[t1], 8")
