@@ -238,6 +238,9 @@ struct abea_host_pool {
 /* ------------------------------------------------------------------ one chunk in flight */
 struct abea_host_slot {
     hipStream_t stream = nullptr;
+    hipStream_t stream_hi = nullptr;                    /* highest priority: what follows the alignment kernel of a chunk */
+    bool hi_always = false, hi_never = false;
+    hipStream_t post = nullptr;                         /* the stream the chunk in flight ends on */
     hipEvent_t k0 = nullptr, k1 = nullptr, k2 = nullptr, k3 = nullptr, kdone = nullptr, done = nullptr;
     uint8_t* up = nullptr;  size_t up_cap = 0;          /* pinned, host -> device: [desc][reads][evm] */
     uint8_t* dn = nullptr;  size_t dn_cap = 0;          /* pinned, device -> host */
@@ -252,10 +255,29 @@ struct abea_host_slot {
     size_t pair_cap = 0;
 };
 
+/* the slot's high-priority stream, created when first needed */
+static int slot_hi_stream(abea_host_slot& s, hipStream_t* out) {
+    if (s.hi_never) { *out = s.stream; return ABEA_OK; }
+    if (!s.stream_hi) {
+        int prio_lo = 0, prio_hi = 0;
+        HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+        HIP_TRY(hipStreamCreateWithPriority(&s.stream_hi, hipStreamNonBlocking, prio_hi));
+    }
+    *out = s.stream_hi;
+    return ABEA_OK;
+}
+
 static int slot_create(abea_host_slot** out) {
     abea_host_slot* s = new abea_host_slot();
     *out = s;
     HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+    /* The kernels behind a chunk's alignment (scaling_single, the copy-out of the result block) are small; on the slot's own
+     * stream their workgroups queue for wave slots behind the alignment kernels of the OTHER slots, which hold all 4096 of
+     * them for milliseconds at a time (measured: 25 ms per chunk for 1 ms of work).  A queue of higher priority is served first
+     * whenever slots free up. */
+    const char* hi = getenv("ABEA_HOST_HI_STREAM");           /* "0": never, "1": always, default: only when scaling_single is fused */
+    s->hi_never = hi && hi[0] == '0';
+    s->hi_always = hi && hi[0] == '1';
     HIP_TRY(hipEventCreate(&s->k0)); HIP_TRY(hipEventCreate(&s->k1)); HIP_TRY(hipEventCreate(&s->k2)); HIP_TRY(hipEventCreate(&s->k3));
     HIP_TRY(hipEventCreateWithFlags(&s->kdone, hipEventDisableTiming | (getenv("ABEA_HOST_SPIN") ? 0 : hipEventBlockingSync)));
     HIP_TRY(hipEventCreateWithFlags(&s->done, hipEventDisableTiming | (getenv("ABEA_HOST_SPIN") ? 0 : hipEventBlockingSync)));
@@ -345,6 +367,7 @@ void abea_host_join_async(abea_ctx* c) {
 void abea_host_release(abea_ctx* c) {
     for (abea_host_slot* s : c->slots) {
         if (!s) continue;
+        if (s->stream_hi && s->stream_hi != s->stream) { hipStreamSynchronize(s->stream_hi); hipStreamDestroy(s->stream_hi); }
         if (s->stream) { hipStreamSynchronize(s->stream); hipStreamDestroy(s->stream); }
         for (hipEvent_t e : {s->k0, s->k1, s->k2, s->k3, s->kdone, s->done}) if (e) hipEventDestroy(e);
         hipHostFree(s->up); hipHostFree(s->dn);
@@ -585,8 +608,8 @@ static int slot_stage(host_run_state& S, abea_host_slot& sl, bool block) {
     const unsigned long long total = *(const unsigned long long*)(sl.dn + sl.o_cursor);
     if (total > sl.pair_cap) return abea_fail(ABEA_EHIP, "internal: %llu compacted pairs exceed the capacity %zu", total, sl.pair_cap);
     if (total)
-        HIP_TRY(hipMemcpyAsync(sl.dn + sl.o_pairs, sl.d_pairs, (size_t)total * sizeof(abea_pair_t), hipMemcpyDeviceToHost, sl.stream));
-    HIP_TRY(hipEventRecord(sl.done, sl.stream));
+        HIP_TRY(hipMemcpyAsync(sl.dn + sl.o_pairs, sl.d_pairs, (size_t)total * sizeof(abea_pair_t), hipMemcpyDeviceToHost, sl.post));
+    HIP_TRY(hipEventRecord(sl.done, sl.post));
     S.st.d2h_bytes += total * sizeof(abea_pair_t);
     sl.staged = true;
     return ABEA_OK;
@@ -654,7 +677,7 @@ struct slot_guard {
     ~slot_guard() {
         for (int q = lane->first_slot; q < lane->first_slot + lane->n_slots && q < (int)c->slots.size(); ++q) {
             abea_host_slot* s = c->slots[(size_t)q];
-            if (s && s->busy) { hipStreamSynchronize(s->stream); s->busy = false; }
+            if (s && s->busy) { hipStreamSynchronize(s->stream); if (s->stream_hi) hipStreamSynchronize(s->stream_hi); s->busy = false; }
         }
     }
 };
@@ -911,24 +934,31 @@ static int host_run(abea_ctx* c, const abea_host_batch* H, const int32_t* mine, 
                            d_desc, d_evm, d_kpar, d_trace, d_codes, d_pairs, d_np, d_diag,
                            S.device_pairs ? d_cursor : (unsigned long long*)nullptr, S.device_pairs ? d_poff : (int64_t*)nullptr);
         HIP_TRY(hipEventRecord(sl.k2, sl.stream));
+        /* the rest of the chunk jumps the queue (slot_create) when scaling_single is fused: its two kernels are the bulk of
+         * the chunk's latency then.  With the alignment alone only the copy-out follows, and the measurements do not show a
+         * gain that outweighs one more busy queue on a host-bound box, so it stays on the slot's stream. */
+        hipStream_t post = sl.stream;
+        if ((scaling || sl.hi_always) && (rc = slot_hi_stream(sl, &post))) return rc;
+        sl.post = post;
+        if (post != sl.stream) HIP_TRY(hipStreamWaitEvent(post, sl.k2, 0));
         if (scaling) {
-            hipLaunchKernelGGL(abea_scaling_kernel, dim3((unsigned)m), dim3(64), 0, sl.stream,
+            hipLaunchKernelGGL(abea_scaling_kernel, dim3((unsigned)m), dim3(64), 0, post,
                                d_desc, d_reads, c->d_model, (int)c->k, d_evm, d_pairs, d_np, d_b2e,
                                (double*)(d_dn + sl.o_epb), (int32_t*)(d_dn + sl.o_flag), (int32_t*)(d_dn + sl.o_nal), d_mrec, d_nm);
-            hipLaunchKernelGGL(abea_recalib_kernel, dim3((unsigned)((m + 63) / 64)), dim3(64), 0, sl.stream,
+            hipLaunchKernelGGL(abea_recalib_kernel, dim3((unsigned)((m + 63) / 64)), dim3(64), 0, post,
                                d_desc, (int)m, d_mrec, d_nm, (abea_scalings_t*)(d_dn + sl.o_sc),
                                (const double*)(d_dn + sl.o_epb), (int32_t*)(d_dn + sl.o_flag), min_rescale);
-            HIP_TRY(hipEventRecord(sl.k3, sl.stream));
+            HIP_TRY(hipEventRecord(sl.k3, post));
         }
         /* the result block goes down by a kernel, not by an SDMA copy: a copy queued behind the alignment kernel would
          * hold its SDMA ring until that kernel ends and stall the next chunks' H2D copies (abea_copy_out_kernel) */
-        if (S.opt.sdma_d2h) HIP_TRY(hipMemcpyAsync(sl.dn, d_dn, dn_copy, hipMemcpyDeviceToHost, sl.stream));
+        if (S.opt.sdma_d2h) HIP_TRY(hipMemcpyAsync(sl.dn, d_dn, dn_copy, hipMemcpyDeviceToHost, post));
         else hipLaunchKernelGGL(abea_copy_out_kernel, dim3((unsigned)std::min<size_t>(512, (dn_copy / 16 + 255) / 256)), dim3(256), 0,
-                                sl.stream, (const uint4*)d_dn, (uint4*)sl.dn, dn_copy / 16);
+                                post, (const uint4*)d_dn, (uint4*)sl.dn, dn_copy / 16);
         HIP_TRY(hipGetLastError());
         S.st.d2h_bytes += dn_copy;
-        if (S.device_pairs) HIP_TRY(hipEventRecord(sl.kdone, sl.stream));       /* the pair copy follows at stage A */
-        else HIP_TRY(hipEventRecord(sl.done, sl.stream));
+        if (S.device_pairs) HIP_TRY(hipEventRecord(sl.kdone, post));            /* the pair copy follows at stage A */
+        else HIP_TRY(hipEventRecord(sl.done, post));
         sl.busy = true;
         S.log("enqueued", chunk_no);
         S.st.n_sub_batches += 1; S.st.fill_launches += 1;

@@ -657,6 +657,7 @@ void abea_scaling_kernel(const abea_read_desc* __restrict__ descs, const char* _
                          const int32_t* __restrict__ n_pairs, abea_index_pair_t* __restrict__ b2e_all,
                          double* __restrict__ epb_out, int32_t* __restrict__ flag_io, int32_t* __restrict__ nalign_out,
                          abea_mrec* __restrict__ mrec_all, int32_t* __restrict__ n_m_out) {
+    __builtin_amdgcn_s_setprio(2);                       /* short, and on its chunk's critical path */
     const abea_read_desc* d = descs + blockIdx.x;
     const int lane = threadIdx.x;
     const int out_idx = d->out_idx;
@@ -734,6 +735,9 @@ extern "C" __global__ __launch_bounds__(64)
 void abea_recalib_kernel(const abea_read_desc* __restrict__ descs, int n_desc, const abea_mrec* __restrict__ mrec_all,
                          const int32_t* __restrict__ n_m_in, abea_scalings_t* __restrict__ sc_io,
                          const double* __restrict__ epb_in, int32_t* __restrict__ flag_io, int min_rescale) {
+    /* a handful of wavefronts with long serial chains, sharing their SIMDs with the fill loops of other chunks: they are
+     * the latency of their chunk, so they issue first */
+    __builtin_amdgcn_s_setprio(3);
     const int j = blockIdx.x * 64 + threadIdx.x;
     if (j >= n_desc) return;
     const abea_read_desc* d = descs + j;
