@@ -83,6 +83,11 @@ static inline float emission_lp(float x, float scale, float shift, const orc_mod
 
 typedef struct { int e; int k; } ll_t;      /* align.c:265-268 */
 
+/* analysis hook (tools/walk_drift.py): when set, orc_align() copies band_lower_left[b].kmer_idx of every band here */
+static __thread int32_t* g_dbg_llk = NULL;
+static __thread size_t g_dbg_llk_cap = 0;
+void orc_debug_band_llk(int32_t* buf, size_t cap) { g_dbg_llk = buf; g_dbg_llk_cap = cap; }
+
 int32_t orc_align(orc_pair_t* out, const char* seq, int32_t seq_len,
                   const orc_event_t* ev, size_t n_events, const orc_model_t* model,
                   uint32_t k, float scale, float shift, orc_diag_t* diag) {
@@ -214,6 +219,9 @@ int32_t orc_align(orc_pair_t* out, const char* seq, int32_t seq_len,
     for (int i = 0, j = n_out - 1; i < j; ++i, --j) {                  /* align.c:503-513 */
         orc_pair_t t = out[i]; out[i] = out[j]; out[j] = t;
     }
+
+    if (g_dbg_llk)
+        for (size_t b = 0; b < n_bands && b < g_dbg_llk_cap; ++b) g_dbg_llk[b] = ll[b].k;
 
     /* align.c:526-543 : QC */
     double avg = sum_emission / n_aligned;

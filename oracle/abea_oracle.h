@@ -92,6 +92,10 @@ float orc_profile_hmm_score(const char* m_seq, const char* m_rc_seq, const orc_e
                             uint32_t event_stop_idx, int8_t event_stride, uint8_t rc, double events_per_base,
                             uint32_t hmm_flags);
 
+/* analysis hook (tools/walk_drift.py): orc_align() on this thread copies every band's lower-left k-mer index
+ * (band_lower_left[b].kmer_idx, align.c:270-322) into buf; NULL = off */
+void orc_debug_band_llk(int32_t* buf, size_t cap);
+
 #ifdef __cplusplus
 }
 #endif

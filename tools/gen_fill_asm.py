@@ -583,7 +583,7 @@ if __name__ == "__main__":
 # Traceback walk (align.c:452-499) on the scalar unit: one inline-asm statement, ~40 SALU per step.
 # Fixed SGPRs s72..s99, VGPRs v64..v75 (the fill statement's range; the two statements never overlap).
 # =====================================================================================================
-WALK_RADIUS = int(os.environ.get("ABEA_WALK_RADIUS", "26"))     # lane pairs either side of the path that a prefetch covers
+WALK_RADIUS = int(os.environ.get("ABEA_WALK_RADIUS", "12"))     # lane pairs either side of the path that a prefetch covers
 
 
 def gen_walk():
