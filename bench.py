@@ -14,6 +14,12 @@ N>1 (config 4): the SAME batch strong-scaled; every rank builds and aligns only 
 RCCL carries the final MAX-time / statistics gather.  `--single-process --gpus N` instead drives N GPUs from one
 process through the library's own multi-device context (abea_init_multi).
 
+Extras in the same line, all outside the timed region: `f5c_default_batch` (one f5c-default batch at a time, and 8
+consecutive ones with 2 / 4 in flight through abea_align_batch_host_submit/_wait), `fused_scaling` (align_db + scaling_db in one
+call), `cpu_baseline` (the oracle port on the host cores, which also checks this run's GPU pairs bit for bit on its sample).
+`roofline.traffic` and `roofline.limiter` come from the committed rocprofv3 PMC passes of the same workload
+(profiles/pmc_traffic.json, built by profiles/make_pmc_traffic.py from profiles/r03/c_*).
+
 Prints ONE JSON line on rank 0.
 """
 import argparse
