@@ -27,7 +27,16 @@ import os
 # Either one writes abea_fill_exp.inc / abea_walk_exp.inc (compiled under -DABEA_EXP) and leaves the shipped files alone.
 VB = int(os.environ.get("ABEA_VBASE", "64"))  # first fixed VGPR (v64..v121 in the shipped build)
 TIED = os.environ.get("ABEA_TIED", "0") == "1"
-EXPERIMENT = VB != 64 or TIED
+# ABEA_PK=1: packed-f32 instructions of gfx90a+ where the two cells of a lane do the same f32 operation on operands that can
+# sit in one aligned VGPR pair (a*a, the two tie-break differences) and v_pk_mov_b32 for the event shift of a down move:
+# -4 VALU on a down-move band, -3 on a right-move band, same arithmetic (v_pk_add/mul_f32 round like v_add/mul_f32).
+PK = os.environ.get("ABEA_PK", "0") in ("1", "2")
+# ABEA_PK=2: the same instructions, but the ten that do not depend on the emission (doubles of the previous scores, the
+# constant adds, the rounded skip score) are issued BETWEEN the steps of the emission chain instead of after it; needs 6 more
+# fixed VGPRs (a, a*a / lp and the second skip sum get registers of their own).
+PKS = os.environ.get("ABEA_PK", "0") == "2"
+EXPERIMENT = VB != 64 or TIED or PK
+assert VB % 2 == 0
 MF0, MF1, SHR, SHD = VB + 0, VB + 1, VB + 2, VB + 3
 TR = [dict(c0=VB + 4, c1=VB + 6, cs=VB + 8), dict(c0=VB + 10, c1=VB + 12, cs=VB + 14)]
 X0, X1 = VB + 16, VB + 17
@@ -54,6 +63,9 @@ TOFF = VB + 55     # trace store offset (lane*16 + group*1024)
 F = [VB + 47, VB + 49]     # from codes: high halves of the TD pairs (free once sd is rounded)
 O0, O1 = VB + 56, VB + 57   # band offsets owned by the lane (border variant only)
 VEND = VB + 58     # one past the last fixed VGPR
+if PKS:
+    PA, PSQ, SK = VB + 58, VB + 60, [VB + 56, VB + 62]      # SK[0] takes the border variant's offset pair (unused in the interior loop)
+    VEND = VB + 64
 TIED_HOME = {"L0": TR[1]['c0'], "L1": TR[1]['c1'], "U1": TR[1]['cs'], "U0": TR[0]['c0']}   # exit homes of the row doubles
 BORDER = False     # generator mode: True adds validity masks + the online end-point scan
 # extra per-cell 32-bit temps reuse the low halves of f64 temps where noted
@@ -156,6 +168,76 @@ def cell_ops(j, D, U, L, quad):
     return ops
 
 
+def cells_pks(D, U, L, quads, pre):
+    """cells_pk with the emission chain and the independent work interleaved (ABEA_PK=2); pre = the converts of the previous
+    band's scores that body() would have issued first."""
+    g = [quads[0], quads[1]]; ck = [quads[0] + 1, quads[1] + 1]; ii = [quads[0] + 2, quads[1] + 2]
+    A = [f"v_sub_f32 {v(PA + j)}, {v(X0 + j)}, {v(g[j])}" for j in (0, 1)]
+    A += [f"v_cvt_f64_f32 {vp(LPD[j])}, {v(PA + j)}" for j in (0, 1)]
+    A += [f"v_mul_f64 {vp(LPD[j])}, {vp(LPD[j])}, {vp(ii[j])}" for j in (0, 1)]
+    A += [f"v_cvt_f32_f64 {v(PA + j)}, {vp(LPD[j])}" for j in (0, 1)]
+    A += [f"v_pk_mul_f32 {vp(PSQ)}, {vp(PA)}, {vp(PA)}"]
+    A += [f"v_fma_f32 {v(PSQ + j)}, -0.5, {v(PSQ + j)}, {v(ck[j])}" for j in (0, 1)]
+    A += [f"v_cvt_f64_f32 {vp(LPD[j])}, {v(PSQ + j)}" for j in (0, 1)]
+    B = list(pre)
+    B += [f"v_add_f64 {vp(TD[j])}, {vp(D[j])}, %[lp_step]" for j in (0, 1)]
+    B += [f"v_add_f64 {vp(TU[j])}, {vp(U[j])}, %[lp_stay]" for j in (0, 1)]
+    B += [f"v_add_f64 {vp(SK[j])}, {vp(L[j])}, %[lp_skip]" for j in (0, 1)]
+    B += [f"v_cvt_f32_f64 {v(SK[0])}, {vp(SK[0])}", f"v_cvt_f32_f64 {v(SK[0] + 1)}, {vp(SK[1])}"]     # sl pair = v[SK0]
+    ops = interleave(A, B)
+    ops += [f"v_add_f64 {vp(TD[j])}, {vp(TD[j])}, {vp(LPD[j])}" for j in (0, 1)]
+    ops += [f"v_add_f64 {vp(TU[j])}, {vp(TU[j])}, {vp(LPD[j])}" for j in (0, 1)]
+    for base, src in ((TD[0], TD), (TU[0], TU)):
+        for j in (0, 1):
+            ops.append(f"v_cvt_f32_f64 {v(base + j)}, {vp(src[j])}")
+    for j in (0, 1):
+        ops.append(f"v_max3_f32 {v(MF0 + j)}, {v(TD[0] + j)}, {v(TU[0] + j)}, {v(SK[0] + j)}")
+    ops.append(f"v_pk_add_f32 {vp(TD[1])}, {vp(TU[0])}, {vp(TD[0])} neg_lo:[0,1] neg_hi:[0,1]")     # su - sd
+    ops.append(f"v_pk_add_f32 {vp(TU[1])}, {vp(SK[0])}, {vp(MF0)} neg_lo:[0,1] neg_hi:[0,1]")       # sl - max
+    return ops
+
+
+def cells_pk(D, U, L, quads):
+    """Interior band, both cells of the lane, with packed f32 where the operands pair up (ABEA_PK=1).  Pairs: a = v[TD0],
+    a*a / lp = v[TU0], then sd = v[TD0] (lo = cell 0, hi = cell 1), su = v[TU0], sl = v[LPD0]; the differences land in
+    v[TD1] = su - sd and v[TU1] = sl - mf."""
+    g = [quads[0], quads[1]]; ck = [quads[0] + 1, quads[1] + 1]; ii = [quads[0] + 2, quads[1] + 2]
+    A = TD[0]; SQ = TU[0]
+    ops = []
+    for j in (0, 1):
+        ops.append(f"v_sub_f32 {v(A + j)}, {v(X0 + j)}, {v(g[j])}")
+    for j in (0, 1):
+        ops.append(f"v_cvt_f64_f32 {vp(LPD[j])}, {v(A + j)}")
+    for j in (0, 1):
+        ops.append(f"v_mul_f64 {vp(LPD[j])}, {vp(LPD[j])}, {vp(ii[j])}")
+    for j in (0, 1):
+        ops.append(f"v_cvt_f32_f64 {v(A + j)}, {vp(LPD[j])}")
+    ops.append(f"v_pk_mul_f32 {vp(SQ)}, {vp(A)}, {vp(A)}")
+    for j in (0, 1):
+        ops.append(f"v_fma_f32 {v(SQ + j)}, -0.5, {v(SQ + j)}, {v(ck[j])}")
+    for j in (0, 1):
+        ops.append(f"v_cvt_f64_f32 {vp(LPD[j])}, {v(SQ + j)}")
+    for j in (0, 1):
+        ops.append(f"v_add_f64 {vp(TD[j])}, {vp(D[j])}, %[lp_step]")
+    for j in (0, 1):
+        ops.append(f"v_add_f64 {vp(TU[j])}, {vp(U[j])}, %[lp_stay]")
+    for j in (0, 1):
+        ops.append(f"v_add_f64 {vp(TD[j])}, {vp(TD[j])}, {vp(LPD[j])}")
+    for j in (0, 1):
+        ops.append(f"v_add_f64 {vp(TU[j])}, {vp(TU[j])}, {vp(LPD[j])}")
+    for j in (0, 1):
+        ops.append(f"v_add_f64 {vp(LPD[j])}, {vp(L[j])}, %[lp_skip]")
+    # rounded scores into pairs: cell 0's convert frees the high dword that cell 1's convert then takes
+    for base, src in ((TD[0], TD), (TU[0], TU), (LPD[0], LPD)):
+        for j in (0, 1):
+            ops.append(f"v_cvt_f32_f64 {v(base + j)}, {vp(src[j])}")
+    for j in (0, 1):
+        ops.append(f"v_max3_f32 {v(MF0 + j)}, {v(TD[0] + j)}, {v(TU[0] + j)}, {v(LPD[0] + j)}")
+    ops.append(f"v_pk_add_f32 {vp(TD[1])}, {vp(TU[0])}, {vp(TD[0])} neg_lo:[0,1] neg_hi:[0,1]")     # su - sd
+    ops.append(f"v_pk_add_f32 {vp(TU[1])}, {vp(LPD[0])}, {vp(MF0)} neg_lo:[0,1] neg_hi:[0,1]")      # sl - max
+    return ops
+
+
 def interleave(a, b):
     """Alternate two independent instruction streams (fills dependent-issue and hazard slots)."""
     res = []
@@ -252,8 +334,12 @@ def body(p, ml, m, rs):
         emit(f"v_mov_b32_dpp {v(SHD)}, {v(MF1)} {DPP_SHR}")
         emit("s_waitcnt lgkmcnt(4)" if ml == 'R' else "s_waitcnt lgkmcnt(0)")     # incoming event landed (a right move's four k-mer reads may still be out)
         emit(f"v_mov_b32_dpp {v(NX)}, {v(X1)} {DPP_SHR}")
-        emit(f"v_mov_b32 {v(X1)}, {v(X0)}")
-        emit(f"v_mov_b32 {v(X0)}, {v(NX)}")
+        if PK and not BORDER:
+            # lo result = src0's dword picked by op_sel[0], hi result = src1's dword picked by op_sel_hi[1]: X0 = NX, X1 = old X0
+            emit(f"v_pk_mov_b32 {vp(X0)}, {vp(NX)}, {vp(X0)} op_sel:[0,0] op_sel_hi:[0,0]")
+        else:
+            emit(f"v_mov_b32 {v(X1)}, {v(X0)}")
+            emit(f"v_mov_b32 {v(X0)}, {v(NX)}")
         emit("s_add_u32 %[e_addr], %[e_addr], 0x04000004")  # LDS address of the next incoming event | position in chunk << 26
         emit(f"s_cbranch_scc1 erefill_{tag}_%=")
         emit(f"econt_{tag}_%=:")
@@ -264,8 +350,10 @@ def body(p, ml, m, rs):
         U = (T['c0'], T['c1']); L = (T['cs'], T['c0'])
         D = (Tp['c0'], Tp['c1']) if ml == 'R' else (Tp['cs'], Tp['c0'])
     # exact doubles of the previous band's scores (c0 issued above)
-    emit(f"v_cvt_f64_f32 {vp(T['c1'])}, {v(MF1)}")
-    emit(f"v_cvt_f64_f32 {vp(T['cs'])}, {v(sh)}")
+    pre = [f"v_cvt_f64_f32 {vp(T['c1'])}, {v(MF1)}", f"v_cvt_f64_f32 {vp(T['cs'])}, {v(sh)}"]
+    if not (PKS and not BORDER):
+        for ins in pre:
+            emit(ins)
     if BORDER:
         # in-matrix offsets [min_off, max_off) (align.c:337-346)
         emit("s_sub_u32 %[t2], %[ll_e], %[Em1]")
@@ -283,7 +371,11 @@ def body(p, ml, m, rs):
         emit(f"v_subrev_u32 {v(F[1])}, %[t2], {v(O1)}")
         emit(f"v_cmp_gt_u32 %[cv0], %[t3], {v(F[0])}")
         emit(f"v_cmp_gt_u32 %[cv1], %[t3], {v(F[1])}")
-    ops0 = cell_ops(0, D[0], U[0], L[0], KQ[rs]); ops1 = cell_ops(1, D[1], U[1], L[1], KQ[(rs + 1) % 3])
+    if PK and not BORDER:
+        qs = (KQ[rs], KQ[(rs + 1) % 3])
+        ops0 = cells_pks(D, U, L, qs, pre) if PKS else cells_pk(D, U, L, qs); ops1 = []
+    else:
+        ops0 = cell_ops(0, D[0], U[0], L[0], KQ[rs]); ops1 = cell_ops(1, D[1], U[1], L[1], KQ[(rs + 1) % 3])
     if BORDER:
         # split off the two trailing from-code selects of each cell (and the s_nop before them)
         tail0, tail1 = ops0[-2:], ops1[-2:]
@@ -356,11 +448,12 @@ def body(p, ml, m, rs):
         # trace bits, oldest first: cell 1 [sl<max], cell 1 [su<sd], cell 0 [sl<max], cell 0 [su<sd]; each v_alignbit
         # is acc = acc << 1 | sign(difference).  Complemented per dword they read f = 2*[sl==max] + [su>=sd]:
         # 0 FROM_D, 1 FROM_U, 2 or 3 FROM_L (align.c:386-392 priority).
-        emit(f"v_alignbit_b32 {v(ACC)}, {v(ACC)}, {v(TD[1])}, 31")
-        emit(f"v_alignbit_b32 {v(ACC)}, {v(ACC)}, {v(F[1])}, 31")
+        b_l1, b_u1, b_l0, b_u0 = (TU[1] + 1, TD[1] + 1, TU[1], TD[1]) if PK else (TD[1], F[1], TD[0], F[0])
+        emit(f"v_alignbit_b32 {v(ACC)}, {v(ACC)}, {v(b_l1)}, 31")
+        emit(f"v_alignbit_b32 {v(ACC)}, {v(ACC)}, {v(b_u1)}, 31")
         emit(f"v_readlane_b32 %[t0], {v(MF0)}, 0")          # mf0 was written 3 instructions ago
-        emit(f"v_alignbit_b32 {v(ACC)}, {v(ACC)}, {v(TD[0])}, 31")
-        emit(f"v_alignbit_b32 {v(ACC)}, {v(ACC)}, {v(F[0])}, 31")
+        emit(f"v_alignbit_b32 {v(ACC)}, {v(ACC)}, {v(b_l0)}, 31")
+        emit(f"v_alignbit_b32 {v(ACC)}, {v(ACC)}, {v(b_u0)}, 31")
         emit(f"v_cmp_lt_f32 vcc, %[t0], {v(MF1)}")          # t0 written 3 instructions ago
     # %[cnt] counts the bands to the next "tick" (a trace dword completes every 8th band; the run ends at b_end): the
     # band index itself is only brought up to date there
