@@ -324,6 +324,7 @@ struct abea_async_job {
     int rc = ABEA_OK;
     std::string err;
     bool active = false;
+    bool waiting = false;                      /* a thread is inside abea_align_batch_host_wait() for this job */
     uint32_t gen = 0;
 };
 
@@ -1125,7 +1126,7 @@ extern "C" int abea_align_batch_host_submit(abea_ctx* c, const abea_host_batch* 
     if (lane < 0) return abea_fail(ABEA_EBUSY, "abea_align_batch_host_submit: all %d lanes are busy (wait for a ticket first)", a->n_lanes);
     abea_async_job& j = a->jobs[lane];
     if (j.th.joinable()) j.th.join();
-    j.H = *H; j.rc = ABEA_OK; j.err.clear(); j.active = true; ++j.gen;
+    j.H = *H; j.rc = ABEA_OK; j.err.clear(); j.active = true; j.waiting = false; ++j.gen;
     memset(&j.st, 0, sizeof j.st);
     ++a->n_active;
     const int n_lanes = a->n_lanes;
@@ -1147,11 +1148,14 @@ extern "C" int abea_align_batch_host_wait(abea_ctx* c, int32_t ticket) {
         abea_host_async* a = async_of(c);
         if (lane >= ABEA_MAX_INFLIGHT || !a->jobs[lane].active || (int32_t)((a->jobs[lane].gen & 0xFFFFFFu) << 3 | lane) != ticket)
             return abea_fail(ABEA_EINVAL, "abea_align_batch_host_wait: ticket %d is not in flight", ticket);
+        if (a->jobs[lane].waiting)               /* a ticket is redeemed once: two joins of one thread would be undefined */
+            return abea_fail(ABEA_EBUSY, "abea_align_batch_host_wait: another thread is already waiting for ticket %d", ticket);
         j = &a->jobs[lane];
+        j->waiting = true;
     }
     if (j->th.joinable()) j->th.join();                      /* outside the lock: other tickets can be submitted / waited meanwhile */
     std::lock_guard<std::mutex> api(c->api_mu);
-    j->active = false;
+    j->active = false; j->waiting = false;
     --c->async->n_active;
     if (j->rc) return abea_fail(j->rc, "%s", j->err.c_str());
     c->stats = j->st;
