@@ -562,6 +562,10 @@ def exit_stub(p, ml, rs):
     tag = f"{p}{ml}{rs}"
     Tl = TR[p ^ 1]
     emit(f"exit_{tag}_%=:")
+    # the incoming k-mer quad (four ds_read_addtid of the last right move) and the pending event may formally still be in
+    # flight: a down move's lgkmcnt(4) leaves the quad's reads outstanding on purpose.  They must have landed before the
+    # quads are shuffled back to the entry layout (found by tools/asm_lint.py; in practice they land ~200 cycles earlier)
+    emit("s_waitcnt lgkmcnt(0)")
     if rs:
         # back to the entry layout: cell 0 -> KQ[0], cell 1 -> KQ[1], incoming -> KQ[2], through the per-cell temps
         tq = [LPD[0], TD[0], TU[0]]                          # three free quads (v106..v117)
