@@ -18,10 +18,14 @@ def findings(lines):
 
 def test_shipped_statements_are_clean():
     for fn, macro, min_lines in (("abea_fill.inc", "ABEA_FILL_ASM", 8000), ("abea_walk.inc", "ABEA_WALK_ASM", 100)):
-        found, n, dead = L.lint(L.statement(os.path.join(CSRC, fn), macro), fn)
+        path = os.path.join(CSRC, fn)
+        found, n, dead = L.lint(L.statement(path, macro), fn, L.undefined_at_entry(path, macro))
+        found, waived = L.apply_waivers(found, fn)
+        assert waived <= 2, waived                          # the one documented value-dependent path (two registers of a pair)
         assert n >= min_lines, (fn, n)                      # the whole statement was parsed
         assert dead == 0, f"{fn}: {dead} unreachable instructions"
         assert not found, "\n".join(found[:10])
+        assert not L.unclobbered_writes(path, macro)
 
 
 def test_planted_wait_state_faults_are_found():
@@ -76,3 +80,16 @@ def test_worst_path_wins_at_a_join():
     loop = ["top_%=:", f"v_mov_b32_dpp v3, v1 {DPP}", "s_nop 4", "s_cmp_eq_u32 %[b], 0", "v_mov_b32 v1, v2", "s_cbranch_scc0 top_%="]
     f = findings(loop)
     assert len(f) == 1 and "H1" in f[0], f
+
+
+def test_planted_read_before_write_is_found():
+    und = {"%t1", "v110"}
+    assert L.lint(["s_add_u32 %[t0], %[t1], 1"], "t", und)[0]
+    assert not L.lint(["s_mov_b32 %[t1], 0", "s_add_u32 %[t0], %[t1], 1"], "t", und)[0]
+    # written on one path only
+    prog = ["s_cmp_eq_u32 %[b], 0", "s_cbranch_scc1 skip_%=", "v_mov_b32 v110, v1", "skip_%=:", "v_add_f32 v2, v110, v110"]
+    f = L.lint(prog, "t", und)[0]
+    assert len(f) == 1 and "U1" in f[0], f
+    # a DPP move keeps the lanes without a source: it reads its destination
+    assert L.lint([f"v_mov_b32_dpp v110, v1 {DPP}"], "t", und)[0]
+    assert len(L.write_only_operands()) >= 15               # the "=&s" / "=&v" operands were found in the kernel source

@@ -13,6 +13,12 @@ control-flow graph of the statement (labels, s_branch, s_cbranch_*), with a forw
     H5  VALU writes SGPR           -> VMEM reads it (scalar address)               >= 5
     H6  SALU writes M0             -> LDS add-TID instruction                      >= 1
     H7  global store of > 64 bits  -> VALU overwrites its data VGPRs               >= 2
+  definite assignment:
+    U1  a write-only operand of the statement ("=&s" / "=&v" in abea_kernels.hip) or a clobbered fixed register is written
+        on every path before it is read (DPP moves and v_writelane keep part of their destination: they read it too)
+  clobbers:
+    C1  every fixed register the statement writes is in its CLOBBERS macro or tied to an operand (m0 and exec are
+        reserved: the statement restores exec and the compiler keeps nothing in m0 across an asm volatile)
   memory results (the counters return in order per class):
     W1  a register that an outstanding ds_read / global_load will write is neither read nor written before an
         s_waitcnt lgkmcnt(n) / vmcnt(n) that covers it (n <= the number of same-class operations issued after it)
@@ -161,23 +167,32 @@ def successors(ins, labels, i):
     return out
 
 
+def write_only_operands():
+    """Names bound with "=&s" / "=&v" in the kernel source: undefined when the statement starts."""
+    text = open(os.path.join(ROOT, "f5c_amd", "csrc", "abea_kernels.hip")).read()
+    return {"%" + m for m in re.findall(r'\[(\w+)\]\s*"=&[sv]"', text)}
+
+
 class State:
     """ages[r] = instructions issued since r was last written by (VALU, SALU); store[r] = since a >64-bit store named r
     as data; pend[(cls, r)] = memory operations of that class issued after the outstanding load that will write r."""
-    __slots__ = ("valu", "salu", "store", "pend")
+    __slots__ = ("valu", "salu", "store", "pend", "undef")
 
-    def __init__(self):
+    def __init__(self, undef=()):
         self.valu, self.salu, self.store, self.pend = {}, {}, {}, {}
+        self.undef = {r: 0 for r in undef}          # registers that may still be unwritten (a dict so that merge() is shared)
 
     def copy(self):
         s = State()
         s.valu, s.salu, s.store, s.pend = dict(self.valu), dict(self.salu), dict(self.store), dict(self.pend)
+        s.undef = dict(self.undef)
         return s
 
     def merge(self, o):
         """Worst case of the two; True if self changed."""
         changed = False
-        for mine, theirs in ((self.valu, o.valu), (self.salu, o.salu), (self.store, o.store), (self.pend, o.pend)):
+        for mine, theirs in ((self.valu, o.valu), (self.salu, o.salu), (self.store, o.store), (self.pend, o.pend),
+                             (self.undef, o.undef)):
             for k, v in theirs.items():
                 if k not in mine or v < mine[k]:
                     mine[k] = v; changed = True
@@ -219,6 +234,14 @@ def step(x, st, report):
                 if (cls, r) in st.pend:
                     report(x, f"W1 {r} is the target of an outstanding {'LDS' if cls == 'lgkm' else 'global'} load "
                               f"({st.pend[(cls, r)]} later operation(s) of its class, no covering s_waitcnt)")
+    reads = list(x.src) + list(x.lane_select)
+    if x.dpp or x.op == "v_writelane_b32":
+        reads += x.dst                                     # lanes without a source / the other 63 lanes keep the old value
+    for r in reads:
+        if r in st.undef:
+            report(x, f"U1 {r} may be read before it is written")
+    for r in x.dst:
+        st.undef.pop(r, None)
     # ---------------- effects
     w = x.wait_states()
     for table in (st.valu, st.salu, st.store):
@@ -254,14 +277,14 @@ def step(x, st, report):
         st.valu["vcc_lo"] = st.valu["vcc_hi"] = 0
 
 
-def lint(lines, name):
+def lint(lines, name, undef=()):
     ins, labels = parse(lines)
     findings = {}
 
     def report(x, msg):
         findings.setdefault((x.idx, msg.split(":")[0]), f"{name}:{x.idx + 1}: `{x.text}`  {msg}")
     states = [None] * len(ins)
-    states[0] = State()
+    states[0] = State(undef)
     work = [0]
     while work:
         i = work.pop()
@@ -276,13 +299,55 @@ def lint(lines, name):
     return list(findings.values()), len(ins), len(unreachable)
 
 
+# Findings that hold on a path the data flow cannot rule out but the values do, each with its reason.
+WAIVERS = {
+    ("abea_walk.inc", "U1", "s_cselect_b64 s[94:95], s[90:91], s[88:89]"):
+        "the first step always branches to reload_lp, which loads s[88:91]: s86 starts at -1 and a lane pair (0..49) never equals it",
+}
+
+
+def unclobbered_writes(path, macro):
+    """C1: fixed registers written by the statement but neither clobbered nor tied."""
+    text = open(path).read()
+    m = re.search(r"#define " + macro.replace("_ASM", "_CLOBBERS") + r" (.*)", text)
+    declared = set(re.findall(r'"(\w+)"', m.group(1))) if m else set()
+    declared |= set(re.findall(r"\{(v\d+)\}", text))                       # tied operands of the experiment layouts
+    for a, b in re.findall(r"\{v\[(\d+):(\d+)\]\}", text):
+        declared |= {f"v{i}" for i in range(int(a), int(b) + 1)}
+    if "vcc" in declared:
+        declared |= {"vcc_lo", "vcc_hi"}
+    declared |= {"m0", "exec_lo", "exec_hi"}
+    bad = {}
+    for x in parse(statement(path, macro))[0]:
+        for r in x.dst:
+            if not r.startswith("%") and r not in declared:
+                bad.setdefault(r, f"{os.path.basename(path)}:{x.idx + 1}: `{x.text}`  C1 {r} is written but not clobbered")
+    return list(bad.values())
+
+
+def undefined_at_entry(path, macro):
+    """Write-only operands + the fixed registers the statement clobbers (its CLOBBERS macro)."""
+    text = open(path).read()
+    m = re.search(r"#define " + macro.replace("_ASM", "_CLOBBERS") + r" (.*)", text)
+    regs = set(re.findall(r'"([vs]\d+)"', m.group(1))) if m else set()
+    return regs | write_only_operands()
+
+
+def apply_waivers(found, fn):
+    keep = [f for f in found if not any(w[0] == fn and f"  {w[1]} " in f and f"`{w[2]}`" in f for w in WAIVERS)]
+    return keep, len(found) - len(keep)
+
+
 def main():
     csrc = os.path.join(ROOT, "f5c_amd", "csrc")
     bad = 0
     for fn, macro in (("abea_fill.inc", "ABEA_FILL_ASM"), ("abea_walk.inc", "ABEA_WALK_ASM")):
         path = os.path.join(csrc, sys.argv[sys.argv.index("--suffix") + 1].join(os.path.splitext(fn))
                             if "--suffix" in sys.argv else fn)
-        found, n, dead = lint(statement(path, macro), os.path.basename(path))
+        found, n, dead = lint(statement(path, macro), os.path.basename(path), undefined_at_entry(path, macro))
+        found, waived = apply_waivers(found, fn)
+        found += unclobbered_writes(path, macro)
+        print(f"{fn}: {waived} finding(s) waived (see WAIVERS)") if waived else None
         print(f"{os.path.basename(path)}: {n} lines, {len(found)} finding(s), {dead} unreachable instruction(s)")
         for f in found[:40]:
             print("  " + f)
