@@ -265,6 +265,23 @@ void abea_align_kernel(const abea_read_desc* __restrict__ descs,
     float nx = e_ring[e_next & 127];
     float nkg, nkc; double nki;                         /* incoming k-mer (uniform) */
     { const abea_kpar_t t = k_ring[k_next & 127]; nkg = t.gpm; nkc = t.ck; nki = t.istd; }
+#ifdef ABEA_FIFO   /* experiment (tools/gen_fill_asm.py, ABEA_FIFO=1): no rings.  Lanes 52..63 of the event registers hold the next 24
+                    * events, lane 63's cell 1 first (a down move rotates the wave); their k-mer quads hold offsets 104..127 as they
+                    * always did.  The pending registers are what the next refill, 24 moves of a kind later, puts into those lanes. */
+#ifdef ABEA_NO_ASM
+#error "ABEA_FIFO is a layout of the asm loop"
+#endif
+    float px0, px1, kag, kac, kbg, kbc; double kai, kbi;
+    int e_cnt = 24, k_cnt = 24;
+    {
+        const int e_in = ll_e + 1, q = 2 * (63 - lane);
+        if (lane >= 52) { x1 = evm[min(e_in + q, E - 1)]; x0 = evm[min(e_in + q + 1, E - 1)]; }
+        px1 = evm[min(e_in + 24 + q, E - 1)]; px0 = evm[min(e_in + 24 + q + 1, E - 1)];
+        const abea_kpar_t ta = kpar[min(max(ll_k + 24 + 2 * lane, 0), K - 1)];
+        const abea_kpar_t tb = kpar[min(max(ll_k + 24 + 2 * lane + 1, 0), K - 1)];
+        kag = ta.gpm; kac = ta.ck; kai = ta.istd; kbg = tb.gpm; kbc = tb.ck; kbi = tb.istd;
+    }
+#endif
 
     /* trace accumulator: 4 bits per band shifted in from the right, COMPLEMENTED (see abea_fill.inc); bands 0,1:
      * only band 1 offset 50 = FROM_U */
@@ -418,7 +435,16 @@ void abea_align_kernel(const abea_read_desc* __restrict__ descs,
             uint4* u_trace = (uint4*)uni_p(trace);
             uint32_t s_best = (uint32_t)uni((int)__float_as_uint(best));
             int s_best_e = uni(best_e), s_best_llk = uni(best_llk);
-#ifdef ABEA_FILL_TIED_VOUTS      /* experiment: the loop state is bound to its physical registers, no entry/exit copies */
+#ifdef ABEA_FIFO
+#define ABEA_FILL_VOUTS \
+                  [Pf0] "+v"(Pf0), [Pf1] "+v"(Pf1), [x0] "+v"(x0), [x1] "+v"(x1), \
+                  [g0] "+v"(g0), [c0] "+v"(c0), [g1] "+v"(g1), [c1] "+v"(c1), \
+                  [px0] "+v"(px0), [px1] "+v"(px1), [kag] "+v"(kag), [kac] "+v"(kac), [kbg] "+v"(kbg), [kbc] "+v"(kbc), \
+                  [a1] "+v"(a1), [a2] "+v"(a2), [a3] "+v"(a3), [acc] "+v"(acc), [toff] "+v"(toff), \
+                  [i0] "+v"(i0), [i1] "+v"(i1), [kai] "+v"(kai), [kbi] "+v"(kbi), \
+                  [L0] "+v"(L0), [L1] "+v"(L1), [U0] "+v"(U0), [U1] "+v"(U1), [e_cnt] "+s"(e_cnt), [k_cnt] "+s"(k_cnt)
+#define ABEA_FILL_VINS [lane] "v"(lane)
+#elif defined(ABEA_FILL_TIED_VOUTS)      /* experiment: the loop state is bound to its physical registers, no entry/exit copies */
 #define ABEA_FILL_VOUTS ABEA_FILL_TIED_VOUTS
 #define ABEA_FILL_VINS ABEA_FILL_TIED_VINS
 #else

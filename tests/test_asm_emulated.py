@@ -34,7 +34,7 @@ def f64bits(x):
     return int(np.float64(x).view(np.uint64))
 
 
-def emulate_align(seq: bytes, means: np.ndarray, model, k: int, scale, shift, fill=None, walk=None):
+def emulate_align(seq: bytes, means: np.ndarray, model, k: int, scale, shift, fill=None, walk=None, fifo=False):
     """abea_pre_kernel + abea_align_kernel for one read; returns (pairs [n, 2] int32 in ascending order, info)."""
     L, E = len(seq), len(means)
     K = L - k + 1
@@ -109,6 +109,18 @@ def emulate_align(seq: bytes, means: np.ndarray, model, k: int, scale, shift, fi
 
     def bits64(a):
         return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+    if fifo:       # the ABEA_FIFO experiment: lanes 52..63 of the event registers hold the next 24 events (lane 63's cell 1 first);
+        # the pending registers hold what the next refill, 24 moves of a kind later, will put into those lanes
+        e_in = ll_e + 1
+        q = 2 * (63 - lane)
+        fl = lane >= 52
+        x1 = np.where(fl, ev(e_in + q), x1).astype(np.float32); x0 = np.where(fl, ev(e_in + q + 1), x0).astype(np.float32)
+        ka, kb = kp(np.maximum(ll_k + 24 + 2 * lane, 0)), kp(np.maximum(ll_k + 24 + 2 * lane + 1, 0))
+        for name, val in (("px1", bits(ev(e_in + 24 + q))), ("px0", bits(ev(e_in + 24 + q + 1))), ("kag", bits(ka["gpm"])),
+                          ("kac", bits(ka["ck"])), ("kbg", bits(kb["gpm"])), ("kbc", bits(kb["ck"]))):
+            w.bind_v(name, val)
+        w.bind_v("kai", bits64(ka["istd"]), wide=True); w.bind_v("kbi", bits64(kb["istd"]), wide=True)
+        w.sym.update(e_cnt=24, k_cnt=24)
     for name, val in (("Pf0", Pf0), ("Pf1", Pf1), ("x0", bits(x0)), ("x1", bits(x1)), ("g0", bits(p0["gpm"])), ("c0", bits(p0["ck"])),
                       ("g1", bits(p1["gpm"])), ("c1", bits(p1["ck"])), ("nkg", bits(nk["gpm"])), ("nkc", bits(nk["ck"])),
                       ("nx", bits(nx)), ("e_pend", bits(e_pend)), ("kpg", bits(kpend["gpm"])), ("kpc", bits(kpend["ck"])),
@@ -256,3 +268,26 @@ def test_a_planted_fault_in_the_statement_is_noticed():
     assert skewed != FILL
     with pytest.raises(AssertionError):
         check_against_oracle(seq, ev, model, k, fill=skewed)
+
+
+def test_fifo_experiment_reproduces_the_oracle():
+    """The ABEA_FIFO generator switch (no LDS rings: events and k-mers wait in lanes 52..63 and are topped up every 24 moves)
+    is not the shipped loop; it is kept correct here so that it can go straight to a GPU A/B."""
+    import subprocess
+    env = dict(os.environ, ABEA_FIFO="1")
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "gen_fill_asm.py")], env=env, stdout=subprocess.DEVNULL)
+    fill = asm_lint.statement(os.path.join(CSRC, "abea_fill_exp.inc"), "ABEA_FILL_ASM")
+    assert not any(ln.startswith("ds_") for ln in fill) and any("wave_ror:1" in ln for ln in fill)
+    k, model = MODEL
+    for seed, n_bases, epb, kind in ((1, 60, 2.0, ""), (4, 420, 2.2, ""), (9, 330, 3.0, ""), (12, 230, 2.0, "noise")):
+        rng = np.random.default_rng(seed)
+        seq, ev = synthetic_read(rng, model, k, n_bases, epb)
+        if kind == "noise":
+            ev["mean"] = rng.normal(90, 12, size=len(ev)).astype(np.float32)
+        scale, shift = orc.estimate_scalings(seq, model, k, ev)
+        o_pairs, o_diag = orc.align(seq, ev, model, k, scale, shift)
+        pairs, info = emulate_align(seq, ev["mean"], model, k, scale, shift, fill=fill, fifo=True)
+        assert np.float32(info["best"]) == np.float32(o_diag["max_score"]) and info["best_e"] == int(o_diag["best_event"])
+        assert info["n"] == int(o_diag["n_aligned"]) and info["max_gap"] == int(o_diag["max_gap"])
+        if len(o_pairs):
+            assert (pairs == o_pairs.view(np.int32).reshape(-1, 2)).all()

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Experiment helper: ONE process, one synthetic batch, several builds of the library (name=path ...): per build the
 abea_align_kernel time of a few launches, and every output bit compared with the first build's.
-  python tools/ab_quick.py ship=f5c_amd/libabea_hip.so pk=build/libabea_pk.so [--config r9_10k_8kb] [--launches 4]"""
+  python tools/ab_quick.py ship=f5c_amd/libabea_hip.so pk=build/libabea_pk.so [--config r9_10k_8kb] [--reads N] [--launches 4]"""
 import os, sys, hashlib
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -10,7 +10,9 @@ from f5c_amd import abea, synth, load_model_f32
 args = [a for a in sys.argv[1:] if "=" in a and not a.startswith("--")]
 cfg_name = sys.argv[sys.argv.index("--config") + 1] if "--config" in sys.argv else "r9_10k_8kb"
 launches = int(sys.argv[sys.argv.index("--launches") + 1]) if "--launches" in sys.argv else 4
-cfg = synth.CONFIGS[cfg_name]
+cfg = dict(synth.CONFIGS[cfg_name])
+if "--reads" in sys.argv:
+    cfg["n_reads"] = int(sys.argv[sys.argv.index("--reads") + 1])
 k, model = load_model_f32("tests/golden/r9.4_450bps.6mer.f32")
 b = synth.make_batch(cfg["n_reads"], model, k, seed=cfg["seed"], law=cfg["law"], workers=32)
 d = abea.AbeaContext.upload(b)

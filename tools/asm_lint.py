@@ -39,7 +39,8 @@ CAP = 8                       # ages saturate here (largest requirement is 5)
 
 # operands of the two statements that the compiler binds to VGPRs (everything else named %[x] is an SGPR / SGPR pair)
 VGPR_OPERANDS = {"Pf0", "Pf1", "x0", "x1", "g0", "c0", "g1", "c1", "nkg", "nkc", "nx", "e_pend", "kpg", "kpc", "a1", "a2", "a3",
-                 "acc", "toff", "i0", "i1", "nki", "kpi", "L0", "L1", "U0", "U1", "lane", "o_cv"}
+                 "acc", "toff", "i0", "i1", "nki", "kpi", "L0", "L1", "U0", "U1", "lane", "o_cv",
+                 "px0", "px1", "kag", "kac", "kai", "kbg", "kbc", "kbi"}      # the last row: the ABEA_FIFO experiment
 
 
 def statement(path, macro):
@@ -235,8 +236,9 @@ def step(x, st, report):
                     report(x, f"W1 {r} is the target of an outstanding {'LDS' if cls == 'lgkm' else 'global'} load "
                               f"({st.pend[(cls, r)]} later operation(s) of its class, no covering s_waitcnt)")
     reads = list(x.src) + list(x.lane_select)
-    if x.dpp or x.op == "v_writelane_b32":
+    if (x.dpp and "wave_ro" not in x.text) or x.op == "v_writelane_b32":
         reads += x.dst                                     # lanes without a source / the other 63 lanes keep the old value
+                                                           # (a wave rotation has a source for every lane)
     for r in reads:
         if r in st.undef:
             report(x, f"U1 {r} may be read before it is written")

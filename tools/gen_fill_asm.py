@@ -35,7 +35,14 @@ PK = os.environ.get("ABEA_PK", "0") in ("1", "2")
 # constant adds, the rounded skip score) are issued BETWEEN the steps of the emission chain instead of after it; needs 6 more
 # fixed VGPRs (a, a*a / lp and the second skip sum get registers of their own).
 PKS = os.environ.get("ABEA_PK", "0") == "2"
-EXPERIMENT = VB != 64 or TIED or PK
+# ABEA_FIFO=1: no LDS rings.  The idle lanes 52..63 hold the NEXT 24 events (in the event registers themselves: a down move
+# shifts them with wave_ror, so lane 63's cell 1 arrives in lane 0) and the next 24 k-mers (offsets 104..127, as before); every
+# 24th move of a kind overwrites those twelve lanes under an EXEC mask from registers that a global load filled 24 moves
+# earlier.  Per band this removes the ring read(s), the M0 set-up and the lgkmcnt wait: -3 instructions on a down move, -6 on a
+# right move; the refill trigger stays two scalar instructions (a countdown).
+FIFO = os.environ.get("ABEA_FIFO", "0") == "1"
+EXPERIMENT = VB != 64 or TIED or PK or FIFO
+assert not (FIFO and (PKS or TIED)), "ABEA_FIFO takes the registers of ABEA_PK=2 / is not wired to ABEA_TIED"
 assert VB % 2 == 0
 MF0, MF1, SHR, SHD = VB + 0, VB + 1, VB + 2, VB + 3
 TR = [dict(c0=VB + 4, c1=VB + 6, cs=VB + 8), dict(c0=VB + 10, c1=VB + 12, cs=VB + 14)]
@@ -66,6 +73,12 @@ VEND = VB + 58     # one past the last fixed VGPR
 if PKS:
     PA, PSQ, SK = VB + 58, VB + 60, [VB + 56, VB + 62]      # SK[0] takes the border variant's offset pair (unused in the interior loop)
     VEND = VB + 64
+if FIFO:
+    PX = VB + 58           # v[122:123]: pending events of the FIFO lanes (-> X1, X0)
+    PKA, PKB = KPEND, VB + 60   # v[96:99], v[124:127]: pending k-mer quads of the FIFO lanes' cell 0 / cell 1
+    VEND = VB + 64
+FIFO_EXEC_HI = "0xFFF00000"   # lanes 52..63
+DPP_ROR = "wave_ror:1 row_mask:0xf bank_mask:0xf"
 TIED_HOME = {"L0": TR[1]['c0'], "L1": TR[1]['c1'], "U1": TR[1]['cs'], "U0": TR[0]['c0']}   # exit homes of the row doubles
 BORDER = False     # generator mode: True adds validity masks + the online end-point scan
 # extra per-cell 32-bit temps reuse the low halves of f64 temps where noted
@@ -301,13 +314,18 @@ def body(p, ml, m, rs):
     if m == 'R':
         c0q, inq = KQ[rs], KQ[(rs + 2) % 3]
         rs = (rs + 1) % 3                                    # roles after the move: cell 0 = old cell 1, cell 1 = old incoming
+        if FIFO:                                            # before ll_k moves: the refill wants the frame of the previous band
+            emit("s_sub_u32 %[k_cnt], %[k_cnt], 1")
+            emit(f"s_cbranch_scc1 krefill_{tag}_%=")
+            emit(f"kcont_{tag}_%=:")
         emit("s_add_u32 %[ll_k], %[ll_k], 1")
         emit(f"v_mov_b32_dpp {v(SHR)}, {v(MF0)} {DPP_SHL}")
         # lanes >= 50 are the k-mer FIFO and their "scores" are garbage; the only one a band cell ever reads is lane 50's
         # slot 0 = offset 100, through this shift into lane 49: pin THAT to -inf (the band ends at offset 99).  Round 2
         # masked slot 0 of every band with a v_cndmask; a down move never looks at it.
         emit(f"v_writelane_b32 {v(SHR)}, %[ninf], 49")
-        emit("s_waitcnt lgkmcnt(1)" if ml == 'D' else "s_waitcnt lgkmcnt(0)")     # incoming k-mer landed
+        if not FIFO:
+            emit("s_waitcnt lgkmcnt(1)" if ml == 'D' else "s_waitcnt lgkmcnt(0)")     # incoming k-mer landed
         # every offset takes the k-mer of the offset above: cell 0's quad slides down one lane INTO the incoming quad,
         # whose lane 63 keeps the pre-read incoming k-mer (DPP `old`); cell 1's quad becomes cell 0's by renaming
         for j in range(4):
@@ -315,16 +333,18 @@ def body(p, ml, m, rs):
         # k_addr = LDS address of the next incoming k-mer (bits 15:0) | its position in the 64-entry chunk (bits 31:26):
         # the add carries out exactly when a new chunk is entered, and the ring wrap is done there too — two scalar
         # instructions per move instead of four (every instruction of the loop costs one issue slot, SALU included)
-        emit("s_add_u32 %[k_addr], %[k_addr], 0x04000010")
-        emit(f"s_cbranch_scc1 krefill_{tag}_%=")
-        emit(f"kcont_{tag}_%=:")
-        # the next incoming k-mer lands in the old cell-0 quad (dead now); only LANE 63 of it matters (the DPP `old` lane of
-        # the next right move), so it is read with ds_read_addtid_b32 (LDS address = M0 + offset + 4*lane, no address VGPR,
-        # no VALU): M0 = k_addr - 252
-        emit("s_sub_u32 m0, %[k_addr], 252")
+        if not FIFO:
+            emit("s_add_u32 %[k_addr], %[k_addr], 0x04000010")
+            emit(f"s_cbranch_scc1 krefill_{tag}_%=")
+            emit(f"kcont_{tag}_%=:")
+            # the next incoming k-mer lands in the old cell-0 quad (dead now); only LANE 63 of it matters (the DPP `old` lane of
+            # the next right move), so it is read with ds_read_addtid_b32 (LDS address = M0 + offset + 4*lane, no address VGPR,
+            # no VALU): M0 = k_addr - 252
+            emit("s_sub_u32 m0, %[k_addr], 252")
         emit(f"v_cvt_f64_f32 {vp(T['c0'])}, {v(MF0)}")
-        for j in range(4):
-            emit(f"ds_read_addtid_b32 {v(KQ[(rs + 2) % 3] + j)} offset:{4 * j}")
+        if not FIFO:
+            for j in range(4):
+                emit(f"ds_read_addtid_b32 {v(KQ[(rs + 2) % 3] + j)} offset:{4 * j}")
         sh = SHR
         U = (T['c1'], T['cs']); L = (T['c0'], T['c1'])
         D = (Tp['c1'], Tp['cs']) if ml == 'R' else (Tp['c0'], Tp['c1'])
@@ -332,20 +352,28 @@ def body(p, ml, m, rs):
         if BORDER:                                          # the border masks need ll_e every band; the interior loop brings
             emit("s_add_u32 %[ll_e], %[ll_e], 1")           # it up to date at the tick (popcount of the recorded moves)
         emit(f"v_mov_b32_dpp {v(SHD)}, {v(MF1)} {DPP_SHR}")
-        emit("s_waitcnt lgkmcnt(4)" if ml == 'R' else "s_waitcnt lgkmcnt(0)")     # incoming event landed (a right move's four k-mer reads may still be out)
-        emit(f"v_mov_b32_dpp {v(NX)}, {v(X1)} {DPP_SHR}")
+        if FIFO:
+            emit("s_sub_u32 %[e_cnt], %[e_cnt], 1")
+            emit(f"s_cbranch_scc1 erefill_{tag}_%=")
+            emit(f"econt_{tag}_%=:")
+            emit(f"v_mov_b32_dpp {v(NX)}, {v(X1)} {DPP_ROR}")     # lane 0 <- lane 63's cell 1: the next event
+        else:
+            emit("s_waitcnt lgkmcnt(4)" if ml == 'R' else "s_waitcnt lgkmcnt(0)")     # incoming event landed (a right move's four k-mer reads may still be out)
+            emit(f"v_mov_b32_dpp {v(NX)}, {v(X1)} {DPP_SHR}")
         if PK and not BORDER:
             # lo result = src0's dword picked by op_sel[0], hi result = src1's dword picked by op_sel_hi[1]: X0 = NX, X1 = old X0
             emit(f"v_pk_mov_b32 {vp(X0)}, {vp(NX)}, {vp(X0)} op_sel:[0,0] op_sel_hi:[0,0]")
         else:
             emit(f"v_mov_b32 {v(X1)}, {v(X0)}")
             emit(f"v_mov_b32 {v(X0)}, {v(NX)}")
-        emit("s_add_u32 %[e_addr], %[e_addr], 0x04000004")  # LDS address of the next incoming event | position in chunk << 26
-        emit(f"s_cbranch_scc1 erefill_{tag}_%=")
-        emit(f"econt_{tag}_%=:")
-        emit("s_mov_b32 m0, %[e_addr]")                     # lane 0 (the DPP `old` lane of the next down move) reads ring[e_addr]
+        if not FIFO:
+            emit("s_add_u32 %[e_addr], %[e_addr], 0x04000004")  # LDS address of the next incoming event | position in chunk << 26
+            emit(f"s_cbranch_scc1 erefill_{tag}_%=")
+            emit(f"econt_{tag}_%=:")
+            emit("s_mov_b32 m0, %[e_addr]")                     # lane 0 (the DPP `old` lane of the next down move) reads ring[e_addr]
         emit(f"v_cvt_f64_f32 {vp(T['c0'])}, {v(MF0)}")
-        emit(f"ds_read_addtid_b32 {v(NX)}")
+        if not FIFO:
+            emit(f"ds_read_addtid_b32 {v(NX)}")
         sh = SHD
         U = (T['c0'], T['c1']); L = (T['cs'], T['c0'])
         D = (Tp['c0'], Tp['c1']) if ml == 'R' else (Tp['cs'], Tp['c0'])
@@ -498,7 +526,59 @@ def body(p, ml, m, rs):
     countdown()
     emit(f"s_branch rotret_{tag}_%=")
     # ---- out-of-line: ring refills
-    if m == 'R':
+    if FIFO and m == 'R':
+        c0q_in, c1q_in = KQ[(rs + 2) % 3], KQ[rs]             # rs is already the state AFTER the move: cell 0 / cell 1 quads before it
+        emit(f"krefill_{tag}_%=:")                       # 24 right moves since the last one: lanes 52..63 hold nothing useful
+        emit("s_waitcnt vmcnt(0)")
+        emit("s_mov_b32 exec_lo, 0")
+        emit(f"s_mov_b32 exec_hi, {FIFO_EXEC_HI}")
+        for q, pk in ((c0q_in, PKA), (c1q_in, PKB)):        # offsets 2*lane and 2*lane + 1 of the frame before this move
+            emit(f"v_mov_b64 {vp(q)}, {vp(pk)}")
+            emit(f"v_mov_b64 {vp(q + 2)}, {vp(pk + 2)}")
+        emit("s_add_u32 %[t0], %[ll_k], 24")              # the frame 24 right moves from now
+        emit(f"v_lshl_add_u32 {v(TMP)}, {v(LANE)}, 1, %[t0]")
+        emit(f"v_add_u32 {v(NX)}, 1, {v(TMP)}")
+        emit(f"v_min_i32 {v(TMP)}, %[Km1], {v(TMP)}")
+        emit(f"v_min_i32 {v(NX)}, %[Km1], {v(NX)}")
+        emit(f"v_lshlrev_b32 {v(TMP)}, 4, {v(TMP)}")
+        emit(f"v_lshlrev_b32 {v(NX)}, 4, {v(NX)}")
+        emit(f"global_load_dwordx4 {vq(PKA)}, {v(TMP)}, %[kpar]")
+        emit(f"global_load_dwordx4 {vq(PKB)}, {v(NX)}, %[kpar]")
+        emit("s_mov_b64 exec, -1")
+        emit("s_mov_b32 %[k_cnt], 23")
+        emit("s_nop 1")
+        emit(f"s_branch kcont_{tag}_%=")
+    elif FIFO:
+        emit(f"erefill_{tag}_%=:")                       # 24 down moves since the last one
+        emit("s_waitcnt vmcnt(0)")
+        if BORDER:
+            emit("s_mov_b32 %[t0], %[ll_e]")                # already moved: the event entering with this band
+        else:
+            emit("s_flbit_i32_b32 %[t0], %[cnt]")
+            emit("s_sub_u32 %[t0], %[per], %[t0]")          # done + 1
+            emit("s_bcnt1_i32_b32 %[t1], %[cnt]")           # rights + 1
+            emit("s_sub_u32 %[t0], %[t0], %[t1]")           # downs since the tick, this band not included
+            emit("s_add_u32 %[t0], %[t0], %[ll_e]")
+            emit("s_add_u32 %[t0], %[t0], 1")               # the event entering with this band
+        emit("s_mov_b32 exec_lo, 0")
+        emit(f"s_mov_b32 exec_hi, {FIFO_EXEC_HI}")
+        emit(f"v_mov_b32 {v(X1)}, {v(PX)}")                 # lane 63: events t0, t0+1 (cell 1, cell 0); lane 62: t0+2, t0+3; ...
+        emit(f"v_mov_b32 {v(X0)}, {v(PX + 1)}")
+        emit("s_add_u32 %[t0], %[t0], 24")
+        emit(f"v_sub_u32 {v(TMP)}, 63, {v(LANE)}")
+        emit(f"v_lshl_add_u32 {v(TMP)}, {v(TMP)}, 1, %[t0]")
+        emit(f"v_add_u32 {v(NX)}, 1, {v(TMP)}")
+        emit(f"v_min_i32 {v(TMP)}, %[Em1], {v(TMP)}")
+        emit(f"v_min_i32 {v(NX)}, %[Em1], {v(NX)}")
+        emit(f"v_lshlrev_b32 {v(TMP)}, 2, {v(TMP)}")
+        emit(f"v_lshlrev_b32 {v(NX)}, 2, {v(NX)}")
+        emit(f"global_load_dword {v(PX)}, {v(TMP)}, %[evm]")
+        emit(f"global_load_dword {v(PX + 1)}, {v(NX)}, %[evm]")
+        emit("s_mov_b64 exec, -1")
+        emit("s_mov_b32 %[e_cnt], 23")
+        emit("s_nop 1")
+        emit(f"s_branch econt_{tag}_%=")
+    elif m == 'R':
         emit(f"krefill_{tag}_%=:")                       # entering chunk c = k_next >> 6: land chunk c+1, fetch c+2
         emit("s_waitcnt vmcnt(0)")
         emit("s_add_u32 %[t0], %[ll_k], 128")               # k_next = ll_k + 128 (k-mer entering at offset 127)
@@ -624,12 +704,18 @@ def main():
         (A0, "a1"), (A1, "a2"), (A2, "a3"), (ACC, "acc"), (TOFF, "toff"), (LANE, "lane"),
     ]
     wide = [(I0, "i0"), (I1, "i1"), (NK + 2, "nki"), (KPEND + 2, "kpi")]
+    if FIFO:       # the incoming quad and NX are dead between bands; the pending refill registers travel instead
+        ent = [e for e in ent if e[1] not in ("nkg", "nkc", "nx", "e_pend", "kpg", "kpc")]
+        ent += [(PX, "px1"), (PX + 1, "px0"), (PKA, "kag"), (PKA + 1, "kac"), (PKB, "kbg"), (PKB + 1, "kbc")]
+        wide = [(I0, "i0"), (I1, "i1"), (PKA + 2, "kai"), (PKB + 2, "kbi")]
     head = []
     if not TIED:
         for reg, name in ent:
             head.append(f"v_mov_b32 {v(reg)}, %[{name}]")
         for reg, name in wide + [(TR[1]['c0'], "L0"), (TR[1]['c1'], "L1"), (TR[1]['cs'], "U1")]:
             head.append(f"v_mov_b64 {vp(reg)}, %[{name}]")
+    if FIFO:       # the incoming quad's lane 63 keeps what it has on every right move: give it a defined value once
+        head += [f"v_mov_b64 {vp(NK)}, 0", f"v_mov_b64 {vp(NK + 2)}, 0"]
     head += [f"v_mov_b32 {v(NINF)}, 0xff800000", f"v_mov_b32 {v(SHR)}, 0xff800000", f"v_mov_b32 {v(SHD)}, 0xff800000",
              f"v_lshlrev_b32 {v(O0)}, 1, {v(LANE)}", f"v_lshl_or_b32 {v(O1)}, {v(LANE)}, 1, 1",
              "s_cmp_eq_u32 %[mode], 0", "s_cbranch_scc0 border_start_%="]

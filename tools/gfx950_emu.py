@@ -233,7 +233,7 @@ class Wave:
             op = parts[0]
             rest = parts[1] if len(parts) > 1 else ""
             mods = ""
-            m = re.search(r"\s(wave_sh[lr]:\d+|offset:\d+|lgkmcnt|vmcnt)", " " + rest)
+            m = re.search(r"\s(wave_sh[lr]:\d+|wave_ro[lr]:\d+|offset:\d+|lgkmcnt|vmcnt)", " " + rest)
             if op in ("s_waitcnt",):
                 ops = []
             else:
@@ -344,6 +344,10 @@ class Wave:
             new[1:] = src[:-1]
         elif "wave_shl:1" in m:
             new[:-1] = src[1:]
+        elif "wave_ror:1" in m:                           # rotate towards higher lanes: lane 0 <- lane 63
+            new = np.roll(src, 1)
+        elif "wave_rol:1" in m:
+            new = np.roll(src, -1)
         else:
             raise NotImplementedError("dpp " + m)
         self.wr_v(o[0], new)
@@ -379,6 +383,7 @@ class Wave:
         sh = self._vec(self.rd32(o[3])).astype(np.uint64) & np.uint64(31)
         self.wr_v(o[0], ((((hi << np.uint64(32)) | lo) >> sh) & np.uint64(M32)).astype(np.uint32))
     def i_v_add_u32(self, o, m): self.wr_v(o[0], self._vec(self.rd32(o[1])) + self._vec(self.rd32(o[2])))
+    def i_v_sub_u32(self, o, m): self.wr_v(o[0], self._vec(self.rd32(o[1])) - self._vec(self.rd32(o[2])))
     def i_v_subrev_u32(self, o, m): self.wr_v(o[0], self._vec(self.rd32(o[2])) - self._vec(self.rd32(o[1])))
     def i_v_min_i32(self, o, m):
         self.wr_v(o[0], np.minimum(self._vec(self.rd32(o[1])).astype(np.int32), self._vec(self.rd32(o[2])).astype(np.int32)).astype(np.uint32))
@@ -421,6 +426,8 @@ class Wave:
 
     def _gather(self, mem, addr, ndw):
         out = []
+        act = self._lanebits(self.exec)
+        addr = np.where(act, addr, 0)                      # inactive lanes make no access
         for j in range(ndw):
             a = addr + 4 * j
             w = (mem[a].astype(np.uint32) | (mem[a + 1].astype(np.uint32) << 8) | (mem[a + 2].astype(np.uint32) << 16)
