@@ -270,14 +270,21 @@ def test_a_planted_fault_in_the_statement_is_noticed():
         check_against_oracle(seq, ev, model, k, fill=skewed)
 
 
-def test_fifo_experiment_reproduces_the_oracle():
-    """The ABEA_FIFO generator switch (no LDS rings: events and k-mers wait in lanes 52..63 and are topped up every 24 moves)
-    is not the shipped loop; it is kept correct here so that it can go straight to a GPU A/B."""
+def test_next_round_candidates_reproduce_the_oracle():
+    """Two generator switches that are NOT the shipped loop are kept correct here so that they can go straight to a GPU A/B:
+    ABEA_FIFO (no LDS rings: events and k-mers wait in lanes 52..63 and are topped up every 24 moves) and ABEA_WALK2 (the
+    step loop of the walk split by trace-group half, 46.9 -> 42.6 scalar instructions per step)."""
     import subprocess
-    env = dict(os.environ, ABEA_FIFO="1")
+    env = dict(os.environ, ABEA_FIFO="1", ABEA_WALK2="1")
     subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "gen_fill_asm.py")], env=env, stdout=subprocess.DEVNULL)
     fill = asm_lint.statement(os.path.join(CSRC, "abea_fill_exp.inc"), "ABEA_FILL_ASM")
+    walk2 = asm_lint.statement(os.path.join(CSRC, "abea_walk_exp.inc"), "ABEA_WALK_ASM")
     assert not any(ln.startswith("ds_") for ln in fill) and any("wave_ror:1" in ln for ln in fill)
+    assert any(ln.startswith("step_hi") for ln in walk2) and len(walk2) > len(WALK)
+    for path, macro in ((os.path.join(CSRC, "abea_fill_exp.inc"), "ABEA_FILL_ASM"), (os.path.join(CSRC, "abea_walk_exp.inc"), "ABEA_WALK_ASM")):
+        found, _, dead = asm_lint.lint(asm_lint.statement(path, macro), "exp", asm_lint.undefined_at_entry(path, macro))
+        found = [f for f in found if "s[90:91]" not in f]       # the walk's first step always loads s[88:91] (asm_lint.WAIVERS)
+        assert not found and dead == 0, found[:5]
     k, model = MODEL
     for seed, n_bases, epb, kind in ((1, 60, 2.0, ""), (4, 420, 2.2, ""), (9, 330, 3.0, ""), (12, 230, 2.0, "noise")):
         rng = np.random.default_rng(seed)
@@ -286,7 +293,7 @@ def test_fifo_experiment_reproduces_the_oracle():
             ev["mean"] = rng.normal(90, 12, size=len(ev)).astype(np.float32)
         scale, shift = orc.estimate_scalings(seq, model, k, ev)
         o_pairs, o_diag = orc.align(seq, ev, model, k, scale, shift)
-        pairs, info = emulate_align(seq, ev["mean"], model, k, scale, shift, fill=fill, fifo=True)
+        pairs, info = emulate_align(seq, ev["mean"], model, k, scale, shift, fill=fill, walk=walk2, fifo=True)
         assert np.float32(info["best"]) == np.float32(o_diag["max_score"]) and info["best_e"] == int(o_diag["best_event"])
         assert info["n"] == int(o_diag["n_aligned"]) and info["max_gap"] == int(o_diag["max_gap"])
         if len(o_pairs):

@@ -41,7 +41,12 @@ PKS = os.environ.get("ABEA_PK", "0") == "2"
 # earlier.  Per band this removes the ring read(s), the M0 set-up and the lgkmcnt wait: -3 instructions on a down move, -6 on a
 # right move; the refill trigger stays two scalar instructions (a countdown).
 FIFO = os.environ.get("ABEA_FIFO", "0") == "1"
-EXPERIMENT = VB != 64 or TIED or PK or FIFO
+# ABEA_WALK2=1: the traceback walk with fewer scalar instructions per step (46.9 -> 42.6): the step loop exists twice, once for the
+# upper 16 bands of a trace group (from-codes in s[90:91]) and once for the lower 16 (s[88:89]), so the half is not selected
+# per step; the band-move word is kept shifted to the current band; the gap counter is reset with a multiply; the band
+# index of the lower-left corner is updated through a popcount.
+WALK2 = os.environ.get("ABEA_WALK2", "0") == "1"
+EXPERIMENT = VB != 64 or TIED or PK or FIFO or WALK2
 assert not (FIFO and (PKS or TIED)), "ABEA_FIFO takes the registers of ABEA_PK=2 / is not wired to ABEA_TIED"
 assert VB % 2 == 0
 MF0, MF1, SHR, SHD = VB + 0, VB + 1, VB + 2, VB + 3
@@ -815,6 +820,10 @@ def gen_walk():
     e(f"v_readlane_b32 s92, {CW[0]}, 50")                                  # band moves of this group ...
     e(f"v_readlane_b32 s93, {CW[1]}, 50")                                  # ... and of the group below
     e(f"s_mov_b32 {LP}, -1")
+    if WALK2:
+        _walk2_loops(e, locals())
+        _finish_walk(o)
+        return
     e("step_%=:")
     e(f"s_sub_u32 {T}, {K}, {LLK}")                                         # band offset of (e,k)
     e(f"s_lshr_b32 {U}, {T}, 1")
@@ -894,6 +903,102 @@ def gen_walk():
     e(f"s_mov_b32 %[o_cwd], {CWD}"); e(f"s_mov_b32 %[o_sh2], {SH2}"); e(f"s_mov_b32 %[o_nfl], {NFL}")
     e(f"s_mov_b32 %[o_maxgap], {MAXGAP}"); e(f"s_mov_b32 %[o_reloads], {RLD}")
     e(f"v_mov_b32 %[o_cv], {CV}")
+    _finish_walk(o)
+
+
+def _walk2_loops(e, r):
+    """The two step loops of ABEA_WALK2 and their out-of-line blocks; r = gen_walk's register names."""
+    K, E, BI, LLK, G, GAP, MAXGAP, CWD, SH2, NFL, LP, DK = (r[n] for n in "K E BI LLK G GAP MAXGAP CWD SH2 NFL LP DK".split())
+    TLO, THI, MV, T64, T64LO, T, U, X, Y = (r[n] for n in "TLO THI MV T64 T64LO T U X Y".split())
+    WC, WR, NWC, RLD, CW, NXG, CV, VT, L16, L4, W = (r[n] for n in "WC WR NWC RLD CW NXG CV VT L16 L4 W".split())
+    # band-move word shifted so that bit 0 = move(b), bit 1 = move(b-1) for the current band; kept so by every step
+    e(f"s_sub_u32 {T}, 31, {BI}"); e(f"s_lshr_b64 {MV}, {MV}, {T}")
+    e(f"s_bitcmp1_b32 {BI}, 4")
+    e("s_cbranch_scc0 step_lo_%=")
+    for half in ("hi", "lo"):
+        e(f"step_{half}_%=:")
+        e(f"s_sub_u32 {T}, {K}, {LLK}")                                     # band offset of (e,k)
+        e(f"s_lshr_b32 {U}, {T}, 1")
+        e(f"s_cmp_eq_u32 {U}, {LP}")
+        e(f"s_cbranch_scc0 reload_lp_{half}_%=")
+        e(f"step_cont_{half}_%=:")
+        e(f"s_and_b32 {T}, {T}, 1"); e(f"s_lshl_b32 {T}, {T}, 1")
+        e(f"s_xor_b32 {X}, {BI}, 7")
+        e(f"s_lshl2_add_u32 {T}, {X}, {T}")                                 # bit position in the 128 bits; a 64-bit shift takes it mod 64
+        e(f"s_lshr_b64 {T64}, {THI if half == 'hi' else TLO}, {T}")
+        e(f"s_and_b32 {U}, {T64LO}, 3")
+        e(f"s_min_u32 {U}, {U}, 2")                                          # from code: 0 D, 1 U, 2 L (3 = L and U tie)
+        e(f"s_and_b32 {T}, s92, 3")                                          # bit0 = move(b), bit1 = move(b-1)
+        e(f"s_lshl_b32 {X}, {U}, {SH2}"); e(f"s_or_b32 {CWD}, {CWD}, {X}"); e(f"s_add_u32 {SH2}, {SH2}, 2")
+        e(f"s_bitcmp1_b32 {SH2}, 5")
+        e(f"s_cbranch_scc1 flush_{half}_%=")
+        e(f"flush_ret_{half}_%=:")
+        e(f"s_and_b32 {DK}, {U}, 1"); e(f"s_xor_b32 {DK}, {DK}, 1")           # D,L step the k-mer
+        e(f"s_lshr_b32 {X}, {U}, 1")                                         # isL
+        e(f"s_xor_b32 {Y}, {X}, 1")                                          # de: D,U step the event
+        e(f"s_add_u32 {GAP}, {GAP}, 1"); e(f"s_mul_i32 {GAP}, {GAP}, {X}")    # gap = isL ? gap + 1 : 0
+        e(f"s_max_i32 {MAXGAP}, {MAXGAP}, {GAP}")
+        e(f"s_and_b32 {U}, {DK}, {Y}")                                       # isD
+        e(f"s_lshl1_add_u32 {X}, {U}, 1")                                    # 1 | isD << 1: move(b-1) counts only on a diagonal step
+        e(f"s_and_b32 {T}, {T}, {X}"); e(f"s_bcnt1_i32_b32 {T}, {T}")
+        e(f"s_sub_u32 {LLK}, {LLK}, {T}")
+        e(f"s_sub_u32 {K}, {K}, {DK}"); e("s_cbranch_scc1 done_%=")          # borrow: ran off k-mer 0
+        e(f"s_sub_u32 {E}, {E}, {Y}"); e("s_cbranch_scc1 done_%=")           # borrow: ran off event 0
+        e(f"s_add_u32 {T}, {DK}, {Y}")
+        e(f"s_lshr_b64 {MV}, {MV}, {T}")                                     # the move word follows the band
+        e(f"s_sub_u32 {BI}, {BI}, {T}")
+        if half == "hi":
+            e(f"s_bitcmp1_b32 {BI}, 4")                                      # 16..31: still the upper half (no borrow possible from >= 16)
+            e("s_cbranch_scc1 step_hi_%=")                                  # else fall into the lower-half loop
+        else:
+            e("s_cbranch_scc0 step_lo_%=")                                  # no borrow: still in this 32-band group
+    e(f"s_add_u32 {BI}, {BI}, 32"); e(f"s_sub_u32 {G}, {G}, 1")
+    e("s_waitcnt vmcnt(0)")
+    for a, b in zip(CW, NXG):
+        e(f"v_mov_b32 {a}, {b}")
+    e(f"s_mov_b32 {WC}, {NWC}"); e(f"s_mov_b32 {WR}, {W}")
+    e("s_branch group_top_%=")
+    for half in ("hi", "lo"):
+        e(f"reload_lp_{half}_%=:")
+        e(f"s_mov_b32 {LP}, {U}")
+        e(f"s_sub_i32 {X}, {U}, {WC}"); e(f"s_abs_i32 {X}, {X}")
+        e(f"s_cmp_le_u32 {X}, {WR}")
+        e(f"s_cbranch_scc0 full_reload_{half}_%=")
+        e(f"reload_ret_{half}_%=:")
+        e(f"v_readlane_b32 s88, {CW[0]}, {U}"); e(f"v_readlane_b32 s89, {CW[1]}, {U}")
+        e(f"v_readlane_b32 s90, {CW[2]}, {U}"); e(f"v_readlane_b32 s91, {CW[3]}, {U}")
+        e(f"s_branch step_cont_{half}_%=")
+        e(f"full_reload_{half}_%=:")
+        e(f"s_lshl_b32 {X}, {G}, 10")
+        e(f"s_mov_b64 {T64}, %[trace]"); e(f"s_add_u32 s94, s94, {X}"); e("s_addc_u32 s95, s95, 0")
+        e("s_waitcnt vmcnt(0)")
+        e(f"global_load_dwordx4 v[{VB}:{VB + 3}], {L16}, {T64}")
+        e(f"s_mov_b32 {WR}, 64"); e(f"s_add_u32 {RLD}, {RLD}, 1")
+        e("s_waitcnt vmcnt(0)")
+        e(f"s_branch reload_ret_{half}_%=")
+        e(f"flush_{half}_%=:")
+        e(f"s_and_b32 {X}, {NFL}, 63")
+        e(f"v_cmp_eq_u32 vcc, {X}, %[lane]")
+        e(f"v_mov_b32 {VT}, {CWD}")
+        e(f"s_mov_b32 {CWD}, 0"); e(f"s_mov_b32 {SH2}, 0")
+        e(f"v_cndmask_b32 {CV}, {CV}, {VT}, vcc")
+        e(f"s_add_u32 {NFL}, {NFL}, 1")
+        e(f"s_and_b32 {X}, {NFL}, 63")
+        e(f"s_cbranch_scc1 flush_ret_{half}_%=")
+        e(f"s_sub_u32 {X}, {NFL}, 64"); e(f"s_lshl_b32 {X}, {X}, 2")
+        e(f"v_add_u32 {VT}, {X}, {L4}")
+        e("s_nop 1")
+        e(f"global_store_dword {VT}, {CV}, %[codes]")
+        e(f"s_branch flush_ret_{half}_%=")
+    e("done_%=:")
+    e("s_waitcnt vmcnt(0)")
+    e(f"s_add_u32 %[last_k], {K}, {DK}")
+    e(f"s_mov_b32 %[o_cwd], {CWD}"); e(f"s_mov_b32 %[o_sh2], {SH2}"); e(f"s_mov_b32 %[o_nfl], {NFL}")
+    e(f"s_mov_b32 %[o_maxgap], {MAXGAP}"); e(f"s_mov_b32 %[o_reloads], {RLD}")
+    e(f"v_mov_b32 %[o_cv], {CV}")
+
+
+def _finish_walk(o):
     text = "\n".join(f'    "{ln}\\n\\t"' for ln in o)
     clob = ", ".join([f'"s{i}"' for i in range(72, 100)] + [f'"v{i}"' for i in range(VB, VB + 12)])
     inc = f"""/* GENERATED by tools/gen_fill_asm.py — do not edit. Scalar-unit traceback walk. */

@@ -307,6 +307,7 @@ class Wave:
         a, b = _s32(self.rd32(o[1])), _s32(self.rd32(o[2])); self.wr_s(o[0], min(a, b)); self.scc = int(a < b)
     def i_s_max_i32(self, o, m):
         a, b = _s32(self.rd32(o[1])), _s32(self.rd32(o[2])); self.wr_s(o[0], max(a, b)); self.scc = int(a > b)
+    def i_s_mul_i32(self, o, m): self.wr_s(o[0], (_s32(self.rd32(o[1])) * _s32(self.rd32(o[2]))) & M32)
     def i_s_abs_i32(self, o, m):
         r = abs(_s32(self.rd32(o[1]))) & M32; self.wr_s(o[0], r); self.scc = int(r != 0)
     def i_s_cmp_eq_u32(self, o, m): self.scc = int(self.rd32(o[0]) == self.rd32(o[1]))
