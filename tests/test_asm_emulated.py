@@ -298,3 +298,20 @@ def test_next_round_candidates_reproduce_the_oracle():
         assert info["n"] == int(o_diag["n_aligned"]) and info["max_gap"] == int(o_diag["max_gap"])
         if len(o_pairs):
             assert (pairs == o_pairs.view(np.int32).reshape(-1, 2)).all()
+
+
+def test_emulated_statements_on_a_real_read_against_the_reference_golden():
+    """A real nanopore read of the reference's test set (tests/golden/ecoli_events.npz, the shortest: 1234 bases, 2047 events):
+    the emulated statements give the oracle's pair list and the n_aligned_events the REFERENCE printed in adaptive.exp."""
+    k, model = MODEL
+    z = np.load(os.path.join(ROOT, "tests", "golden", "ecoli_events.npz"))
+    i = int(np.argmin(np.diff(z["ev_ptr"])))
+    seq = bytes(z["seq"][z["seq_ptr"][i]:z["seq_ptr"][i + 1]])
+    ev = np.zeros(int(z["ev_ptr"][i + 1] - z["ev_ptr"][i]), dtype=EVENT_DT)
+    ev["mean"] = z["mean"][z["ev_ptr"][i]:z["ev_ptr"][i + 1]]
+    scale, shift = float(z["scale"][i]), float(z["shift"][i])
+    o_pairs, o_diag = orc.align(seq, ev, model, k, scale, shift)
+    pairs, info = emulate_align(seq, ev["mean"], model, k, scale, shift)
+    assert info["n"] == int(z["printed_n"][i]) == int(o_diag["n_aligned"])
+    assert len(o_pairs) and (pairs == o_pairs.view(np.int32).reshape(-1, 2)).all()
+    assert np.float32(info["best"]) == np.float32(o_diag["max_score"])
