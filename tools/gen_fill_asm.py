@@ -35,6 +35,11 @@ PK = os.environ.get("ABEA_PK", "0") in ("1", "2")
 # constant adds, the rounded skip score) are issued BETWEEN the steps of the emission chain instead of after it; needs 6 more
 # fixed VGPRs (a, a*a / lp and the second skip sum get registers of their own).
 PKS = os.environ.get("ABEA_PK", "0") == "2"
+# ABEA_SCHED=1: the schedule of ABEA_PK=2 with plain instructions (no packed f32): the independent work between the steps of the
+# emission chain.  Nothing for four waves per SIMD (the other waves fill the gaps anyway); meant for a wave alone on its SIMD.
+SCHED = os.environ.get("ABEA_SCHED", "0") == "1"
+if SCHED:
+    PK = PKS = True
 # ABEA_FIFO=1: no LDS rings.  The idle lanes 52..63 hold the NEXT 24 events (in the event registers themselves: a down move
 # shifts them with wave_ror, so lane 63's cell 1 arrives in lane 0) and the next 24 k-mers (offsets 104..127, as before); every
 # 24th move of a kind overwrites those twelve lanes under an EXEC mask from registers that a global load filled 24 moves
@@ -194,7 +199,10 @@ def cells_pks(D, U, L, quads, pre):
     A += [f"v_cvt_f64_f32 {vp(LPD[j])}, {v(PA + j)}" for j in (0, 1)]
     A += [f"v_mul_f64 {vp(LPD[j])}, {vp(LPD[j])}, {vp(ii[j])}" for j in (0, 1)]
     A += [f"v_cvt_f32_f64 {v(PA + j)}, {vp(LPD[j])}" for j in (0, 1)]
-    A += [f"v_pk_mul_f32 {vp(PSQ)}, {vp(PA)}, {vp(PA)}"]
+    if SCHED:
+        A += [f"v_mul_f32 {v(PSQ + j)}, {v(PA + j)}, {v(PA + j)}" for j in (0, 1)]
+    else:
+        A += [f"v_pk_mul_f32 {vp(PSQ)}, {vp(PA)}, {vp(PA)}"]
     A += [f"v_fma_f32 {v(PSQ + j)}, -0.5, {v(PSQ + j)}, {v(ck[j])}" for j in (0, 1)]
     A += [f"v_cvt_f64_f32 {vp(LPD[j])}, {v(PSQ + j)}" for j in (0, 1)]
     B = list(pre)
@@ -210,6 +218,10 @@ def cells_pks(D, U, L, quads, pre):
             ops.append(f"v_cvt_f32_f64 {v(base + j)}, {vp(src[j])}")
     for j in (0, 1):
         ops.append(f"v_max3_f32 {v(MF0 + j)}, {v(TD[0] + j)}, {v(TU[0] + j)}, {v(SK[0] + j)}")
+    if SCHED:
+        ops += [f"v_sub_f32 {v(TD[1] + j)}, {v(TU[0] + j)}, {v(TD[0] + j)}" for j in (0, 1)]
+        ops += [f"v_sub_f32 {v(TU[1] + j)}, {v(SK[0] + j)}, {v(MF0 + j)}" for j in (0, 1)]
+        return ops
     ops.append(f"v_pk_add_f32 {vp(TD[1])}, {vp(TU[0])}, {vp(TD[0])} neg_lo:[0,1] neg_hi:[0,1]")     # su - sd
     ops.append(f"v_pk_add_f32 {vp(TU[1])}, {vp(SK[0])}, {vp(MF0)} neg_lo:[0,1] neg_hi:[0,1]")       # sl - max
     return ops
@@ -365,7 +377,7 @@ def body(p, ml, m, rs):
         else:
             emit("s_waitcnt lgkmcnt(4)" if ml == 'R' else "s_waitcnt lgkmcnt(0)")     # incoming event landed (a right move's four k-mer reads may still be out)
             emit(f"v_mov_b32_dpp {v(NX)}, {v(X1)} {DPP_SHR}")
-        if PK and not BORDER:
+        if PK and not SCHED and not BORDER:
             # lo result = src0's dword picked by op_sel[0], hi result = src1's dword picked by op_sel_hi[1]: X0 = NX, X1 = old X0
             emit(f"v_pk_mov_b32 {vp(X0)}, {vp(NX)}, {vp(X0)} op_sel:[0,0] op_sel_hi:[0,0]")
         else:
