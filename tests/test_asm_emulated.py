@@ -271,11 +271,12 @@ def test_a_planted_fault_in_the_statement_is_noticed():
 
 
 def test_next_round_candidates_reproduce_the_oracle():
-    """Two generator switches that are NOT the shipped loop are kept correct here so that they can go straight to a GPU A/B:
-    ABEA_FIFO (no LDS rings: events and k-mers wait in lanes 52..63 and are topped up every 24 moves) and ABEA_WALK2 (the
-    step loop of the walk split by trace-group half, 46.9 -> 42.6 scalar instructions per step)."""
+    """Generator switches that are NOT the shipped loop are kept correct here so that they can go straight to a GPU A/B:
+    ABEA_FIFO (no LDS rings: events and k-mers wait in lanes 52..63 and are topped up every 24 moves), ABEA_WALK2 (the step
+    loop of the walk split by trace-group half, 46.9 -> 42.6 scalar instructions per step) and ABEA_EARLY (the move decision
+    issued ahead of the trace packing)."""
     import subprocess
-    env = dict(os.environ, ABEA_FIFO="1", ABEA_WALK2="1")
+    env = dict(os.environ, ABEA_FIFO="1", ABEA_WALK2="1", ABEA_EARLY="1")
     subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "gen_fill_asm.py")], env=env, stdout=subprocess.DEVNULL)
     fill = asm_lint.statement(os.path.join(CSRC, "abea_fill_exp.inc"), "ABEA_FILL_ASM")
     walk2 = asm_lint.statement(os.path.join(CSRC, "abea_walk_exp.inc"), "ABEA_WALK_ASM")

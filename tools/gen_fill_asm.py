@@ -38,6 +38,10 @@ PKS = os.environ.get("ABEA_PK", "0") == "2"
 # ABEA_SCHED=1: the schedule of ABEA_PK=2 with plain instructions (no packed f32): the independent work between the steps of the
 # emission chain.  Nothing for four waves per SIMD (the other waves fill the gaps anyway); meant for a wave alone on its SIMD.
 SCHED = os.environ.get("ABEA_SCHED", "0") == "1"
+# ABEA_EARLY=1: the move decision of the next band (v_readlane of the lower-left score, v_cmp with the upper-right one) is
+# issued right after the two v_max3 instead of behind the trace packing: the scalar test and branch at the end of the band no
+# longer wait for the compare.  Same instructions, other order (interior loop, plain cell_ops path).
+EARLY = os.environ.get("ABEA_EARLY", "0") == "1"
 if SCHED:
     PK = PKS = True
 # ABEA_FIFO=1: no LDS rings.  The idle lanes 52..63 hold the NEXT 24 events (in the event registers themselves: a down move
@@ -51,7 +55,8 @@ FIFO = os.environ.get("ABEA_FIFO", "0") == "1"
 # per step; the band-move word is kept shifted to the current band; the gap counter is reset with a multiply; the band
 # index of the lower-left corner is updated through a popcount.
 WALK2 = os.environ.get("ABEA_WALK2", "0") == "1"
-EXPERIMENT = VB != 64 or TIED or PK or FIFO or WALK2
+EXPERIMENT = VB != 64 or TIED or PK or FIFO or WALK2 or EARLY
+assert not (EARLY and PK), "ABEA_EARLY re-orders the plain cell_ops tail"
 assert not (FIFO and (PKS or TIED)), "ABEA_FIFO takes the registers of ABEA_PK=2 / is not wired to ABEA_TIED"
 assert VB % 2 == 0
 MF0, MF1, SHR, SHD = VB + 0, VB + 1, VB + 2, VB + 3
@@ -426,6 +431,14 @@ def body(p, ml, m, rs):
         tail0, tail1 = ops0[-2:], ops1[-2:]
         for ins in interleave(ops0[:-3], ops1[:-3]):
             emit(ins)
+    elif EARLY:
+        il = interleave(ops0, ops1)
+        for ins in il[:-4]:                                  # ... v_max3 cell 0, v_max3 cell 1
+            emit(ins)
+        emit(f"v_readlane_b32 %[t0], {v(MF0)}, 0")          # mf0 written two instructions ago
+        emit(il[-4]); emit(il[-3])                          # the two [su < sd] differences
+        emit(f"v_cmp_lt_f32 vcc, %[t0], {v(MF1)}")          # t0 written three instructions ago
+        emit(il[-2]); emit(il[-1])                          # the two [sl < max] differences
     else:
         for ins in interleave(ops0, ops1):
             emit(ins)
@@ -496,10 +509,12 @@ def body(p, ml, m, rs):
         b_l1, b_u1, b_l0, b_u0 = (TU[1] + 1, TD[1] + 1, TU[1], TD[1]) if PK else (TD[1], F[1], TD[0], F[0])
         emit(f"v_alignbit_b32 {v(ACC)}, {v(ACC)}, {v(b_l1)}, 31")
         emit(f"v_alignbit_b32 {v(ACC)}, {v(ACC)}, {v(b_u1)}, 31")
-        emit(f"v_readlane_b32 %[t0], {v(MF0)}, 0")          # mf0 was written 3 instructions ago
+        if not EARLY:
+            emit(f"v_readlane_b32 %[t0], {v(MF0)}, 0")      # mf0 was written 3 instructions ago
         emit(f"v_alignbit_b32 {v(ACC)}, {v(ACC)}, {v(b_l0)}, 31")
         emit(f"v_alignbit_b32 {v(ACC)}, {v(ACC)}, {v(b_u0)}, 31")
-        emit(f"v_cmp_lt_f32 vcc, %[t0], {v(MF1)}")          # t0 written 3 instructions ago
+        if not EARLY:
+            emit(f"v_cmp_lt_f32 vcc, %[t0], {v(MF1)}")      # t0 written 3 instructions ago
     # %[cnt] counts the bands to the next "tick" (a trace dword completes every 8th band; the run ends at b_end): the
     # band index itself is only brought up to date there
     emit(f"s_lshl1_add_u32 %[cnt], %[cnt], {1 if m == 'R' else 0}")
