@@ -106,7 +106,9 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ and not args.single_process):
+        # launched by torch.distributed.run: the process group is built at world size 1 too, so that a 1-GPU box
+        # executes the RCCL path (init + the statistics all_gather on `cuda`) that the scaling runs depend on
         import torch.distributed as dist
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # nccl == RCCL on ROCm
@@ -182,6 +184,15 @@ def main():
     gdev = "cuda" if (dist is not None and args.backend == "nccl") else "cpu"
     g = dist_util.gather_stats(dict(elapsed=elapsed, events=float(sum_events), reads=float(n_reads), pairs=qc_pass), device=gdev)
     t_max, total_events, total_reads = g["t_max"], g["events"], g["reads"]
+    # what every rank's host side did per step (flatten / un-flatten are the caller thread's loops, wait = idle on the GPU):
+    # a flat or a linear scaling curve can be read off the one line
+    hs = host_stats or {}
+    per_rank = dist_util.gather_rows([rank, sum_events, elapsed / max(1, args.steps) * 1e3,
+                                      (acc["flatten_ms"] if host_stats else 0.0) / max(1, args.steps),
+                                      (acc["unflatten_ms"] if host_stats else 0.0) / max(1, args.steps),
+                                      (acc["wait_ms"] if host_stats else 0.0) / max(1, args.steps),
+                                      hs.get("host_threads", 0),
+                                      (acc["fill_ms"] + acc["pre_ms"] if host_stats else 0.0) / max(1, args.steps)], device=gdev)
     if dev is not None:      # the slowest rank's device-resident / kernel time: whole-job rates of those legs too
         gd = dist_util.gather_stats(dict(elapsed=dev["elapsed"], events=(dev["fill_ms"] + dev["pre_ms"]) * 1e-3, reads=0.0, pairs=0.0),
                                     device=gdev)
@@ -225,6 +236,21 @@ def main():
                 "pcie_bytes_per_step": {"h2d": int(host_stats["h2d_bytes"]), "d2h": int(host_stats["d2h_bytes"])},
                 "note": "pairs come down as the 2-bit traceback walk and are expanded on the host into the caller's buffers",
             }
+            rows = [{"rank": int(r[0]), "events": int(r[1]), "ms_per_step": round(r[2], 2),
+                     "host_ms_per_step": {"flatten": round(r[3], 1), "unflatten": round(r[4], 1), "wait_for_gpu": round(r[5], 1)},
+                     "host_threads": int(r[6]), "kernels_ms_per_step_sum_over_chunks": round(r[7], 1)} for r in per_rank]
+            slow = max(rows, key=lambda r: r["ms_per_step"])
+            busy = slow["host_ms_per_step"]["flatten"] + slow["host_ms_per_step"]["unflatten"]
+            out["per_rank"] = rows
+            # the caller thread of the slowest rank either works (flatten + un-flatten) or waits for its GPU
+            out["bound"] = "host" if busy >= slow["host_ms_per_step"]["wait_for_gpu"] else "gpu"
+            out["bound_note"] = ("slowest rank %d: %.0f ms of host loops and %.0f ms waiting for the GPU per %.0f-ms step; all ranks share one "
+                                 "host's DRAM bandwidth and CPU quota (%d usable CPUs), so host-to-host `value` stops scaling when the "
+                                 "host loops dominate; device_resident / kernel_only below are the whole-job rates without host traffic"
+                                 % (slow["rank"], busy, slow["host_ms_per_step"]["wait_for_gpu"], slow["ms_per_step"], effective_cpus()))
+            out["collective"] = {"backend": (args.backend if dist is not None else None), "world": world,
+                                 "gather_device": gdev if dist is not None else None,
+                                 "note": "statistics all_gather only; no data-path collective (reads are independent)"}
         if dev is not None:
             dsteps = args.device_steps
             fill_avg_ms = dev["fill_ms"] / max(1, dev["launches"])
@@ -239,6 +265,11 @@ def main():
                                   "align_launches_per_step": int(dev["launches_per_step"])}
             out["roofline"] = {"bound": "hbm", "kernel": "abea_align_kernel", "achieved": round(achieved, 2),
                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+                               "target_frac": 0.40, "target_met": bool(achieved / HBM_PEAK_GBS >= 0.40),
+                               "target_note": "north_star asks for >= 0.40 of the HBM roofline on A_ref; NOT met and not reachable with the CPU "
+                                              "path's arithmetic (27 of ~50 VALU instructions per band are fp64-class, align.c:382-384): the kernel "
+                                              "sits on the VALU issue ceiling, see valu_roofline",
+                               "valu_roofline": valu_roofline(args.config, sum_events, fill_avg_ms, dev["launches_per_step"]),
                                "traffic": pmc_traffic(args.config, sum_events, dev["launches_per_step"]),
                                "algorithmic_bytes_per_launch": int(a_ref_launch),
                                "bytes_per_event_ref": round(dev["a_ref"] / sum_events, 1),
@@ -287,7 +318,11 @@ def small_batch(ctx, batch):
     out = {"reads": n0, "bases": int(L[:n0].sum()), "events": ev_all[0], "ms_per_batch": round(t * 1e3, 2),
            "mevents_per_s": round(ev_all[0] / t / 1e6, 1), "longest_read_bases": int(L[:n0].max()),
            "note": "host-to-host, one batch at a time as process_db issues them; INTEGRATION.md recommends -K 20000 -B 200M"}
-    ref_np = [v["n_pairs"].copy() for v in views[:1]]
+    ref = []                                                       # every batch synchronously: the reference for the lanes
+    for v in views:
+        ctx.align_view(v)
+        ref.append((v["n_pairs"].copy(), v["pairs"].copy()))
+        v["pairs"].fill(0); v["n_pairs"].fill(-1)
     over = {}
     for lanes in (2, 4):
         ctx.set_inflight(lanes)
@@ -301,7 +336,8 @@ def small_batch(ctx, batch):
             for tk in pending:
                 ctx.wait(tk)
             dt = time.perf_counter() - t0
-        assert (views[0]["n_pairs"] == ref_np[0]).all(), "submitted batch differs from the synchronous one"
+        for v, (np_ref, pairs_ref) in zip(views, ref):
+            assert (v["n_pairs"] == np_ref).all() and (v["pairs"] == pairs_ref).all(), "submitted batch differs from the synchronous one"
         over[str(lanes)] = {"mevents_per_s": round(sum(ev_all) / dt / 1e6, 1), "ms_per_batch": round(dt / len(views) * 1e3, 2)}
     ctx.set_inflight(2)
     out["in_flight"] = {"batches": len(views), "events": sum(ev_all), "lanes": over,
@@ -353,13 +389,35 @@ def valu_issue(config, sum_events, launch_ms, launches):
         t = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))[config]
         # the counter books one quad-cycle per VALU instruction of any class and the per-XCD GRBM clocks are averaged, so the
         # measured ratio is good to about 1 %: it reads 1.0015 on this workload ("saturated"); frac is capped at 1, raw kept
-        return {"unit": "valu-busy", "frac": round(min(1.0, t["valu_busy"]), 4), "raw_counter_ratio": round(t["valu_busy"], 4),
+        prof_ms = t["kernel_ms_in_each_pass"].get("sqb")
+        return {"unit": "valu-busy", "static": True,
+                "static_note": "counter ratio of the committed PMC pass (profiles/pmc_traffic.json), NOT measured in this run; "
+                               "stale if kernel_ms_this_run is more than 3 % from kernel_ms_in_the_pmc_pass",
+                "stale": bool(prof_ms is None or abs(launch_ms - prof_ms) > 0.03 * prof_ms),
+                "frac": round(min(1.0, t["valu_busy"]), 4), "raw_counter_ratio": round(t["valu_busy"], 4),
                 "formula": t["valu_busy_formula"],
                 "valu_wave_instr_per_launch": int(t["valu_wave_instr_per_event"] * sum_events / max(1, launches)),
                 "wave_time_split": {k: round(v, 3) for k, v in t["wave_time_split"].items()},
                 "lds_bank_conflict_cycles": t.get("lds_bank_conflict_cycles"),
                 "kernel_ms_in_the_pmc_pass": t["kernel_ms_in_each_pass"].get("sqb"), "kernel_ms_this_run": round(launch_ms, 3),
                 "source": t["passes"].get("sqb")}
+    except Exception:
+        return None
+
+
+def valu_roofline(config, sum_events, launch_ms, launches):
+    """The ceiling the kernel actually sits on: VALU issue.  A SIMD issues one VALU wave-instruction per 4 cycles, so
+    ceiling_ms = VALU wave-instructions per launch / (1024 SIMDs x shader clock / 4); frac = ceiling_ms / measured ms.
+    The instruction count and the clock are from the committed SQ pass of the same workload (profiles/pmc_traffic.json:
+    static, per event, scaled to this launch); the time is this run's."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))[config]
+        instr = t["valu_wave_instr_per_event"] * sum_events / max(1, launches)
+        clk = t["shader_clock_ghz"]
+        ceiling_ms = instr / (1024 * clk * 1e9 / 4) * 1e3
+        return {"valu_wave_instr_per_launch": int(instr), "simds": 1024, "shader_clock_ghz": round(clk, 3),
+                "issue_cycles_per_instr": 4, "ceiling_ms": round(ceiling_ms, 2), "measured_ms": round(launch_ms, 3),
+                "frac": round(ceiling_ms / launch_ms, 4), "counters": "static: " + str(t["passes"].get("sqb"))}
     except Exception:
         return None
 

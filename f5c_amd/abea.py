@@ -17,9 +17,10 @@ EXPORTS = ["abea_init", "abea_init_multi", "abea_device_count", "abea_free", "ab
            "abea_align_batch_device", "abea_detect_events_device", "abea_get_stats", "abea_get_device_stats",
            "abea_device_info", "abea_selftest", "abea_rsq_format", "abea_lpt_split", "abea_hmm_score_batch_host", "abea_expand_walk_codes", "abea_expand_walk_codes_to_map",
            "abea_host_plan_chunks", "abea_host_plan_threads", "abea_set_inflight", "abea_align_batch_host_submit",
-           "abea_align_batch_host_wait"]
+           "abea_align_batch_host_wait", "abea_events_batch_host", "abea_process_batch_host", "abea_rsq_format_batch",
+           "abea_hmm_score_batch_device"]
 SHIM_EXPORTS = ["abea_f5c_init", "abea_f5c_align", "abea_f5c_align_scale", "abea_f5c_free", "abea_f5c_align_submit",
-                "abea_f5c_align_wait"]      # include/abea_f5c_shim.h
+                "abea_f5c_align_wait", "abea_f5c_event_db", "abea_f5c_process"]      # include/abea_f5c_shim.h
 
 
 class AbeaError(RuntimeError):
@@ -356,18 +357,23 @@ class AbeaContext:
         self._chk(self._lib.abea_align_batch_host_wait(self._h, ticket), "abea_align_batch_host_wait")
 
     # ---- row N4: profile-HMM forward scores ----
-    def hmm_score_batch(self, jobs, cpgmodel, kmer_size):
+    def hmm_score_batch(self, jobs, cpgmodel, kmer_size, device_events=False):
         """jobs: list of dicts(m_seq, m_rc_seq: bytes; events: EVENT_DT array (the read's table); scaling: 4 floats
         (scale, shift, var, log_var); e_start, e_stop, stride, rc, events_per_base, flags) = the arguments of
-        profile_hmm_score (hmm.c:689-703).  Returns float32[n] scores."""
+        profile_hmm_score (hmm.c:689-703).  Returns float32[n] scores.  device_events=True: `events` is the DEVICE address
+        (int) of the read's event_t table in HBM and the call is abea_hmm_score_batch_device."""
         n = len(jobs)
         arr = (HmmJob * max(1, n))()
         keep = []
         for j, jb in enumerate(jobs):
-            ev = np.ascontiguousarray(jb["events"], dtype=EVENT_DT)
-            keep.append(ev)
             a = arr[j]
-            a.m_seq = jb["m_seq"]; a.m_rc_seq = jb["m_rc_seq"]; a.events = ev.ctypes.data
+            if device_events:
+                a.events = int(jb["events"])
+            else:
+                ev = np.ascontiguousarray(jb["events"], dtype=EVENT_DT)
+                keep.append(ev)
+                a.events = ev.ctypes.data
+            a.m_seq = jb["m_seq"]; a.m_rc_seq = jb["m_rc_seq"]
             a.scaling = _Scal(*[float(x) for x in jb["scaling"]])
             a.event_start_idx = int(jb["e_start"]); a.event_stop_idx = int(jb["e_stop"])
             a.event_stride = int(jb["stride"]); a.rc = int(jb["rc"]); a.hmm_flags = int(jb.get("flags", 0))
@@ -375,8 +381,11 @@ class AbeaContext:
         m = np.ascontiguousarray(cpgmodel, dtype=MODEL_DT)
         assert len(m) == 5 ** kmer_size
         out = np.zeros(max(1, n), dtype=np.float32)
-        self._chk(self._lib.abea_hmm_score_batch_host(self._h, C.cast(arr, C.c_void_p), n, _p(m), kmer_size, _p(out)),
-                  "abea_hmm_score_batch_host")
+        fn = self._lib.abea_hmm_score_batch_device if device_events else self._lib.abea_hmm_score_batch_host
+        fn.restype = C.c_int
+        fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_uint32, C.c_void_p]
+        self._chk(fn(self._h, C.cast(arr, C.c_void_p), n, _p(m), kmer_size, _p(out)),
+                  "abea_hmm_score_batch_device" if device_events else "abea_hmm_score_batch_host")
         return out[:n]
 
     # ---- device-resident flattened batch ----

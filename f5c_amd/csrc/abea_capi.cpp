@@ -381,6 +381,11 @@ extern "C" int abea_detect_events_device(abea_ctx* c, const abea_signal_batch* B
     if (!c || !B) return abea_fail(ABEA_EINVAL, "null argument");
     if (!c->children.empty()) return abea_fail(ABEA_EINVAL, "abea_detect_events_device needs a single-device context");
     ABEA_API_ENTER(c, "abea_detect_events_device");
+    return abea_detect_events_locked(c, B);
+}
+
+/* the entry's body; the caller holds the context (abea_process.cpp chains it behind a host-side flatten) */
+int abea_detect_events_locked(abea_ctx* c, const abea_signal_batch* B) {
     const int32_t n = B->n_reads;
     if (n < 0) return abea_fail(ABEA_EINVAL, "n_reads < 0");
     if (n == 0) return ABEA_OK;

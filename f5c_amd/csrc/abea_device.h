@@ -37,8 +37,10 @@ typedef struct __attribute__((aligned(16))) {
 
 /* one 'M' state of recalibrate_model (align.c:688-753): what its sums read, in k order.  Records of the 64 reads that
  * share a wavefront of abea_recalib_kernel are INTERLEAVED: record m of the read in lane l sits at index
- * desc.pad64 + 64 * m (desc.pad64 = 64 * wave base + l), so the lane-per-read kernel's loads are coalesced. */
-struct __attribute__((aligned(16))) abea_mrec { double inv_var; float mu; float e; float sd; float pad0; float pad1; float pad2; };
+ * desc.pad64 + 64 * m (desc.pad64 = 64 * wave base + l), so the lane-per-read kernel's loads are coalesced.  Two 16-byte
+ * halves, one per pass of that kernel (each pass keeps a ring of 16-byte loads in flight per lane): the normal-equation
+ * sums read {1/(stdv*stdv), level_mean, event mean}, the variance sum {stdv*stdv (exact in fp64), level_mean, event mean}. */
+struct __attribute__((aligned(16))) abea_mrec { double inv_var; float mu; float e; double sd2; float mu2; float e2; };
 #define ABEA_MREC_STRIDE 64
 
 #endif

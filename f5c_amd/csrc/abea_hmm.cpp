@@ -28,8 +28,25 @@ void abea_hmm_release(abea_ctx* c) {
     c->hmm = nullptr;
 }
 
+extern "C" __global__ void abea_hmm_gather_kernel(int, const abea_hmm_job*, const int64_t*, const int32_t*, float*);
+
+static int hmm_score_batch(abea_ctx* c, const abea_hmm_job_t* jobs, int32_t n_jobs, const abea_model_t* cpgmodel,
+                           uint32_t kmer_size, float* scores, bool events_on_device);
+
 extern "C" int abea_hmm_score_batch_host(abea_ctx* c, const abea_hmm_job_t* jobs, int32_t n_jobs,
                                          const abea_model_t* cpgmodel, uint32_t kmer_size, float* scores) {
+    return hmm_score_batch(c, jobs, n_jobs, cpgmodel, kmer_size, scores, false);
+}
+
+/* the same with every job's `events` a DEVICE pointer (the read's table as the chain left it in HBM: events + event_ptr[i] of
+ * abea_detect_events_device / abea_device_batch): the event windows are gathered by a kernel instead of the host */
+extern "C" int abea_hmm_score_batch_device(abea_ctx* c, const abea_hmm_job_t* jobs, int32_t n_jobs,
+                                           const abea_model_t* cpgmodel, uint32_t kmer_size, float* scores) {
+    return hmm_score_batch(c, jobs, n_jobs, cpgmodel, kmer_size, scores, true);
+}
+
+static int hmm_score_batch(abea_ctx* c, const abea_hmm_job_t* jobs, int32_t n_jobs, const abea_model_t* cpgmodel,
+                           uint32_t kmer_size, float* scores, bool events_on_device) {
     if (!c || n_jobs < 0 || (n_jobs && (!jobs || !scores)) || !cpgmodel) return abea_fail(ABEA_EINVAL, "abea_hmm_score_batch_host: null argument");
     if (!c->children.empty()) return abea_fail(ABEA_EINVAL, "abea_hmm_score_batch_host needs a single-device context");
     if (kmer_size < 1 || kmer_size > ABEA_MAX_KMER_SIZE) return abea_fail(ABEA_EINVAL, "kmer_size %u", kmer_size);
@@ -137,8 +154,11 @@ extern "C" int abea_hmm_score_batch_host(abea_ctx* c, const abea_hmm_job_t* jobs
     const size_t o_desc = o;  o = align_up(o + (size_t)n_jobs * sizeof(abea_hmm_job), 256);
     const size_t o_flank = o; o = align_up(o + flank.size() * 4, 256);
     const size_t o_seq = o;   o = align_up(o + tot_seq, 256);
-    const size_t o_ev = o;    o = align_up(o + tot_ev * 4, 256);
+    /* device-resident events: per job the table's device address and {first event, stride} instead of the window itself */
+    const size_t o_src = o;   if (events_on_device) o = align_up(o + (size_t)n_jobs * 16, 256);
+    const size_t o_ev = o;    if (!events_on_device) o = align_up(o + tot_ev * 4, 256);
     const size_t up_bytes = o;
+    if (events_on_device) o = align_up(o + tot_ev * 4, 256);           /* the windows exist on the device only */
     const size_t o_out = o;   o = align_up(o + (size_t)n_jobs * 4, 256);
     const size_t o_col = o;   o = align_up(o + tot_col * 4, 256);
     if (o + 4096 > c->arena_bytes) return abea_fail(ABEA_ENOMEM, "%d HMM jobs need %zu bytes, the arena has %zu", n_jobs, o, c->arena_bytes);
@@ -151,6 +171,12 @@ extern "C" int abea_hmm_score_batch_host(abea_ctx* c, const abea_hmm_job_t* jobs
             const abea_hmm_job_t& J = jobs[order[(size_t)q]];
             const abea_hmm_job& d = desc[(size_t)q];
             memcpy(S->pin + o_seq + d.seq_off, d.rc ? J.m_rc_seq : J.m_seq, (size_t)d.seq_len + 1);
+            if (events_on_device) {
+                ((int64_t*)(S->pin + o_src))[q] = (int64_t)(uintptr_t)J.events;
+                int32_t* ss = (int32_t*)(S->pin + o_src + (size_t)n_jobs * 8) + 2 * q;
+                ss[0] = (int32_t)J.event_start_idx; ss[1] = J.event_stride;
+                continue;
+            }
             float* w = (float*)(S->pin + o_ev) + d.ev_off;
             for (int32_t r = 0; r < d.n_events; ++r)                   /* event_idx = e_start + (row-1)*stride, hmm.c:432 */
                 w[r] = J.events[(int64_t)J.event_start_idx + (int64_t)r * J.event_stride].mean;
@@ -160,6 +186,10 @@ extern "C" int abea_hmm_score_batch_host(abea_ctx* c, const abea_hmm_job_t* jobs
     HIP_TRY(hipMemcpyAsync(dev, S->pin, up_bytes, hipMemcpyHostToDevice, c->stream));
     const int blocks16 = (n16 + 15) / 16, blocks64 = (n_jobs - n16 + 3) / 4;
     HIP_TRY(hipEventRecord(S->e0, c->stream));
+    if (events_on_device)
+        hipLaunchKernelGGL(abea_hmm_gather_kernel, dim3((unsigned)((n_jobs + 3) / 4)), dim3(256), 0, c->stream,
+                           (int)n_jobs, (const abea_hmm_job*)(dev + o_desc), (const int64_t*)(dev + o_src),
+                           (const int32_t*)(dev + o_src + (size_t)n_jobs * 8), (float*)(dev + o_ev));
     hipLaunchKernelGGL(abea_hmm_forward_kernel, dim3((unsigned)(blocks16 + blocks64)), dim3(256), 0, c->stream,
                        n16, n_jobs, blocks16, (const abea_hmm_job*)(dev + o_desc), (const char*)(dev + o_seq),
                        (const float*)(dev + o_ev), S->d_model, (int)kmer_size, S->d_tbl, (const float*)(dev + o_flank),

@@ -157,3 +157,19 @@ void abea_hmm_forward_kernel(int n16, int n_jobs, int blocks16, const abea_hmm_j
         hmm_forward<64>(n16 - blocks16 * 4, n_jobs - n16 + blocks16 * 4, jobs, seqs, evw, cpgmodel, kmer_size, tbl, flank, col_scratch, out);
     }
 }
+
+
+/* device-resident event tables (abea_hmm_score_batch_device): the event-mean window of every job, in row order
+ * (event_idx = e_start + row * stride, hmm.c:432), gathered from the read's AoS event_t table where the chain left it in
+ * HBM.  One wavefront per job (a window is a few dozen events). */
+extern "C" __global__ __launch_bounds__(256)
+void abea_hmm_gather_kernel(int n_jobs, const abea_hmm_job* __restrict__ jobs, const int64_t* __restrict__ table,
+                            const int32_t* __restrict__ start_stride, float* __restrict__ windows) {
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= n_jobs) return;
+    const abea_hmm_job d = jobs[q];
+    const abea_event_t* __restrict__ ev = reinterpret_cast<const abea_event_t*>((uintptr_t)table[q]);
+    const int64_t e0 = start_stride[2 * q], stride = start_stride[2 * q + 1];
+    float* __restrict__ w = windows + d.ev_off;
+    for (int r = threadIdx.x & 63; r < d.n_events; r += 64) w[r] = ev[e0 + (int64_t)r * stride].mean;
+}

@@ -1096,6 +1096,12 @@ extern "C" int abea_align_batch_host(abea_ctx* c, const abea_host_batch* H) {
     int rc = check_host_batch(H);
     if (rc) return rc;
     std::lock_guard<std::mutex> api(c->api_mu);
+    return abea_host_batch_locked(c, H);
+}
+
+int abea_host_batch_locked(abea_ctx* c, const abea_host_batch* H) {
+    int rc = check_host_batch(H);
+    if (rc) return rc;
     if (async_of(c)->n_active) return abea_fail(ABEA_EBUSY, "abea_align_batch_host: %d submitted batch(es) still in flight", c->async->n_active);
     if (H->n_reads == 0) { memset(&c->stats, 0, sizeof c->stats); return ABEA_OK; }
     abea_stats st;

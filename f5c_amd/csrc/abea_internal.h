@@ -19,7 +19,7 @@ extern "C" {
 __global__ void abea_selftest_kernel(int* out);
 __global__ void abea_pre_kernel(const abea_read_desc*, const char*, const abea_event_t*, const abea_model_t*, int,
                                 abea_kpar_t*, float*);
-struct abea_mrec;            /* 16-byte 'M'-state record {stdv, level_mean, event mean, 0}: abea_kernels.hip */
+struct abea_mrec;            /* 32-byte 'M'-state record, abea_device.h */
 __global__ void abea_scaling_kernel(const abea_read_desc*, const char*, const abea_model_t*, int, const float*,
                                     const abea_pair_t*, const int32_t*, abea_index_pair_t*, double*, int32_t*, int32_t*,
                                     abea_mrec*, int32_t*);
@@ -85,6 +85,9 @@ int abea_host_batches_in_flight(abea_ctx* c);   /* abea_host.cpp: submitted and 
  * its duration and refuses to run while submitted host batches are in flight */
 #define ABEA_API_ENTER(c, name) std::lock_guard<std::mutex> api_lock_((c)->api_mu); \
     if (abea_host_batches_in_flight(c)) return abea_fail(ABEA_EBUSY, name ": submitted host batches are still in flight")
+/* bodies of public entries for callers that already hold the context (abea_process.cpp chains them) */
+int abea_detect_events_locked(abea_ctx* c, const abea_signal_batch* B);            /* abea_capi.cpp */
+int abea_host_batch_locked(abea_ctx* c, const abea_host_batch* H);                 /* abea_host.cpp */
 int abea_device_numa_node(int device);      /* abea_host.cpp: sysfs numa_node of a HIP device's PCI function */
 
 /* ------------------------------------------------------------------ batch planning */

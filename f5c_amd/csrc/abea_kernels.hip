@@ -739,8 +739,9 @@ void abea_scaling_kernel(const abea_read_desc* __restrict__ descs, const char* _
             const abea_model_t mo = model[rank];
             abea_mrec r;
             const double sd = mo.level_stdv;
-            r.inv_var = 1. / (sd * sd);                      /* align.c:697: the division is done here, in parallel */
-            r.mu = mo.level_mean; r.e = evm[m.start]; r.sd = mo.level_stdv; r.pad0 = r.pad1 = r.pad2 = 0.f;
+            r.sd2 = sd * sd;                                 /* exact: two 24-bit significands */
+            r.inv_var = 1. / r.sd2;                          /* align.c:697: the division is done here, in parallel */
+            r.mu = r.mu2 = mo.level_mean; r.e = r.e2 = evm[m.start];
             mrec[(size_t)(n_M + __popcll(mm & ((1ull << lane) - 1ull))) * ABEA_MREC_STRIDE] = r;   /* compacted: record m = the m-th 'M' state */
         }
         n_M += __popcll(mm);
@@ -756,53 +757,98 @@ void abea_scaling_kernel(const abea_read_desc* __restrict__ descs, const char* _
 }
 
 /* recalibrate_model's arithmetic (align.c:688-765) and scaling_single's flags (f5c.c:770-805): lane = read.  Reads of a
- * wavefront are neighbours in the launch order (longest first), so their chains have similar lengths. */
+ * wavefront are neighbours in the launch order (longest first), so their chains have similar lengths.
+ *
+ * Round 4.  A step of either chain is ~60-100 cycles of arithmetic, an HBM round trip ~0.5-1 us under the load of the
+ * alignment kernels; with one record per lane in flight (round 3) every one of a 50-kb read's 45 k steps waited for memory.
+ * Hiding the latency needs ~40 steps = 40 KiB per wavefront in flight, and the wavefront must still fit beside three
+ * alignment waves (122 VGPRs each, a SIMD's file holds four), so the ring cannot be registers.  Each pass streams its 16-byte
+ * half of the records through a 32-step ring in LDS by LDS-DMA (global_load_lds_dwordx4: 64 lanes x 16 B = one 1-KiB
+ * step per instruction, written at M0 + 16 * lane, no VGPR destination): slot (m & 31) is read with one ds_read_b128 and
+ * at once re-issued for step m + 32.  The loads return in order, so "step m has landed" is vmcnt(31).  hipcc does not count
+ * asm loads, hence the waits are written out (and its own waits can only over-wait: it has no VMEM in the loops).  The sums
+ * themselves are unchanged: one lane adds its read's terms in k order, in fp64, the division by the compiler's IEEE
+ * expansion. */
+#define ABEA_RECALIB_RING 32
+static __device__ __forceinline__ void recalib_issue(unsigned lds_dst, unsigned v_off, const void* step_base) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(lds_dst), "v"(v_off), "s"(step_base) : "memory");
+}
+/* wait for the oldest step of the ring, read this lane's 16 bytes of it, and re-issue the slot for a later step */
+static __device__ __forceinline__ uint4 recalib_take(unsigned v_lds, unsigned lds_dst, unsigned v_off, const void* next_base) {
+    uint4 v;
+    asm volatile("s_waitcnt vmcnt(%5)\n\tds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)\n\t"
+                 "s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %4"
+                 : "=&v"(v) : "v"(v_lds), "s"(lds_dst), "v"(v_off), "s"(next_base), "n"(ABEA_RECALIB_RING - 1) : "memory");
+    return v;
+}
+
 extern "C" __global__ __launch_bounds__(64)
 void abea_recalib_kernel(const abea_read_desc* __restrict__ descs, int n_desc, const abea_mrec* __restrict__ mrec_all,
                          const int32_t* __restrict__ n_m_in, abea_scalings_t* __restrict__ sc_io,
                          const double* __restrict__ epb_in, int32_t* __restrict__ flag_io, int min_rescale) {
+    __shared__ __attribute__((aligned(1024))) uint4 ring[ABEA_RECALIB_RING * 64];
     /* a handful of wavefronts with long serial chains, sharing their SIMDs with the fill loops of other chunks: they are
      * the latency of their chunk, so they issue first */
     __builtin_amdgcn_s_setprio(3);
-    const int j = blockIdx.x * 64 + threadIdx.x;
-    if (j >= n_desc) return;
-    const abea_read_desc* d = descs + j;
-    const int n_M = n_m_in[j];
-    if (n_M < 0) return;                                 /* not aligned: flagged by abea_scaling_kernel */
-    const int out_idx = d->out_idx;
-    const abea_mrec* __restrict__ mrec = mrec_all + d->pad64;
-    bool calibrated = false;
+    const unsigned lane = threadIdx.x;
+    const int j = blockIdx.x * 64 + (int)lane;
+    const bool live = j < n_desc;
+    const int n_M = live ? n_m_in[j] : -1;               /* < 0: not aligned, flagged by abea_scaling_kernel */
+    const bool calibrated = n_M >= min_rescale;
+    const int nm = calibrated ? n_M : 0;                 /* steps this lane takes */
+    int nmax = nm;
+    for (int off = 32; off > 0; off >>= 1) nmax = max(nmax, __shfl_xor(nmax, off, 64));
+    nmax = uni(nmax);
+    /* the group's records: record m of lane l at grp[m * 64 + l] (lane 0 of a group always exists) */
+    const abea_mrec* grp = (const abea_mrec*)uni_p(mrec_all + descs[blockIdx.x * 64].pad64);
+    const unsigned ring_a = (unsigned)uni((int)(unsigned)(uintptr_t)ring);
+    const unsigned v_lds = ring_a + lane * 16u;
     double shift = 0, scale = 0, var = 0;
-    if (n_M >= min_rescale) {
-        /* the loads of record m + 1 are issued before record m is consumed: the chain is the five adds, not the memory */
+    if (nmax > 0) {
+        const int smax = nmax - 1;                       /* steps past the group's last re-load it (never consumed) */
         double A00 = 0, A01 = 0, A11 = 0, b0 = 0, b1 = 0;
-        abea_mrec nx = mrec[0];
-        for (int m = 0; m < n_M; ++m) {
-            const abea_mrec r = nx;
-            nx = mrec[(size_t)min(m + 1, n_M - 1) * ABEA_MREC_STRIDE];
-            const double inv_var = r.inv_var, mu = r.mu, e = r.e;   /* align.c:697-706, in this order */
-            A00 += inv_var;
-            A01 += mu * inv_var;
-            A11 += mu * mu * inv_var;
-            b0 += e * inv_var;
-            b1 += mu * e * inv_var;
+        const unsigned off1 = lane * (unsigned)sizeof(abea_mrec);
+        for (int s = 0; s < ABEA_RECALIB_RING; ++s)
+            recalib_issue(ring_a + (unsigned)s * 1024u, off1, grp + (size_t)min(s, smax) * ABEA_MREC_STRIDE);
+        for (int m = 0; m < nmax; ++m) {
+            const unsigned slot = ((unsigned)m & (ABEA_RECALIB_RING - 1)) * 1024u;
+            const uint4 v = recalib_take(v_lds + slot, ring_a + slot, off1,
+                                         grp + (size_t)min(m + ABEA_RECALIB_RING, smax) * ABEA_MREC_STRIDE);
+            if (m < nm) {
+                const double inv_var = __hiloint2double((int)v.y, (int)v.x);   /* align.c:697-706, in this order */
+                const double mu = (double)__uint_as_float(v.z), e = (double)__uint_as_float(v.w);
+                A00 += inv_var;
+                A01 += mu * inv_var;
+                A11 += mu * mu * inv_var;
+                b0 += e * inv_var;
+                b1 += mu * e * inv_var;
+            }
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   /* the ring is idle before the second pass refills it */
         const double A10 = A01;
         const double div = A00 * A11 - A01 * A10;
         shift = -(A01 * b1 - A11 * b0) / div;
         scale = (A00 * b1 - A10 * b0) / div;
-        nx = mrec[0];
-        for (int m = 0; m < n_M; ++m) {                  /* align.c:738-753 */
-            const abea_mrec r = nx;
-            nx = mrec[(size_t)min(m + 1, n_M - 1) * ABEA_MREC_STRIDE];
-            const double sd = r.sd, mu = r.mu, e = r.e;
-            const double yi = (e - shift - scale * mu);
-            var += yi * yi / (sd * sd);
+        const unsigned off2 = off1 + 16u;                /* second half of the record: {stdv * stdv, level_mean, event mean} */
+        for (int s = 0; s < ABEA_RECALIB_RING; ++s)
+            recalib_issue(ring_a + (unsigned)s * 1024u, off2, grp + (size_t)min(s, smax) * ABEA_MREC_STRIDE);
+        for (int m = 0; m < nmax; ++m) {
+            const unsigned slot = ((unsigned)m & (ABEA_RECALIB_RING - 1)) * 1024u;
+            const uint4 v = recalib_take(v_lds + slot, ring_a + slot, off2,
+                                         grp + (size_t)min(m + ABEA_RECALIB_RING, smax) * ABEA_MREC_STRIDE);
+            if (m < nm) {                                                        /* align.c:738-751 */
+                const double sd2 = __hiloint2double((int)v.y, (int)v.x);         /* level_stdv * level_stdv */
+                const double mu = (double)__uint_as_float(v.z), e = (double)__uint_as_float(v.w);
+                const double yi = (e - shift - scale * mu);
+                var += yi * yi / sd2;
+            }
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         var /= n_M;
         var = sqrt(var);
-        calibrated = true;
     }
+    if (!live || n_M < 0) return;
+    const int out_idx = descs[j].out_idx;
     const double events_per_base = epb_in[out_idx];
     int flag = 0;
     float fvar = sc_io[out_idx].var;
@@ -1461,12 +1507,27 @@ void abea_ev_create_kernel(int n_reads, const int32_t* __restrict__ order, const
             e.stdv = sqrtf(fmaxf(var, 0.0f));
             /* RNA: event_single() reverses the table to 3'->5' AFTER the scalings are estimated (f5c.c:711-719): the
              * table goes out reversed, mean_all (what the scalings kernel sums, in order) stays in detection order.  A
-             * truncated table (n_ev > cap, reported to the caller through n_events) holds the LAST cap events then. */
+             * truncated RNA table (n_ev > cap, reported to the caller through n_events) is only partly written and not
+             * usable: the caller redoes the read with a larger table (include/abea.h; abea_events_batch_host does). */
             const int at = rna ? n_ev - 1 - j : j;
             if (at < event_cap[r]) ev[at] = e;
             mean_all[peak_base[w] + (int64_t)j * 64 + lane] = e.mean;
         }
     }
+}
+
+/* event tables of a chunk, each in its own slot range of `src`, copied back to back into `dst` (block = read): what
+ * abea_events_batch_host sends down over PCIe (event slots are sized from the sample count, ~2x the events found) */
+extern "C" __global__ __launch_bounds__(256)
+void abea_ev_compact_kernel(int n_reads, const abea_event_t* __restrict__ src, const int64_t* __restrict__ src_ptr,
+                            const int64_t* __restrict__ dst_ptr, const int32_t* __restrict__ n_events,
+                            abea_event_t* __restrict__ dst) {
+    const int r = blockIdx.x;
+    if (r >= n_reads) return;
+    const unsigned long long* __restrict__ s = reinterpret_cast<const unsigned long long*>(src + src_ptr[r]);
+    unsigned long long* __restrict__ d = reinterpret_cast<unsigned long long*>(dst + dst_ptr[r]);
+    const int64_t words = (int64_t)max(n_events[r], 0) * 3;          /* event_t = 24 bytes */
+    for (int64_t i = threadIdx.x; i < words; i += blockDim.x) d[i] = s[i];
 }
 
 /* pass 4b: model level of every k-mer of every read (align.c:75-78), parallel; interleaved like the other scratch */

@@ -24,6 +24,8 @@ extern "C" void abea_f5c_init(abea_f5c_core* core) {
         if (abea_init_multi(&ctx, &cfg, core->cuda_dev_ids, core->n_cuda_devs) != ABEA_OK) SHIM_DIE("abea_init_multi");
     } else if (abea_init(&ctx, &cfg) != ABEA_OK) SHIM_DIE("abea_init");
     core->cuda = ctx;
+    if (core->inflight > 0 && abea_set_inflight(ctx, core->inflight) != ABEA_OK) SHIM_DIE("abea_set_inflight");
+    core->event_time = 0;
     core->align_kernel_time = core->align_pre_kernel_time = core->align_core_kernel_time = 0;
     core->align_post_kernel_time = core->align_cuda_memcpy = core->align_cuda_preprocess = 0;
     core->align_cuda_postprocess = core->align_cuda_total_kernel = 0;
@@ -138,6 +140,68 @@ extern "C" void abea_f5c_align_wait(abea_f5c_core* core, void* handle) {
     if (abea_align_batch_host_wait((abea_ctx*)core->cuda, p->ticket) != ABEA_OK) SHIM_DIE("abea_align_batch_host_wait");
     shim_finish(core, p->db, false, __func__);
     delete p;
+}
+
+static void shim_need_signal(const abea_f5c_db* db, const char* who) {
+    if (!db->rawptr || !db->nsample || !db->offset || !db->range || !db->digitisation) {
+        fprintf(stderr, "[%s::ERROR] the db view lacks the signal_t fields\n", who);
+        exit(EXIT_FAILURE);
+    }
+}
+
+extern "C" void abea_f5c_event_db(abea_f5c_core* core, abea_f5c_db* db) {
+    shim_need_signal(db, __func__);
+    const int32_t n = db->n_bam_rec;
+    std::vector<abea_event_t*> ev((size_t)n);
+    std::vector<uint64_t> n_ev((size_t)n);
+    abea_events_host_batch eb;
+    memset(&eb, 0, sizeof eb);
+    eb.n_reads = n; eb.rawptr = db->rawptr; eb.n_samples = db->nsample; eb.offset = db->offset; eb.range = db->range;
+    eb.digitisation = db->digitisation; eb.read = db->read; eb.read_len = db->read_len; eb.rna = core->rna;
+    eb.signal_to_pa_in_place = 1;
+    eb.events = ev.data(); eb.n_events = n_ev.data(); eb.scalings = db->scalings;
+    if (abea_events_batch_host((abea_ctx*)core->cuda, &eb) != ABEA_OK) SHIM_DIE("abea_events_batch_host");
+    for (int32_t i = 0; i < n; ++i) {
+        db->et[i].event = ev[(size_t)i]; db->et[i].n = (size_t)n_ev[(size_t)i];
+        db->et[i].start = 0; db->et[i].end = (size_t)n_ev[(size_t)i];           /* events.c:576-580 */
+        if (db->event_align_pairs) {                                            /* f5c.c:722-731 */
+            db->event_align_pairs[i] = db->nsample[i] > 0 ? (abea_pair_t*)malloc(sizeof(abea_pair_t) * ((size_t)n_ev[(size_t)i] + (size_t)db->read_len[i])) : nullptr;
+            if (db->nsample[i] > 0 && !db->event_align_pairs[i]) { fprintf(stderr, "[%s::ERROR] malloc failed\n", __func__); exit(EXIT_FAILURE); }
+        }
+    }
+    abea_stats st;
+    abea_get_stats((abea_ctx*)core->cuda, &st);
+    core->event_time += st.total_ms * 1e-3;
+}
+
+extern "C" void abea_f5c_process(abea_f5c_core* core, abea_f5c_db* db) {
+    shim_need_signal(db, __func__);
+    if (!db->base_to_event_map || !db->events_per_base || !db->read_stat_flag || !db->n_event_alignment) {
+        fprintf(stderr, "[%s::ERROR] the db view lacks the scaling_single outputs\n", __func__);
+        exit(EXIT_FAILURE);
+    }
+    const int32_t n = db->n_bam_rec;
+    std::vector<abea_event_t*> ev((size_t)n);
+    std::vector<uint64_t> n_ev((size_t)n);
+    abea_process_batch pb;
+    memset(&pb, 0, sizeof pb);
+    pb.n_reads = n; pb.rawptr = db->rawptr; pb.n_samples = db->nsample; pb.offset = db->offset; pb.range = db->range;
+    pb.digitisation = db->digitisation; pb.read = db->read; pb.read_len = db->read_len; pb.rna = core->rna;
+    pb.signal_to_pa_in_place = 1;
+    pb.events = ev.data(); pb.n_events = n_ev.data(); pb.scalings = db->scalings;
+    pb.pairs = db->event_align_pairs; pb.n_pairs = db->n_event_align_pairs;
+    pb.base_to_event_map = db->base_to_event_map; pb.events_per_base = db->events_per_base;
+    pb.read_stat_flag = db->read_stat_flag; pb.n_event_alignment = db->n_event_alignment;
+    pb.min_num_events_to_rescale = core->min_num_events_to_rescale;
+    if (abea_process_batch_host((abea_ctx*)core->cuda, &pb) != ABEA_OK) SHIM_DIE("abea_process_batch_host");
+    for (int32_t i = 0; i < n; ++i) {
+        db->et[i].event = ev[(size_t)i]; db->et[i].n = (size_t)n_ev[(size_t)i];
+        db->et[i].start = 0; db->et[i].end = (size_t)n_ev[(size_t)i];
+    }
+    abea_stats st;
+    abea_get_stats((abea_ctx*)core->cuda, &st);
+    core->event_time += st.event_ms * 1e-3;
+    shim_finish(core, db, false, __func__);              /* the maps of failed reads were released by the library */
 }
 
 extern "C" void abea_f5c_free(abea_f5c_core* core) {

@@ -205,6 +205,60 @@ typedef struct {
 } abea_signal_batch;
 int abea_detect_events_device(abea_ctx* ctx, const abea_signal_batch* batch);
 
+/* ---- event_db on host buffers (row N2): pthread_db(core, db, event_single), src/f5c.c:682-734 ----
+ * f5c keeps a read's signal as FLOAT ADC counts (signal_t.rawptr, src/f5c.h:276-286; the slow5 / fast5 readers widen int16)
+ * and event_single() turns them into pA in place, runs getevents(), estimates the scalings and — RNA — reverses the table.
+ * Here the flatten loop narrows the counts back to int16 (2 bytes per sample over PCIe; a sample that is not an integral
+ * int16 value is refused with ABEA_EINVAL: it cannot be an ADC count), the detector of abea_detect_events_device runs on
+ * the device chunk by chunk, and each read's table comes back as a malloc()ed event_t array — where getevents()
+ * (src/events.c:562-582) would have put it; the caller releases it with free() as free_db_tmp does.  Reads with
+ * n_samples <= 0 get events = NULL, n_events = 0 (f5c.c:727-731).  A read whose table overflows the first guess of its
+ * size is redone with the exact size inside the call. */
+typedef struct {
+    int32_t n_reads;                       /* db->n_bam_rec */
+    float* const* rawptr;                  /* db->sig[i]->rawptr: ADC counts as float; rewritten to pA when signal_to_pa_in_place */
+    const int64_t* n_samples;              /* db->sig[i]->nsample */
+    const float* offset;                   /* db->sig[i]->offset        [n_reads] */
+    const float* range;                    /* db->sig[i]->range         [n_reads] */
+    const float* digitisation;             /* db->sig[i]->digitisation  [n_reads] */
+    const char* const* read;               /* db->read[i]; NULL with scalings == NULL */
+    const int32_t* read_len;               /* db->read_len[i] */
+    int32_t rna;                           /* core->opt.flag & F5C_RNA */
+    int32_t signal_to_pa_in_place;         /* != 0: rawptr[j] = (rawptr[j] + offset) * (range / digitisation) as f5c.c:693-696 leaves it */
+    abea_event_t** events;                 /* out [n_reads]: db->et[i].event, malloc()ed by the library */
+    uint64_t* n_events;                    /* out [n_reads]: db->et[i].n */
+    abea_scalings_t* scalings;             /* out [n_reads]: db->scalings[i] = estimate_scalings_using_mom(); may be NULL */
+} abea_events_host_batch;
+int abea_events_batch_host(abea_ctx* ctx, const abea_events_host_batch* batch);
+
+/* ---- the chain event_db -> align_db -> scaling_db on host buffers (row N3): process_db_rsq, src/resquiggle.c:283-315
+ * (process_db starts with the same three steps, src/f5c.c:907-936) ----
+ * One call: raw signals and sequences in; event tables, (optionally) pair lists, base_to_event_map, recalibrated scalings,
+ * events_per_base, read_stat_flag, n_event_alignment out.  Per-read buffers are malloc()ed by the library exactly where
+ * the reference mallocs them — et[i].event (getevents), event_align_pairs[i] (f5c.c:722-725, n_events + read_len entries),
+ * base_to_event_map[i] (scaling_single -> postalign, f5c.c:746; NULL for a read that did not align) — and released by the
+ * caller with free().  The alignment stage is the chunk pipeline of abea_align_batch_host with scaling_single fused. */
+typedef struct {
+    int32_t n_reads;
+    float* const* rawptr; const int64_t* n_samples;          /* as abea_events_host_batch */
+    const float* offset; const float* range; const float* digitisation;
+    const char* const* read; const int32_t* read_len;
+    int32_t rna, signal_to_pa_in_place;
+    abea_event_t** events; uint64_t* n_events;               /* out: db->et[i] */
+    abea_scalings_t* scalings;                               /* out: db->scalings[i] after scaling_single (recalibrated when it could be) */
+    abea_scalings_t* scalings_estimated;                     /* out, optional: the method-of-moments estimate before it */
+    abea_pair_t** pairs;                                     /* out, optional (NULL = pair lists not returned): db->event_align_pairs[i] */
+    int32_t* n_pairs;                                        /* out: db->n_event_align_pairs[i] */
+    abea_read_diag* diag;                                    /* out, optional */
+    abea_index_pair_t** base_to_event_map;                   /* out: db->base_to_event_map[i] */
+    double* events_per_base;                                 /* out: db->events_per_base[i] */
+    int32_t* read_stat_flag;                                 /* in/out: ABEA_FAILED_* bits OR-ed in */
+    int32_t* n_event_alignment;                              /* out */
+    int32_t min_num_events_to_rescale;                       /* 0 -> 200 */
+    int32_t reserved;
+} abea_process_batch;
+int abea_process_batch_host(abea_ctx* ctx, const abea_process_batch* batch);
+
 /* ---- resquiggle output of one read (row N3): the per-read body of output_db_rsq() (src/resquiggle.c:319-449) ----
  * fmt 0 = TSV (one line per k-mer: read_id, k-mer index, first sample, one-past-last sample or "."), fmt 1 = PAF
  * (one line; the ss:Z: string encodes matched samples "n,", skipped samples "nI", k-mers without events "nD").
@@ -216,6 +270,16 @@ int abea_detect_events_device(abea_ctx* ctx, const abea_signal_batch* batch);
 int64_t abea_rsq_format(char* out, size_t cap, int fmt, const char* read_id, int32_t read_len, uint32_t kmer_size,
                         abea_index_pair_t* base_to_event_map, const abea_event_t* events, int64_t n_samples,
                         float scale, float shift, int rna);
+
+/* The loop of output_db_rsq() over a batch (src/resquiggle.c:319-449): every read whose read_stat_flag is clear, in batch
+ * order, through abea_rsq_format; as in the reference the sc:f: / sh:f: tags carry the FIRST read's scalings
+ * (db->scalings->scale).  The caller's maps are left untouched (an RNA map is reversed on a copy, so a size query followed
+ * by the real call prints the same text).  snprintf-like (returns the full length, writes at most
+ * cap-1 bytes + NUL; out may be NULL with cap 0); n_printed (optional) = reads printed. */
+int64_t abea_rsq_format_batch(char* out, size_t cap, int fmt, int32_t n_reads, const char* const* read_id,
+                              const int32_t* read_len, uint32_t kmer_size, abea_index_pair_t* const* base_to_event_map,
+                              const abea_event_t* const* events, const int64_t* n_samples, const abea_scalings_t* scalings,
+                              const int32_t* read_stat_flag, int rna, int32_t* n_printed);
 
 /* ---- profile-HMM forward scores (row N4): batches of profile_hmm_score() calls, src/hmm.c:689-735 ----
  * One job = one call as calculate_methylation_for_read issues them (src/meth.c:473-474: the unmethylated and the
@@ -237,6 +301,11 @@ typedef struct {
 } abea_hmm_job_t;
 int abea_hmm_score_batch_host(abea_ctx* ctx, const abea_hmm_job_t* jobs, int32_t n_jobs, const abea_model_t* cpgmodel,
                               uint32_t kmer_size, float* scores);
+/* The same with the event tables still in HBM after the chain (abea_detect_events_device -> abea_align_batch_device):
+ * every job's `events` is the DEVICE address of its read's table (events + event_ptr[i]); the windows are gathered on
+ * the device.  Sequences, scalings and events_per_base are host values as above; scores[] is a host array. */
+int abea_hmm_score_batch_device(abea_ctx* ctx, const abea_hmm_job_t* jobs, int32_t n_jobs, const abea_model_t* cpgmodel,
+                                uint32_t kmer_size, float* scores);
 
 /* ---- timing / accounting of the last batch (core_t timing fields, src/f5c.h:457-466) ---- */
 typedef struct {

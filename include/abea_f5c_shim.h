@@ -37,6 +37,9 @@ typedef struct {                       /* the slice of core_t used by init_cuda/
     const int32_t* cuda_dev_ids;
     int32_t n_cuda_devs;
     int32_t min_num_events_to_rescale; /* core->opt.min_num_events_to_rescale (abea_f5c_align_scale only) */
+    int32_t rna;                       /* core->opt.flag & F5C_RNA (abea_f5c_event_db / abea_f5c_process only) */
+    int32_t inflight;                  /* lanes for abea_f5c_align_submit (1..ABEA_MAX_INFLIGHT); 0 = the library's default, 2 */
+    double event_time;                 /* core->event_time: seconds spent in abea_f5c_event_db / the event stage of abea_f5c_process */
 } abea_f5c_core;
 
 typedef struct {                       /* the slice of db_t align_cuda reads/writes, src/f5c.h:290-352 */
@@ -54,6 +57,11 @@ typedef struct {                       /* the slice of db_t align_cuda reads/wri
     double* events_per_base;           /* db->events_per_base */
     int32_t* read_stat_flag;           /* db->read_stat_flag (FAILED_* bits are OR-ed in) */
     int32_t* n_event_alignment;        /* db->n_event_alignment */
+    /* abea_f5c_event_db / abea_f5c_process only: the signal_t fields event_single reads (src/f5c.h:276-286), gathered */
+    float** rawptr;                    /* db->sig[i]->rawptr (ADC counts as float; left as pA like f5c.c:693-696) */
+    const float* offset;               /* db->sig[i]->offset */
+    const float* range;                /* db->sig[i]->range */
+    const float* digitisation;         /* db->sig[i]->digitisation */
 } abea_f5c_db;
 
 void abea_f5c_init(abea_f5c_core* core);
@@ -62,11 +70,21 @@ void abea_f5c_align(abea_f5c_core* core, abea_f5c_db* db);
  * base_to_event_map / recalibrated db->scalings / events_per_base / read_stat_flag come back.  db->event_align_pairs
  * may be NULL (or given, then it is filled as well, e.g. for --print-banded-aln). */
 void abea_f5c_align_scale(abea_f5c_core* core, abea_f5c_db* db);
-/* abea_f5c_align split in two, so that a caller can keep two (up to ABEA_MAX_INFLIGHT) process_db batches in flight —
- * f5c's default -K 512 / -B 2M batches are latency-bound on a GPU.  submit returns a handle at once;
- * wait blocks until db->event_align_pairs / n_event_align_pairs are complete.  db must stay valid and untouched between. */
+/* abea_f5c_align split in two, so that a caller can keep several process_db batches in flight — f5c's default -K 512 /
+ * -B 2M batches are latency-bound on a GPU.  submit returns a handle at once; wait blocks until
+ * db->event_align_pairs / n_event_align_pairs are complete.  db must stay valid and untouched between.  At most
+ * core->inflight handles (set before abea_f5c_init; 0 = the library's default of 2, at most ABEA_MAX_INFLIGHT) may be
+ * outstanding: a submit beyond that is misuse and exits like every other error here — wait for a handle first.  Each
+ * lane owns 1/inflight of the device arena and of the worker threads, so a read that fits the synchronous call can be
+ * too long for a lane (ABEA_ENOMEM, exit); INTEGRATION.md gives the arithmetic. */
 void* abea_f5c_align_submit(abea_f5c_core* core, abea_f5c_db* db);
 void abea_f5c_align_wait(abea_f5c_core* core, void* handle);
+/* event_db: pthread_db(core, db, event_single) (f5c.c:682-734) on the GPU.  Fills db->et[i] (malloc()ed tables, n = 0 /
+ * event = NULL for reads without signal), db->scalings[i] (method of moments), leaves db->rawptr[i] in pA and malloc()s
+ * db->event_align_pairs[i] (n + read_len entries, f5c.c:722-725) when that array is given. */
+void abea_f5c_event_db(abea_f5c_core* core, abea_f5c_db* db);
+/* process_db_rsq (resquiggle.c:283-315) = event_db -> align_db -> scaling_db in one call; every output of the three. */
+void abea_f5c_process(abea_f5c_core* core, abea_f5c_db* db);
 void abea_f5c_free(abea_f5c_core* core);
 
 #ifdef __cplusplus

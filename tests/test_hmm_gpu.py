@@ -60,6 +60,30 @@ def test_profile_hmm_scores_bit_exact(ctx, orc, k):
     assert (got2.view(np.uint32) == want[:37].view(np.uint32)).all()
 
 
+def test_profile_hmm_scores_from_device_resident_event_tables(ctx, orc):
+    """abea_hmm_score_batch_device: the reads' event tables are in HBM (as the chain leaves them) and every job names its
+    read's table by device address; the windows are gathered on the device.  Same bits as the host entry and the oracle."""
+    import torch
+    from f5c_amd.types import EVENT_DT
+    k = 6
+    model = _cpg_model(k, 21)
+    r = np.random.default_rng(77)
+    jobs = _jobs(r, model, k, 120, 1, 16) + _jobs(r, model, k, 40, 17, 64) + _jobs(r, model, k, 8, 65, 150)
+    want = _oracle(orc, jobs, model, k)
+    # one flat device buffer holding every job's table back to back, like `events` + event_ptr[] of a device batch
+    off, flat = [], []
+    at = 0
+    for j in jobs:
+        off.append(at); flat.append(np.ascontiguousarray(j["events"], dtype=EVENT_DT)); at += len(j["events"])
+    d_ev = torch.from_numpy(np.concatenate(flat).view(np.uint8)).cuda()
+    torch.cuda.synchronize()
+    djobs = [dict(j, events=d_ev.data_ptr() + 24 * o) for j, o in zip(jobs, off)]
+    got = ctx.hmm_score_batch(djobs, model, k, device_events=True)
+    assert (got.view(np.uint32) == want.view(np.uint32)).all()
+    assert (ctx.hmm_score_batch(jobs, model, k).view(np.uint32) == want.view(np.uint32)).all()
+    assert ctx.stats()["hmm_ms"] > 0
+
+
 def test_methylation_signal_and_call_shape(ctx, orc):
     """The use meth.c makes of the scores: events drawn from the unmethylated levels favour the unmethylated sequence
     (log-likelihood ratio < 0), from the methylated levels the methylated one; GPU == CPU on every score."""

@@ -454,3 +454,29 @@ def test_bench_two_ranks_and_single_process_two_contexts(tmp_path):
         assert abs(j["qc_pass_frac"] - ref["qc_pass_frac"]) < 1e-9
     assert j2["config"]["events_rank0"] < 0.6 * ref["config"]["events"]          # rank 0 holds its shard only
     assert j3["host_to_host"]["devices"] == 2
+
+
+@pytest.mark.gpu
+def test_bench_under_torchrun_world_size_1_runs_rccl(tmp_path):
+    """The scaling runs are the driver's (no multi-GPU box here), but their communication path must have executed at least
+    once: bench.py under torch.distributed.run with ONE rank builds the `nccl` (= RCCL) process group and runs its
+    statistics all_gather on `cuda`; the line carries the per-rank host breakdown and the host/gpu verdict."""
+    import json
+    import sys
+    port = 29900 + os.getpid() % 90
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                        "--gpus", "1", "--config", "r9_10k_8kb", "--reads", "1500", "--steps", "2", "--warmup", "1",
+                        "--arena-gib", "8", "--no-cpu-baseline", "--no-small-batch", "--backend", "nccl"],
+                       capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert j["collective"] == {"backend": "nccl", "world": 1, "gather_device": "cuda",
+                               "note": "statistics all_gather only; no data-path collective (reads are independent)"}
+    assert j["n_gpus"] == 1 and j["value"] > 0 and j["bound"] in ("host", "gpu")
+    assert len(j["per_rank"]) == 1 and j["per_rank"][0]["rank"] == 0 and j["per_rank"][0]["host_threads"] >= 1
+    assert j["per_rank"][0]["events"] == j["config"]["events"]
+    assert set(j["per_rank"][0]["host_ms_per_step"]) == {"flatten", "unflatten", "wait_for_gpu"}
+    assert j["roofline"]["target_frac"] == 0.40 and j["roofline"]["target_met"] is False
+    assert 0.5 < j["roofline"]["valu_roofline"]["frac"] < 1.3

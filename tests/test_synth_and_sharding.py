@@ -84,3 +84,27 @@ def test_two_rank_gloo_shard_and_gather(r9, orc, tmp_path):
     assert res[0] == pytest.approx(0.02)                   # MAX over ranks
     assert res[1] == full["n_events"].sum() and res[2] == 24 and res[3] == n_pairs.sum()
     assert (res[4:].astype(np.int64) == n_pairs).all()     # per-read gather reassembles the unsharded result
+
+
+def test_lpt_split_of_the_100k_batch_over_8_gpus_is_balanced():
+    """BASELINE configs[3]: the 100k-read batch over 8 GPUs.  The library's split (abea_lpt_split, what
+    abea_align_batch_host applies on a multi-device context and bench.py per rank) on the real band counts E + K + 2 of
+    configs[2] (n_events / read_len of every read are part of the committed goldens): every bin within 2 % of the mean."""
+    import ctypes as C
+    from f5c_amd import abea, synth
+    path = os.path.join(ROOT, "tests", "golden", "config_goldens_r9_100k_mixed.npz")
+    if not os.path.exists(path):
+        pytest.skip("config goldens not minted")
+    g = np.load(path)
+    w = g["n_events"].astype(np.int64) + (g["read_len"].astype(np.int64) - 6 + 1) + 2
+    lib = abea.load_library()
+    for bins in (2, 4, 8):
+        out = np.zeros(len(w), dtype=np.int32)
+        assert lib.abea_lpt_split(w.ctypes.data_as(C.c_void_p), len(w), bins, out.ctypes.data_as(C.c_void_p)) == 0
+        assert (out == synth.lpt_bins(w, bins)).all()                 # bench.py's per-rank rule is the same rule
+        load = np.bincount(out, weights=w, minlength=bins)
+        assert load.min() > 0 and (np.abs(load / load.mean() - 1.0) < 0.02).all(), load / load.mean()
+        # and on what bench.py actually shards on before the batch exists: 3 x read length (E ~ 2.04 L for this generator)
+        pre = synth.lpt_bins(3 * g["read_len"].astype(np.int64), bins)
+        load = np.bincount(pre, weights=w, minlength=bins)
+        assert (np.abs(load / load.mean() - 1.0) < 0.02).all(), load / load.mean()
