@@ -269,7 +269,9 @@ def main():
                                "target_note": "north_star asks for >= 0.40 of the HBM roofline on A_ref; NOT met and not reachable with the CPU "
                                               "path's arithmetic (27 of ~50 VALU instructions per band are fp64-class, align.c:382-384): the kernel "
                                               "sits on the VALU issue ceiling, see valu_roofline",
-                               "valu_roofline": valu_roofline(args.config, sum_events, fill_avg_ms, dev["launches_per_step"]),
+                               "valu_roofline": valu_roofline(args.config, sum_events, fill_avg_ms, dev["launches_per_step"],
+                                                              n_right=float((batch["read_len"].astype(np.int64) - k + 1).clip(min=0).sum()) / max(1, dev["launches_per_step"]),
+                                                              n_down=float(sum_events) / max(1, dev["launches_per_step"])),
                                "traffic": pmc_traffic(args.config, sum_events, dev["launches_per_step"]),
                                "algorithmic_bytes_per_launch": int(a_ref_launch),
                                "bytes_per_event_ref": round(dev["a_ref"] / sum_events, 1),
@@ -405,19 +407,37 @@ def valu_issue(config, sum_events, launch_ms, launches):
         return None
 
 
-def valu_roofline(config, sum_events, launch_ms, launches):
-    """The ceiling the kernel actually sits on: VALU issue.  A SIMD issues one VALU wave-instruction per 4 cycles, so
-    ceiling_ms = VALU wave-instructions per launch / (1024 SIMDs x shader clock / 4); frac = ceiling_ms / measured ms.
-    The instruction count and the clock are from the committed SQ pass of the same workload (profiles/pmc_traffic.json:
-    static, per event, scaled to this launch); the time is this run's."""
+def valu_roofline(config, sum_events, launch_ms, launches, n_right=0, n_down=0):
+    """The ceiling the kernel actually sits on: VALU issue.  Two models, both against this run's measured launch time:
+      issue_slots   every VALU wave-instruction holds its SIMD for 4 cycles: VALU wave-instructions per launch (SQ_INSTS_VALU of
+                    the committed SQ pass of the same workload, per event, scaled to this launch) / (1024 SIMDs x clock / 4).
+                    Not a bound: full-rate f32 / int instructions issue a wave64 in 2 passes on CDNA3/4, so frac can pass 1.
+      class_floor   the fill loop only, from the COMMITTED instruction stream (tools/isa_audit.py over abea_fill.inc): per band
+                    `slow` instructions (fp64 add/mul, converts, DPP, cross-lane, compares: 4 cycles) and `fast` ones (f32 / int
+                    full rate: 2 cycles), times the right-move and down-move bands of this launch.  A true lower bound of the
+                    kernel time (walk and expansion add to it)."""
     try:
         t = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))[config]
         instr = t["valu_wave_instr_per_event"] * sum_events / max(1, launches)
         clk = t["shader_clock_ghz"]
         ceiling_ms = instr / (1024 * clk * 1e9 / 4) * 1e3
-        return {"valu_wave_instr_per_launch": int(instr), "simds": 1024, "shader_clock_ghz": round(clk, 3),
-                "issue_cycles_per_instr": 4, "ceiling_ms": round(ceiling_ms, 2), "measured_ms": round(launch_ms, 3),
-                "frac": round(ceiling_ms / launch_ms, 4), "counters": "static: " + str(t["passes"].get("sqb"))}
+        out = {"issue_slots": {"valu_wave_instr_per_launch": int(instr), "simds": 1024, "shader_clock_ghz": round(clk, 3),
+                               "cycles_per_instr": 4, "ms": round(ceiling_ms, 2), "frac": round(ceiling_ms / launch_ms, 4),
+                               "counters": "static: " + str(t["passes"].get("sqb"))},
+               "measured_ms": round(launch_ms, 3)}
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import isa_audit
+            c = isa_audit.interior_classes()
+            cyc = n_right * (4 * c["R"]["slow"] + 2 * c["R"]["fast"]) + n_down * (4 * c["D"]["slow"] + 2 * c["D"]["fast"])
+            floor_ms = cyc / (1024 * clk * 1e9) * 1e3
+            out["class_floor"] = {"per_band": c, "right_move_bands": int(n_right), "down_move_bands": int(n_down),
+                                  "cycles": {"slow": 4, "fast": 2}, "ms": round(floor_ms, 2), "frac": round(floor_ms / launch_ms, 4),
+                                  "source": "f5c_amd/csrc/abea_fill.inc (interior bodies) via tools/isa_audit.py"}
+            out["frac"] = out["class_floor"]["frac"]
+        except Exception:
+            out["frac"] = out["issue_slots"]["frac"]
+        return out
     except Exception:
         return None
 

@@ -450,7 +450,7 @@ int abea_detect_events_locked(abea_ctx* c, const abea_signal_batch* B) {
         const size_t o_need = put(nullptr, N * 4);                    /* per-read "segments never met" flags, zeroed */
         const size_t o_need_s = put(nullptr, N * 4);                  /* per-read "prefix sums may round" flags */
         double* dS = (double*)(d + align_up(o, 256));
-        double* dQ = dS + entries;
+        double* dQ = dS + entries;                 /* back to back: the kernels address [dS, dQ + entries) as ONE array of {S, Q} pairs */
         float* dT1 = (float*)(dQ + entries);
         float* dT2 = dT1 + entries;
         int32_t* dPk = (int32_t*)(dT2 + entries);

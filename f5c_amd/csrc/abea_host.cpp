@@ -95,6 +95,9 @@ static std::string format_cpulist(const std::vector<int>& v) {
  *            event tables from wherever they are but WRITES its pinned staging (allocated by hipHostMalloc on the node
  *            nearest the current device) locally, and un-flatten reads it locally. */
 struct host_thread_plan { int threads; std::vector<int> cpus; };
+/* ONE switch for the binding, read by the run-time path and by the host-only report alike: opt-in, ABEA_HOST_NUMA=1
+ * (measured to hurt unless the caller places each device's share of the batch on that device's node) */
+static bool host_numa_enabled() { const char* nu = getenv("ABEA_HOST_NUMA"); return nu && nu[0] == '1'; }
 static std::vector<host_thread_plan> plan_host_threads(int usable_cpus, const std::vector<int>& allowed, int n_devices,
                                                         const int32_t* dev_node, const std::vector<std::vector<int>>& node_cpus,
                                                         int forced_threads, bool numa) {
@@ -125,9 +128,8 @@ extern "C" int abea_host_plan_threads(int32_t usable_cpus, const char* allowed_c
     std::vector<std::vector<int>> nodes;
     for (int32_t i = 0; i < n_nodes; ++i) nodes.push_back(parse_cpulist(node_cpulist[i]));
     const char* e = getenv("ABEA_HOST_THREADS");
-    const char* nu = getenv("ABEA_HOST_NUMA");
     const std::vector<host_thread_plan> plan = plan_host_threads(usable_cpus, parse_cpulist(allowed_cpulist), n_devices, device_numa_node,
-                                                                 nodes, e ? std::max(1, atoi(e)) : 0, !(nu && nu[0] == '0'));
+                                                                 nodes, e ? std::max(1, atoi(e)) : 0, host_numa_enabled());
     for (int32_t d = 0; d < n_devices; ++d) {
         threads_per_device[d] = plan[(size_t)d].threads;
         if (bind_cpulists) snprintf(bind_cpulists + (size_t)d * cap_each, cap_each, "%s", format_cpulist(plan[(size_t)d].cpus).c_str());
@@ -151,16 +153,28 @@ static std::vector<int> allowed_cpus() {
     return out;
 }
 static std::vector<std::vector<int>> numa_node_cpus() {
-    std::vector<std::vector<int>> out;
-    for (int n = 0; n < 64; ++n) {
-        char path[96], buf[4096];
-        snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", n);
-        FILE* f = fopen(path, "r");
-        if (!f) break;
+    /* indexed by node number; the nodes that exist are listed in .../node/online (numbering may be sparse: a missing node
+     * stays an empty list instead of ending the enumeration) */
+    std::vector<int> online;
+    if (FILE* f = fopen("/sys/devices/system/node/online", "r")) {
+        char buf[1024];
         const size_t got = fread(buf, 1, sizeof buf - 1, f);
         buf[got] = 0;
         fclose(f);
-        out.push_back(parse_cpulist(buf));
+        online = parse_cpulist(buf);
+    }
+    std::vector<std::vector<int>> out;
+    for (int n : online) {
+        if (n < 0 || n >= 1024) continue;
+        char path[96], buf[4096];
+        snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", n);
+        FILE* f = fopen(path, "r");
+        if (!f) continue;
+        const size_t got = fread(buf, 1, sizeof buf - 1, f);
+        buf[got] = 0;
+        fclose(f);
+        if ((int)out.size() <= n) out.resize((size_t)n + 1);
+        out[(size_t)n] = parse_cpulist(buf);
     }
     return out;
 }
@@ -284,22 +298,6 @@ static int slot_create(abea_host_slot** out) {
     return ABEA_OK;
 }
 
-/* the plan for the devices of a context (children of a multi-device parent, or the context itself) */
-static std::vector<host_thread_plan> context_thread_plan(abea_ctx* c) {
-    std::vector<int32_t> nodes;
-    if (c->children.empty()) nodes.push_back(c->numa_node);
-    else for (abea_ctx* ch : c->children) nodes.push_back(ch->numa_node);
-    const char* e = getenv("ABEA_HOST_THREADS");
-    /* Binding is OPT-IN at run time (ABEA_HOST_NUMA=1).  Measured on the MI355X box (2 sockets, bench.py, 100 k reads): with
-     * the workers of the one device bound to its node, flatten went from 217 to 602 ms per step — the loop READS 24 B per
-     * event from the caller's tables, which live wherever the caller's threads first touched them (both nodes), and only
-     * WRITES 4 B per event to the local pinned staging; binding trades the small local write for remote reads through one
-     * socket.  It pays only when the caller places each device's share of the batch on that device's node. */
-    const char* nu = getenv("ABEA_HOST_NUMA");
-    return plan_host_threads(effective_cpus(), allowed_cpus(), (int)nodes.size(), nodes.data(), numa_node_cpus(),
-                             e ? std::max(1, atoi(e)) : 0, nu && nu[0] == '1');
-}
-
 int abea_default_host_threads() {
     const char* e = getenv("ABEA_HOST_THREADS");
     return plan_host_threads(effective_cpus(), std::vector<int>(), 1, nullptr, std::vector<std::vector<int>>(),
@@ -329,6 +327,7 @@ struct abea_async_job {
 };
 
 struct abea_host_async {
+    std::vector<host_thread_plan> plan; std::string plan_key = "?";     /* context_thread_plan's cache (top-level context) */
     int n_lanes = 2;
     abea_host_lane full;                       /* per device context */
     std::vector<abea_host_lane> lanes;         /* per device context */
@@ -339,6 +338,29 @@ struct abea_host_async {
 static abea_host_async* async_of(abea_ctx* c) {
     if (!c->async) c->async = new abea_host_async();
     return c->async;
+}
+
+/* the plan for the devices of a context (children of a multi-device parent, or the context itself) */
+static std::vector<host_thread_plan> context_thread_plan(abea_ctx* c) {
+    std::vector<int32_t> nodes;
+    if (c->children.empty()) nodes.push_back(c->numa_node);
+    else for (abea_ctx* ch : c->children) nodes.push_back(ch->numa_node);
+    const char* e = getenv("ABEA_HOST_THREADS");
+    /* the plan is cached per context: it was re-derived (sched_getaffinity + up to 64 sysfs reads) on every batch, which is
+     * per-call overhead on the latency-bound default f5c batches (round-3 advisor finding); the key is the two switches */
+    const bool numa = host_numa_enabled();
+    abea_host_async* a = async_of(c);
+    const std::string key = std::string(e ? e : "") + "|" + (numa ? "1" : "0");
+    if (a->plan_key == key && a->plan.size() == nodes.size()) return a->plan;
+    /* Binding is OPT-IN at run time (ABEA_HOST_NUMA=1).  Measured on the MI355X box (2 sockets, bench.py, 100 k reads): with
+     * the workers of the one device bound to its node, flatten went from 217 to 602 ms per step — the loop READS 24 B per
+     * event from the caller's tables, which live wherever the caller's threads first touched them (both nodes), and only
+     * WRITES 4 B per event to the local pinned staging; binding trades the small local write for remote reads through one
+     * socket.  It pays only when the caller places each device's share of the batch on that device's node. */
+    a->plan = plan_host_threads(effective_cpus(), numa ? allowed_cpus() : std::vector<int>(), (int)nodes.size(), nodes.data(),
+                                numa ? numa_node_cpus() : std::vector<std::vector<int>>(), e ? std::max(1, atoi(e)) : 0, numa);
+    a->plan_key = key;
+    return a->plan;
 }
 
 int abea_host_batches_in_flight(abea_ctx* c) { return c->async ? c->async->n_active : 0; }
@@ -686,13 +708,16 @@ struct slot_guard {
 /* the lanes of a DEVICE context, built on first use: the full lane and n_lanes equal shares.  Slot objects (stream,
  * events, pinned staging) are created on demand by host_run; a slot index belongs to exactly one share and the full lane
  * is only used while no share is (the top-level context's bookkeeping guarantees it). */
-static void ensure_lanes(abea_ctx* c, const host_thread_plan& pl, int n_lanes, int n_slots) {
+static void ensure_lanes(abea_ctx* c, const host_thread_plan& pl, int n_lanes, int n_slots, bool want_shares) {
     abea_host_async* a = async_of(c);
     if (!a->full.pool || a->full.pool->threads() != pl.threads) {
         delete a->full.pool;
         a->full.pool = new abea_host_pool(pl.threads, pl.cpus);
     }
     a->full.first_slot = 0; a->full.n_slots = n_slots; a->full.arena_off = 0; a->full.arena_bytes = c->arena_bytes;
+    /* the share lanes (and their worker pools) exist only once a batch has been SUBMITTED: a context that is only ever
+     * called synchronously keeps one pool per device (round-3 advisor finding: 30 threads per device instead of 16) */
+    if (!want_shares) return;
     const int per_threads = std::max(1, pl.threads / std::max(1, n_lanes));
     if ((int)a->lanes.size() != n_lanes || (n_lanes && a->lanes[0].pool->threads() != per_threads)) {
         for (abea_host_lane& l : a->lanes) delete l.pool;
@@ -1042,7 +1067,7 @@ static int run_host_batch(abea_ctx* c, const abea_host_batch* H, int lane_no, in
     auto lane_of = [&](abea_ctx* dev, const host_thread_plan& pl) -> abea_host_lane& {
         {
             std::lock_guard<std::mutex> lk(dev->slots_mu);
-            ensure_lanes(dev, pl, n_lanes, opt.n_slots);
+            ensure_lanes(dev, pl, n_lanes, opt.n_slots, lane_no >= 0);
         }
         abea_host_async* a = async_of(dev);
         return lane_no < 0 ? a->full : a->lanes[(size_t)lane_no];

@@ -17,13 +17,8 @@
 #include <hip/hip_runtime.h>
 #include <type_traits>
 #include "abea_device.h"
-#ifdef ABEA_EXP          /* next-round register-layout experiments (tools/gen_fill_asm.py, ABEA_VBASE / ABEA_TIED) */
-#include "abea_fill_exp.inc"
-#include "abea_walk_exp.inc"
-#else
 #include "abea_fill.inc"
 #include "abea_walk.inc"
-#endif
 
 #define NINF (-__builtin_inff())
 
@@ -156,13 +151,12 @@ static __device__ __forceinline__ void abea_cell(float x, float gpm, float ck, d
  *
  * Phase-1 state layout:
  *   lane l owns band offsets o0 = 2l and o1 = 2l+1.  Offsets 0..99 (lanes 0..49) are the band;
- *   offsets 100..127 (lanes 50..63) never hold scores (offset 100 is pinned to -inf, the rest is never read) but DO hold k-mer parameters:
- *   they are the FIFO through which upcoming k-mers slide towards offset 99, so a "right" move is
- *   one DPP wave shift per register with the new k-mer entering at lane 63 through the DPP `old`
- *   operand.  Events enter at offset 0 (lane 0) the same way on "down" moves.
- *   The next event / k-mer is read ahead of time from a wave-private LDS ring (broadcast ds_read,
- *   off the critical path); the ring is refilled 64 entries at a time from HBM with the global load
- *   issued one refill period before its data is needed.
+ *   offsets 100..127 (lanes 50..63) never hold scores (offset 100 is pinned to -inf, the rest is never read) but DO hold
+ *   what enters the band next (round 4: no LDS rings): their k-mer quads are offsets 100..127 as ever — a "right" move is
+ *   one DPP wave shift per register, so upcoming k-mers slide towards offset 99 — and lanes 52..63 of the EVENT
+ *   registers hold the next 24 events, lane 63's cell 1 first: a "down" move shifts the event registers with wave_ror, so
+ *   the next event arrives in lane 0 from lane 63.  Every 24th move of a kind the twelve lanes are overwritten under an
+ *   EXEC mask from "pending" registers that two global loads filled 24 moves earlier (tools/gen_fill_asm.py).
  *   Neighbours (DESIGN.md "frames"): right move: left = P[o], up = P[o+1], diag = previous band's up;
  *   down move: left = P[o-1], up = P[o], diag = previous band's left.
  * Trace layout (per read): per 32 bands one uint4 per lane = 128 bits, 8 bands per dword with the OLDEST band in the
@@ -191,14 +185,15 @@ void abea_align_kernel(const abea_read_desc* __restrict__ descs,
     /* pairs_all == nullptr: the pair lists are not materialised on the device (the host entry expands them from the
      * walk codes).  pair_cursor != nullptr: pair lists are packed back to back in completion order (atomic bump
      * allocation of n entries per read, offset reported in pair_off_out[]) instead of at desc.pair_off. */
-    /* 4 KiB: [1024, 1536) event ring, [2048, 4096) k-mer ring; phase 3 reuses all of it as its emission buffer.  The
-     * rings sit above offset 252 because the fill loop reads them with ds_read_addtid_b32 (address = M0 + 4*lane, M0 >= 0)
-     * and the k-mer ring's reader is lane 63.  4 KiB per
-     * wavefront keeps LDS from capping the occupancy (160 KiB per CU). */
+    /* 4 KiB of LDS per wavefront: phase 3's emission buffer (1024 floats in walk order).  Round 4: the fill loop no longer
+     * touches LDS — upcoming events and k-mers wait in the idle lanes 52..63 of the band registers (below) — so under
+     * ABEA_NO_ASM only, the C++ twin of the loop keeps its two rings here: [1024, 1536) events, [2048, 4096) k-mers. */
     __shared__ __attribute__((aligned(4096))) uint4 smem[256];
+    float* const lp_s = reinterpret_cast<float*>(smem);                      /* 1024 x 4 B */
+#ifdef ABEA_NO_ASM
     abea_kpar_t* const k_ring = reinterpret_cast<abea_kpar_t*>(smem + 128);  /* 128 x 16 B */
     float* const e_ring = reinterpret_cast<float*>(smem + 64);               /* 128 x 4 B  */
-    float* const lp_s = reinterpret_cast<float*>(smem);                      /* 1024 x 4 B */
+#endif
 
     const abea_read_desc* d = descs + blockIdx.x;
     const int lane = threadIdx.x;
@@ -226,13 +221,13 @@ void abea_align_kernel(const abea_read_desc* __restrict__ descs,
     const int nb_pad = n_groups * ABEA_GROUP;
     const double lp_skip = d->lp_skip, lp_stay = d->lp_stay, lp_step = d->lp_step, lp_trim = d->lp_trim;
     const int o0 = 2 * lane, o1 = o0 + 1;              /* offsets owned by this lane */
-    const bool hi = lane >= 50;                        /* FIFO lanes: scores pinned to -inf */
+    [[maybe_unused]] const bool hi = lane >= 50;        /* FIFO lanes: scores pinned to -inf (C++ twin) */
 
     /* ---- state after bands 0 and 1 (align.c:277-291) ---- */
     int ll_e = 50, ll_k = -51;                          /* lower-left of band 1 */
     float Pf0 = NINF, Pf1 = NINF;                       /* band 1 scores (offset 50 = trim of event 0) */
     if (lane == 25) Pf0 = (float)lp_trim;
-    double P0 = (double)Pf0, P1 = (double)Pf1;
+    [[maybe_unused]] double P0 = (double)Pf0, P1 = (double)Pf1;
     /* band 1 was a "down" move from band 0: in band-1 frame U[o] = band0[o], L[o] = band0[o-1];
      * band 0 is -inf except offset 50 (start cell, 0.0f) */
     double U0 = (lane == 25) ? 0.0 : (double)NINF, U1 = (double)NINF;
@@ -251,7 +246,8 @@ void abea_align_kernel(const abea_read_desc* __restrict__ descs,
         g0 = p0.gpm; c0 = p0.ck; i0 = p0.istd;
         g1 = p1.gpm; c1 = p1.ck; i1 = p1.istd;
     }
-    /* LDS rings: entry i lives at slot i & 127 (chunk c = i >> 6 in half c & 1) */
+#ifdef ABEA_NO_ASM
+    /* C++ twin only — LDS rings: entry i lives at slot i & 127 (chunk c = i >> 6 in half c & 1) */
     int e_next = ll_e + 1;                              /* event entering at offset 0 on the next down move */
     int k_next = ll_k + 128;                            /* k-mer entering at offset 127 on the next right move */
     e_ring[lane] = evm[min(lane, E - 1)];
@@ -265,12 +261,10 @@ void abea_align_kernel(const abea_read_desc* __restrict__ descs,
     float nx = e_ring[e_next & 127];
     float nkg, nkc; double nki;                         /* incoming k-mer (uniform) */
     { const abea_kpar_t t = k_ring[k_next & 127]; nkg = t.gpm; nkc = t.ck; nki = t.istd; }
-#ifdef ABEA_FIFO   /* experiment (tools/gen_fill_asm.py, ABEA_FIFO=1): no rings.  Lanes 52..63 of the event registers hold the next 24
-                    * events, lane 63's cell 1 first (a down move rotates the wave); their k-mer quads hold offsets 104..127 as they
-                    * always did.  The pending registers are what the next refill, 24 moves of a kind later, puts into those lanes. */
-#ifdef ABEA_NO_ASM
-#error "ABEA_FIFO is a layout of the asm loop"
-#endif
+#else
+    /* Lanes 52..63 of the event registers hold the next 24 events (lane 63's cell 1 first; a down move rotates the wave);
+     * their k-mer quads hold offsets 104..127 as they always did.  The pending registers are what the next refill, 24 moves
+     * of a kind later, puts into those lanes. */
     float px0, px1, kag, kac, kbg, kbc; double kai, kbi;
     int e_cnt = 24, k_cnt = 24;
     {
@@ -286,11 +280,12 @@ void abea_align_kernel(const abea_read_desc* __restrict__ descs,
     /* trace accumulator: 4 bits per band shifted in from the right, COMPLEMENTED (see abea_fill.inc); bands 0,1:
      * only band 1 offset 50 = FROM_U */
     uint32_t acc = (lane == 25) ? 0xFEu : 0xFFu;
-    uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    [[maybe_unused]] uint32_t a0 = 0; uint32_t a1 = 0, a2 = 0, a3 = 0;
     uint32_t mvacc = 0, mvprev = 0;                     /* band-move bits of this group / the group below */
     int b = 2;
 
-    [[maybe_unused]] auto step = [&](auto border_tag) {   /* reference semantics of one band; the shipped path is the asm below */
+#ifdef ABEA_NO_ASM   /* the C++ twin of the band loop: reference semantics of one band (LDS-ring feeds); the shipped path is the asm below */
+    auto step = [&](auto border_tag) {
         constexpr bool BORDER = decltype(border_tag)::value;
         /* ---- Suzuki-Kasahara move (align.c:304-322): right = ll < ur, alternate when both are -inf ---- */
         const float s_ll = readlane_f(Pf0, 0);
@@ -396,6 +391,7 @@ void abea_align_kernel(const abea_read_desc* __restrict__ descs,
         }
         ++b;
     };
+#endif
 
     while (b < nb_pad) {
         /* bands for which every one of the 100 cells is inside the matrix and neither the trim column
@@ -412,7 +408,6 @@ void abea_align_kernel(const abea_read_desc* __restrict__ descs,
              * band has touched the bottom/right edge of the matrix (never interior again: ll_e, ll_k only grow) */
             uint32_t toff = (uint32_t)lane * 16u + (uint32_t)(b >> 5) * 1024u;
             uint32_t t0, t1, t2, t3, t4, cnt, per; uint64_t cm0a, cm0b, cm1a, cm1b, cv0, cv1;
-            const uint32_t kring_a = (uint32_t)(uintptr_t)k_ring, ering_a = (uint32_t)(uintptr_t)e_ring;
             /* "s" operands must be provably wave-uniform */
             int s_ll_e = uni(ll_e), s_ll_k = uni(ll_k);
             int s_b = uni(b);
@@ -421,11 +416,6 @@ void abea_align_kernel(const abea_read_desc* __restrict__ descs,
             const int s_b_end = interior ? uni(b + run)
                               : past_edge ? uni(nb_pad)
                               : uni(min(nb_pad, b + max(max(-ll_k, 99 - ll_e), 256)));   /* chunk: re-check for the interior variant later */
-            /* ring addresses carry the entry's position in its 64-entry chunk in bits 31:26: the loop's add carries out when
-             * a new chunk is entered (refill + ring wrap), see gen_fill_asm.py */
-            uint32_t s_k_addr = (uint32_t)uni((int)((kring_a + ((uint32_t)k_next & 127u) * 16u) | (((uint32_t)k_next & 63u) << 26)));
-            uint32_t s_e_addr = (uint32_t)uni((int)((ering_a + ((uint32_t)e_next & 127u) * 4u) | (((uint32_t)e_next & 63u) << 26)));
-            if (kring_a < 252u || kring_a + 2048u > 65536u) __builtin_trap();                /* M0 = k_addr - 252, 16-bit LDS addresses */   /* ring wrap uses s_bitset0; M0 = k_addr - 252 */
             const int Km1 = K - 1, Em1 = E - 1;
             const uint64_t m50 = 1ull << ABEA_MOVE_LANE;
             uint32_t s_mvacc = (uint32_t)uni((int)mvacc), s_mvprev = (uint32_t)uni((int)mvprev);
@@ -435,37 +425,20 @@ void abea_align_kernel(const abea_read_desc* __restrict__ descs,
             uint4* u_trace = (uint4*)uni_p(trace);
             uint32_t s_best = (uint32_t)uni((int)__float_as_uint(best));
             int s_best_e = uni(best_e), s_best_llk = uni(best_llk);
-#ifdef ABEA_FIFO
-#define ABEA_FILL_VOUTS \
+#define ABEA_FILL_OUTS \
                   [Pf0] "+v"(Pf0), [Pf1] "+v"(Pf1), [x0] "+v"(x0), [x1] "+v"(x1), \
                   [g0] "+v"(g0), [c0] "+v"(c0), [g1] "+v"(g1), [c1] "+v"(c1), \
                   [px0] "+v"(px0), [px1] "+v"(px1), [kag] "+v"(kag), [kac] "+v"(kac), [kbg] "+v"(kbg), [kbc] "+v"(kbc), \
                   [a1] "+v"(a1), [a2] "+v"(a2), [a3] "+v"(a3), [acc] "+v"(acc), [toff] "+v"(toff), \
                   [i0] "+v"(i0), [i1] "+v"(i1), [kai] "+v"(kai), [kbi] "+v"(kbi), \
-                  [L0] "+v"(L0), [L1] "+v"(L1), [U0] "+v"(U0), [U1] "+v"(U1), [e_cnt] "+s"(e_cnt), [k_cnt] "+s"(k_cnt)
-#define ABEA_FILL_VINS [lane] "v"(lane)
-#elif defined(ABEA_FILL_TIED_VOUTS)      /* experiment: the loop state is bound to its physical registers, no entry/exit copies */
-#define ABEA_FILL_VOUTS ABEA_FILL_TIED_VOUTS
-#define ABEA_FILL_VINS ABEA_FILL_TIED_VINS
-#else
-#define ABEA_FILL_VOUTS \
-                  [Pf0] "+v"(Pf0), [Pf1] "+v"(Pf1), [x0] "+v"(x0), [x1] "+v"(x1), \
-                  [g0] "+v"(g0), [c0] "+v"(c0), [g1] "+v"(g1), [c1] "+v"(c1), \
-                  [nkg] "+v"(nkg), [nkc] "+v"(nkc), [nx] "+v"(nx), [e_pend] "+v"(e_pend), \
-                  [kpg] "+v"(kpg), [kpc] "+v"(kpc), [a1] "+v"(a1), [a2] "+v"(a2), [a3] "+v"(a3), \
-                  [acc] "+v"(acc), [toff] "+v"(toff), \
-                  [i0] "+v"(i0), [i1] "+v"(i1), [nki] "+v"(nki), [kpi] "+v"(kpi), \
-                  [L0] "+v"(L0), [L1] "+v"(L1), [U0] "+v"(U0), [U1] "+v"(U1)
-#define ABEA_FILL_VINS [lane] "v"(lane)
-#endif
-#define ABEA_FILL_OUTS ABEA_FILL_VOUTS, \
-                  [ll_e] "+s"(s_ll_e), [ll_k] "+s"(s_ll_k), [e_addr] "+s"(s_e_addr), [k_addr] "+s"(s_k_addr), \
+                  [L0] "+v"(L0), [L1] "+v"(L1), [U0] "+v"(U0), [U1] "+v"(U1), [e_cnt] "+s"(e_cnt), [k_cnt] "+s"(k_cnt), \
+                  [ll_e] "+s"(s_ll_e), [ll_k] "+s"(s_ll_k), \
                   [mvacc] "+s"(s_mvacc), [mvprev] "+s"(s_mvprev), [b] "+s"(s_b), \
                   [t0] "=&s"(t0), [t1] "=&s"(t1), [cnt] "=&s"(cnt), [per] "=&s"(per), [cm0a] "=&s"(cm0a), [cm0b] "=&s"(cm0b), \
                   [cm1a] "=&s"(cm1a), [cm1b] "=&s"(cm1b)
 #define ABEA_FILL_INS \
-                  ABEA_FILL_VINS, [lp_step] "s"(u_step), [lp_stay] "s"(u_stay), [lp_skip] "s"(u_skip), \
-                  [Km1] "s"(uni(Km1)), [Em1] "s"(uni(Em1)), [kring] "s"(kring_a), [ering] "s"(ering_a), \
+                  [lane] "v"(lane), [lp_step] "s"(u_step), [lp_stay] "s"(u_stay), [lp_skip] "s"(u_skip), \
+                  [Km1] "s"(uni(Km1)), [Em1] "s"(uni(Em1)), \
                   [b_end] "s"(s_b_end), [m50] "s"(m50), [evm] "s"(u_evm), [kpar] "s"(u_kpar), [trace] "s"(u_trace), \
                   [ninf] "s"(0xff800000u)
             asm volatile(ABEA_FILL_ASM
@@ -474,7 +447,7 @@ void abea_align_kernel(const abea_read_desc* __restrict__ descs,
                 : ABEA_FILL_INS, [lp_trim] "s"(u_trim), [mode] "s"(uni(interior ? 0 : 1))
                 : ABEA_FILL_CLOBBERS);
             best = __uint_as_float(s_best); best_e = s_best_e; best_llk = s_best_llk;
-            ll_e = s_ll_e; ll_k = s_ll_k; e_next = ll_e + 1; k_next = ll_k + 128; b = s_b; run = 0;
+            ll_e = s_ll_e; ll_k = s_ll_k; b = s_b; run = 0;
             mvacc = s_mvacc; mvprev = s_mvprev;
             P0 = (double)Pf0; P1 = (double)Pf1;
 #endif
@@ -1012,9 +985,12 @@ void abea_ev_pwrite_kernel(int n_reads, const int32_t* __restrict__ order, const
     if (need_seq[r]) return;
     const int n = n_samples[r];
     const int lo = j * ABEA_EV_SEG_SUM, hi = min(lo + ABEA_EV_SEG_SUM, n);
-    double* __restrict__ Sw = S_all + wave_base[w] + lane;
-    double* __restrict__ Qw = Q_all + wave_base[w] + lane;
-    if (j == 0) { Sw[0] = 0.0; Qw[0] = 0.0; }
+    /* round 4: S and Q of a sample sit side by side (one 16-byte element at [row][lane]; the host allocates the two arrays
+     * back to back, Q_all = S_all + entries, and the pair array overlays them): the event pass looks both up per boundary,
+     * and a look-up costs a 64-byte sector whatever it reads */
+    (void)Q_all;
+    double2* __restrict__ SQw = reinterpret_cast<double2*>(S_all) + wave_base[w] + lane;
+    if (j == 0) SQw[0] = make_double2(0.0, 0.0);
     if (lo >= hi) return;
     const int16_t* __restrict__ sig = signal + sig_ptr[r];
     const float offset = scaling[3 * r], raw_unit = scaling[3 * r + 1] / scaling[3 * r + 2];
@@ -1023,7 +999,7 @@ void abea_ev_pwrite_kernel(int n_reads, const int32_t* __restrict__ order, const
     auto take = [&](int p, int raw) {
         const float x = abea_pa(raw, offset, raw_unit);
         S += (double)x; Q += (double)__fmul_rn(x, x);
-        Sw[(size_t)(p + 1) * 64] = S; Qw[(size_t)(p + 1) * 64] = Q;
+        SQw[(size_t)(p + 1) * 64] = make_double2(S, Q);
     };
     int p = lo;
     if ((((uintptr_t)(sig + lo)) & 15u) == 0u)
@@ -1051,15 +1027,15 @@ void abea_ev_sums_kernel(int n_reads, const int32_t* __restrict__ order, const i
     const int16_t* __restrict__ sig = signal + sig_ptr[r];
     const float offset = scaling[3 * r], range = scaling[3 * r + 1], digitisation = scaling[3 * r + 2];
     const float raw_unit = range / digitisation;                    /* f5c.c:693 */
-    double* __restrict__ Sw = S_all + wave_base[blockIdx.x] + lane;
-    double* __restrict__ Qw = Q_all + wave_base[blockIdx.x] + lane;
+    (void)Q_all;
+    double2* __restrict__ SQw = reinterpret_cast<double2*>(S_all) + wave_base[blockIdx.x] + lane;   /* {S, Q} pairs, see abea_ev_pwrite_kernel */
     double S = 0.0, Q = 0.0;
-    Sw[0] = 0.0; Qw[0] = 0.0;                                       /* S[0] = Q[0] = 0 */
+    SQw[0] = make_double2(0.0, 0.0);                                /* S[0] = Q[0] = 0 */
     auto sample = [&](int i, int raw) {
         const float x = ((float)raw + offset) * raw_unit;            /* f5c.c:694-696 */
         S = S + (double)x;                                           /* events.c:309-312; the square is a float product */
         Q = Q + (double)(x * x);
-        Sw[(size_t)(i + 1) * 64] = S; Qw[(size_t)(i + 1) * 64] = Q;
+        SQw[(size_t)(i + 1) * 64] = make_double2(S, Q);
     };
     int i = 0;
     const int head = min(n, (int)(((16u - ((uintptr_t)sig & 15u)) & 15u) >> 1));
@@ -1117,15 +1093,16 @@ static __device__ __forceinline__ void tstat_body(int n_reads, const int32_t* __
     const int n = slot < n_reads ? n_samples[order[slot]] : 0;
     const int64_t base = wave_base[w];
     const int len = wave_len[w];
-    const double* Sw = S_all + base + lane;
-    const double* Qw = Q_all + base + lane;
+    (void)Q_all;
+    const double2* SQw = reinterpret_cast<const double2*>(S_all) + base + lane;
     constexpr int ROWS = POS + 2 * W2;
     for (int p0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * POS; p0 < len; p0 += gridDim.x * 4 * POS) {
         double sr[ROWS], qr[ROWS];
         #pragma unroll
         for (int i = 0; i < ROWS; ++i) {
             const int row = min(max(p0 - W2 + i, 0), len - 1);
-            sr[i] = Sw[(int64_t)row * 64]; qr[i] = Qw[(int64_t)row * 64];
+            const double2 v = SQw[(int64_t)row * 64];
+            sr[i] = v.x; qr[i] = v.y;
         }
         #pragma unroll
         for (int i = 0; i < POS; ++i) {
@@ -1492,7 +1469,10 @@ void abea_ev_create_kernel(int n_reads, const int32_t* __restrict__ order, const
             b[i] = (j < 0) ? 0ull : (j >= n_ev - 1) ? (unsigned long long)n : (unsigned long long)pk[(size_t)min(j, wcap - 1) * 64];
         }
         #pragma unroll
-        for (int i = 0; i < 9; ++i) { sb[i] = S_all[base + (int64_t)b[i] * 64]; qb[i] = Q_all[base + (int64_t)b[i] * 64]; }
+        for (int i = 0; i < 9; ++i) {                                /* one 16-byte look-up per boundary: {S, Q} side by side */
+            const double2 v = reinterpret_cast<const double2*>(S_all)[base + (int64_t)b[i] * 64];
+            sb[i] = v.x; qb[i] = v.y;
+        }
         #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int j = j0 + i;

@@ -355,10 +355,10 @@ int abea_host_plan_chunks(const int32_t* read_len, const int32_t* n_events, int3
 /* The worker-thread / CPU-affinity plan of the host entry (host-only, pure): per DEVICE context
  * threads = (usable_cpus - 2) / n_devices clamped to [1, 16] (ABEA_HOST_THREADS overrides, per device), bound to the CPUs of
  * the device's NUMA node that the process may run on when the machine has several nodes and that set is at least as large
- * (the rule this function reports; ABEA_HOST_NUMA=0 removes the binding from the report).  At run time the library applies
- * the binding only when ABEA_HOST_NUMA=1 is set: the host loops read the caller's event tables (24 B per event) from
- * wherever the caller placed them and write 4 B per event of staging, so binding a device's workers to its node pays only
- * if the caller's buffers are on that node too (measured: DESIGN.md §5).  cpulists use the sysfs format ("0-63,128-191"); allowed_cpulist NULL or "" = all.
+ * — when ABEA_HOST_NUMA=1.  The binding is opt-in, and this report and the run-time path read the SAME switch: the host
+ * loops read the caller's event tables (24 B per event) from wherever the caller placed them and write 4 B per event of
+ * staging, so binding a device's workers to its node pays only if the caller's buffers are on that node too (measured:
+ * DESIGN.md §5); without ABEA_HOST_NUMA=1 every bind list is "".  cpulists use the sysfs format ("0-63,128-191"); allowed_cpulist NULL or "" = all.
  * bind_cpulists (may be NULL) receives n_devices strings of cap_each bytes, "" = not bound.  At run time the inputs come
  * from sched_getaffinity, the cgroup CPU quota, /sys/bus/pci/devices/<bdf>/numa_node and /sys/devices/system/node. */
 int abea_host_plan_threads(int32_t usable_cpus, const char* allowed_cpulist, int32_t n_devices, const int32_t* device_numa_node,

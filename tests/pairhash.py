@@ -6,6 +6,8 @@ from the oracle's pair lists (tests/golden/make_config_goldens.py) and the GPU t
   mix(x)  = (y ^ (y >> 29)) * C2 ,  y = x * C1        (two odd 64-bit constants)
 
 Position-dependent (a swap of two pairs changes it), vectorisable with numpy over a whole flattened batch (reduceat).
+The pair (0, 0) alone contributes 0 (mix(0) = 0); the tests compare n_pairs beside the hash, so a list is never mistaken
+for an empty one.
 """
 import numpy as np
 

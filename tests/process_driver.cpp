@@ -137,7 +137,7 @@ int main(int argc, char** argv) {
     /* output_db_rsq, both formats (size query first, then the text) */
     std::vector<const char*> idp(n); std::vector<const abea_event_t*> evp(n);
     for (int32_t i = 0; i < n; ++i) { idp[i] = ids[i].c_str(); evp[i] = et[i].event; }
-    for (int fmt = 0; fmt < 2; ++fmt) {
+    for (int fmt = 0; fmt < 2 && mode != 1; ++fmt) {        /* mode 1's tables hold means only: no sample coordinates to print */
         int32_t printed = 0;
         const int64_t len = abea_rsq_format_batch(nullptr, 0, fmt, n, idp.data(), read_len.data(), k, b2e.data(), evp.data(),
                                                   nsample.data(), sc.data(), flag.data(), rna, &printed);

@@ -2,8 +2,8 @@
 abea_walk.inc: scalar traceback walk), EXECUTED on the CPU by tools/gfx950_emu.py and compared with the oracle.
 
 This is the only place where the hot loop's arithmetic and control flow are checked without a GPU: the C++ around the
-statements (abea_kernels.hip: the state after bands 0 and 1, the LDS rings, the re-entry loop, the expansion of the walk's
-codes) is mirrored below line by line, the statements themselves are taken from the generated files as they are compiled."""
+statements (abea_kernels.hip: the state after bands 0 and 1, the FIFO lanes 52..63 that hold the upcoming events and k-mers,
+the re-entry loop, the expansion of the walk's codes) is mirrored below line by line, the statements themselves are taken from the generated files as they are compiled."""
 import math
 import os
 import sys
@@ -34,7 +34,7 @@ def f64bits(x):
     return int(np.float64(x).view(np.uint64))
 
 
-def emulate_align(seq: bytes, means: np.ndarray, model, k: int, scale, shift, fill=None, walk=None, fifo=False):
+def emulate_align(seq: bytes, means: np.ndarray, model, k: int, scale, shift, fill=None, walk=None):
     """abea_pre_kernel + abea_align_kernel for one read; returns (pairs [n, 2] int32 in ascending order, info)."""
     L, E = len(seq), len(means)
     K = L - k + 1
@@ -65,8 +65,6 @@ def emulate_align(seq: bytes, means: np.ndarray, model, k: int, scale, shift, fi
     a_kpar = w.alloc(kpar)
     a_trace = w.alloc(np.zeros(n_groups * 64 * 4, dtype=np.uint32))
     a_codes = w.alloc(np.zeros((E + K) // 16 + 8, dtype=np.uint32))
-    KRING, ERING = 2048, 1024                                    # smem at LDS address 0: k_ring = smem + 128, e_ring = smem + 64
-
     def ev(i):
         return evm[np.minimum(i, E - 1)]
 
@@ -91,17 +89,6 @@ def emulate_align(seq: bytes, means: np.ndarray, model, k: int, scale, shift, fi
         return out
     x0, x1 = ev_or0(ll_e - o0), ev_or0(ll_e - o1)
     p0, p1 = kp_or0(ll_k + o0), kp_or0(ll_k + o1)
-    e_next, k_next = ll_e + 1, ll_k + 128
-    lds_f = w.lds.view(np.float32)
-    lds_k = w.lds[KRING:KRING + 128 * 16].view(KPAR_DT)
-    lds_f[ERING // 4 + lane] = ev(lane)
-    lds_f[ERING // 4 + 64 + lane] = ev(64 + lane)
-    e_pend = ev(128 + lane)
-    lds_k[64 + lane] = kp(64 + lane)
-    lds_k[lane] = kp(128 + lane)
-    kpend = kp(192 + lane)
-    nx = np.full(64, lds_f[ERING // 4 + (e_next & 127)], dtype=np.float32)
-    nk = np.full(64, lds_k[k_next & 127], dtype=KPAR_DT)
     acc = np.full(64, 0xFF, dtype=np.uint32); acc[25] = 0xFE
 
     def bits(a):
@@ -109,30 +96,28 @@ def emulate_align(seq: bytes, means: np.ndarray, model, k: int, scale, shift, fi
 
     def bits64(a):
         return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
-    if fifo:       # the ABEA_FIFO experiment: lanes 52..63 of the event registers hold the next 24 events (lane 63's cell 1 first);
-        # the pending registers hold what the next refill, 24 moves of a kind later, will put into those lanes
-        e_in = ll_e + 1
-        q = 2 * (63 - lane)
-        fl = lane >= 52
-        x1 = np.where(fl, ev(e_in + q), x1).astype(np.float32); x0 = np.where(fl, ev(e_in + q + 1), x0).astype(np.float32)
-        ka, kb = kp(np.maximum(ll_k + 24 + 2 * lane, 0)), kp(np.maximum(ll_k + 24 + 2 * lane + 1, 0))
-        for name, val in (("px1", bits(ev(e_in + 24 + q))), ("px0", bits(ev(e_in + 24 + q + 1))), ("kag", bits(ka["gpm"])),
-                          ("kac", bits(ka["ck"])), ("kbg", bits(kb["gpm"])), ("kbc", bits(kb["ck"]))):
-            w.bind_v(name, val)
-        w.bind_v("kai", bits64(ka["istd"]), wide=True); w.bind_v("kbi", bits64(kb["istd"]), wide=True)
-        w.sym.update(e_cnt=24, k_cnt=24)
+    # lanes 52..63 of the event registers hold the next 24 events (lane 63's cell 1 first); the pending registers hold what the
+    # next refill, 24 moves of a kind later, will put into those lanes (abea_kernels.hip, phase 1 set-up)
+    e_in = ll_e + 1
+    q = 2 * (63 - lane)
+    fl = lane >= 52
+    x1 = np.where(fl, ev(e_in + q), x1).astype(np.float32); x0 = np.where(fl, ev(e_in + q + 1), x0).astype(np.float32)
+    ka, kb = kp(np.maximum(ll_k + 24 + 2 * lane, 0)), kp(np.maximum(ll_k + 24 + 2 * lane + 1, 0))
+    for name, val in (("px1", bits(ev(e_in + 24 + q))), ("px0", bits(ev(e_in + 24 + q + 1))), ("kag", bits(ka["gpm"])),
+                      ("kac", bits(ka["ck"])), ("kbg", bits(kb["gpm"])), ("kbc", bits(kb["ck"]))):
+        w.bind_v(name, val)
+    w.bind_v("kai", bits64(ka["istd"]), wide=True); w.bind_v("kbi", bits64(kb["istd"]), wide=True)
+    w.sym.update(e_cnt=24, k_cnt=24)
     for name, val in (("Pf0", Pf0), ("Pf1", Pf1), ("x0", bits(x0)), ("x1", bits(x1)), ("g0", bits(p0["gpm"])), ("c0", bits(p0["ck"])),
-                      ("g1", bits(p1["gpm"])), ("c1", bits(p1["ck"])), ("nkg", bits(nk["gpm"])), ("nkc", bits(nk["ck"])),
-                      ("nx", bits(nx)), ("e_pend", bits(e_pend)), ("kpg", bits(kpend["gpm"])), ("kpc", bits(kpend["ck"])),
+                      ("g1", bits(p1["gpm"])), ("c1", bits(p1["ck"])),
                       ("a1", np.zeros(64, np.uint32)), ("a2", np.zeros(64, np.uint32)), ("a3", np.zeros(64, np.uint32)),
                       ("acc", acc), ("toff", np.zeros(64, np.uint32)), ("lane", lane.astype(np.uint32))):
         w.bind_v(name, val)
-    for name, val in (("i0", bits64(p0["istd"])), ("i1", bits64(p1["istd"])), ("nki", bits64(nk["istd"])),
-                      ("kpi", bits64(kpend["istd"])), ("L0", L0), ("L1", L1), ("U0", U0), ("U1", U1)):
+    for name, val in (("i0", bits64(p0["istd"])), ("i1", bits64(p1["istd"])), ("L0", L0), ("L1", L1), ("U0", U0), ("U1", U1)):
         w.bind_v(name, val, wide=True)
     S = w.sym
     S.update(lp_step=f64bits(lp_step), lp_stay=f64bits(lp_stay), lp_skip=f64bits(lp_skip), lp_trim=f64bits(lp_trim),
-             Km1=K - 1, Em1=E - 1, kring=KRING, ering=ERING, m50=1 << 50, evm=a_evm, kpar=a_kpar, trace=a_trace,
+             Km1=K - 1, Em1=E - 1, m50=1 << 50, evm=a_evm, kpar=a_kpar, trace=a_trace,
              ninf=NINF32, mvacc=0, mvprev=0, best=NINF32, best_e=0, best_llk=0)
     for t in ("t0", "t1", "t2", "t3", "t4", "cnt", "per", "cm0a", "cm0b", "cm1a", "cm1b", "cv0", "cv1"):
         S[t] = 0xDEADBEEF                                        # write-only operands: garbage at entry
@@ -144,13 +129,10 @@ def emulate_align(seq: bytes, means: np.ndarray, model, k: int, scale, shift, fi
         past_edge = (E - 2 - ll_e <= 0) or (K - 102 - ll_k <= 0)
         b_end = b + run if interior else (nb_pad if past_edge else min(nb_pad, b + max(max(-ll_k, 99 - ll_e), 256)))
         w.bind_v("toff", (lane * 16 + (b >> 5) * 1024).astype(np.uint32))
-        S.update(ll_e=ll_e & M32, ll_k=ll_k & M32, b=b, b_end=b_end, mode=0 if interior else 1,
-                 k_addr=((KRING + (k_next & 127) * 16) | ((k_next & 63) << 26)) & M32,
-                 e_addr=((ERING + (e_next & 127) * 4) | ((e_next & 63) << 26)) & M32)
+        S.update(ll_e=ll_e & M32, ll_k=ll_k & M32, b=b, b_end=b_end, mode=0 if interior else 1)
         w.run(fill or FILL)
         ll_e = S["ll_e"] - (1 << 32) if S["ll_e"] & 0x80000000 else S["ll_e"]
         ll_k = S["ll_k"] - (1 << 32) if S["ll_k"] & 0x80000000 else S["ll_k"]
-        e_next, k_next = ll_e + 1, ll_k + 128
         assert S["b"] > b, "the statement made no progress"
         b = S["b"]
         entries += 1
@@ -229,9 +211,10 @@ def test_emulated_statements_reproduce_the_oracle(seed, n_bases, epb):
     info = check_against_oracle(seq, ev, model, k)
     assert info["qc_pass"]
     mix = info["mix"]
-    if n_bases >= 400:     # what the run went through: the interior variant (only it packs trace bits with v_alignbit), both ring
-        assert mix["v_alignbit_b32"] >= 4 * 500            # refills, group stores, the border variant's selects
-        assert mix["ds_write_b128"] >= 4 and mix["ds_write_b32"] >= 8 and mix["global_store_dwordx4"] >= 40
+    if n_bases >= 400:     # what the run went through: the interior variant (only it packs trace bits with v_alignbit), both FIFO
+        assert mix["v_alignbit_b32"] >= 4 * 500            # refills (every 24 moves of a kind), group stores, the border variant's selects
+        assert mix["global_load_dwordx4"] >= 2 * 10 and mix["global_load_dword"] >= 2 * 20 and mix["global_store_dwordx4"] >= 40
+        assert not any(op.startswith("ds_") for op in mix)  # the fill loop does not touch LDS
         assert mix["v_cndmask_b32"] > 1000 and info["entries"] >= 3
 
 
@@ -270,35 +253,18 @@ def test_a_planted_fault_in_the_statement_is_noticed():
         check_against_oracle(seq, ev, model, k, fill=skewed)
 
 
-def test_next_round_candidates_reproduce_the_oracle():
-    """Generator switches that are NOT the shipped loop are kept correct here so that they can go straight to a GPU A/B:
-    ABEA_FIFO (no LDS rings: events and k-mers wait in lanes 52..63 and are topped up every 24 moves), ABEA_WALK2 (the step
-    loop of the walk split by trace-group half, 46.9 -> 42.6 scalar instructions per step) and ABEA_EARLY (the move decision
-    issued ahead of the trace packing)."""
-    import subprocess
-    env = dict(os.environ, ABEA_FIFO="1", ABEA_WALK2="1", ABEA_EARLY="1")
-    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "gen_fill_asm.py")], env=env, stdout=subprocess.DEVNULL)
-    fill = asm_lint.statement(os.path.join(CSRC, "abea_fill_exp.inc"), "ABEA_FILL_ASM")
-    walk2 = asm_lint.statement(os.path.join(CSRC, "abea_walk_exp.inc"), "ABEA_WALK_ASM")
-    assert not any(ln.startswith("ds_") for ln in fill) and any("wave_ror:1" in ln for ln in fill)
-    assert any(ln.startswith("step_hi") for ln in walk2) and len(walk2) > len(WALK)
-    for path, macro in ((os.path.join(CSRC, "abea_fill_exp.inc"), "ABEA_FILL_ASM"), (os.path.join(CSRC, "abea_walk_exp.inc"), "ABEA_WALK_ASM")):
-        found, _, dead = asm_lint.lint(asm_lint.statement(path, macro), "exp", asm_lint.undefined_at_entry(path, macro))
-        found = [f for f in found if "s[90:91]" not in f]       # the walk's first step always loads s[88:91] (asm_lint.WAIVERS)
-        assert not found and dead == 0, found[:5]
+def test_the_shipped_statements_are_the_round_4_design():
+    """No LDS in the fill loop (the upcoming events and k-mers wait in lanes 52..63, rotated in with wave_ror), the walk's step
+    loop exists per trace-group half; more reads through both, among them a hostile one."""
+    assert not any(ln.startswith("ds_") for ln in FILL) and any("wave_ror:1" in ln for ln in FILL)
+    assert any(ln.startswith("step_hi") for ln in WALK) and any(ln.startswith("step_lo") for ln in WALK)
     k, model = MODEL
-    for seed, n_bases, epb, kind in ((1, 60, 2.0, ""), (4, 420, 2.2, ""), (9, 330, 3.0, ""), (12, 230, 2.0, "noise")):
+    for seed, n_bases, epb, kind in ((9, 330, 3.0, ""), (12, 230, 2.0, "noise"), (21, 500, 1.1, "")):
         rng = np.random.default_rng(seed)
         seq, ev = synthetic_read(rng, model, k, n_bases, epb)
         if kind == "noise":
             ev["mean"] = rng.normal(90, 12, size=len(ev)).astype(np.float32)
-        scale, shift = orc.estimate_scalings(seq, model, k, ev)
-        o_pairs, o_diag = orc.align(seq, ev, model, k, scale, shift)
-        pairs, info = emulate_align(seq, ev["mean"], model, k, scale, shift, fill=fill, walk=walk2, fifo=True)
-        assert np.float32(info["best"]) == np.float32(o_diag["max_score"]) and info["best_e"] == int(o_diag["best_event"])
-        assert info["n"] == int(o_diag["n_aligned"]) and info["max_gap"] == int(o_diag["max_gap"])
-        if len(o_pairs):
-            assert (pairs == o_pairs.view(np.int32).reshape(-1, 2)).all()
+        check_against_oracle(seq, ev, model, k)
 
 
 def test_emulated_statements_on_a_real_read_against_the_reference_golden():

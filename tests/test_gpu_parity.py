@@ -347,6 +347,10 @@ def test_baseline_config2_full_size_bit_exact(orc, r9):
         ora = orc.align_batch(batch, model, k, n_threads=workers)
         _check_batch(batch, (pairs, n_pairs, diag), ora, "config2")
         assert (n_pairs > 0).mean() > 0.95                       # QC-pass fraction
+        # the committed per-read goldens of this config (tests/golden/config_goldens_r9_10k_8kb.npz) say the same, so the
+        # hash route that configs[2] and [4] rely on is itself checked against an element-wise comparison
+        from test_full_size import check_against_config_goldens
+        check_against_config_goldens("r9_10k_8kb", batch, pairs, n_pairs, diag)
         flat = pairs.view(np.int32).reshape(-1, 2)
         for i in np.random.default_rng(0).choice(len(n_pairs), 200, replace=False):
             s, m = int(batch["pair_ptr"][i]), int(n_pairs[i])

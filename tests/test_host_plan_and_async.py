@@ -30,18 +30,24 @@ def test_thread_plan_is_per_device(monkeypatch):
 def test_thread_plan_binds_to_the_devices_numa_node(monkeypatch):
     from f5c_amd import abea
     monkeypatch.delenv("ABEA_HOST_THREADS", raising=False)
-    monkeypatch.delenv("ABEA_HOST_NUMA", raising=False)
+    monkeypatch.setenv("ABEA_HOST_NUMA", "1")                  # opt-in: the one switch the library's run-time path reads too
     dev_node = [0, 0, 0, 0, 1, 1, 1, 1]
     thr, bind = abea.plan_host_threads(256, 8, dev_node, NODES)
     assert bind[:4] == [NODES[0]] * 4 and bind[4:] == [NODES[1]] * 4
     # the process's affinity mask is honoured; a node with fewer allowed CPUs than threads is not bound to
     thr, bind = abea.plan_host_threads(64, 2, [0, 1], NODES, allowed="0-31,64-71")
     assert thr.tolist() == [16, 16] and bind == ["0-31", ""]
-    # unknown node, a single-node machine, or ABEA_HOST_NUMA=0: no binding
+    # unknown node, a single-node machine, a node missing from a sparse numbering, or the switch not set: no binding
     assert abea.plan_host_threads(64, 2, [-1, 5], NODES)[1] == ["", ""]
     assert abea.plan_host_threads(64, 1, [0], NODES[:1])[1] == [""]
-    monkeypatch.setenv("ABEA_HOST_NUMA", "0")
-    assert abea.plan_host_threads(256, 8, dev_node, NODES)[1] == [""] * 8
+    assert abea.plan_host_threads(64, 2, [0, 2], [NODES[0], "", NODES[1]])[1] == [NODES[0], NODES[1]]
+    assert abea.plan_host_threads(64, 2, [0, 1], [NODES[0], "", NODES[1]])[1] == [NODES[0], ""]
+    for off in ("0", None):
+        if off is None:
+            monkeypatch.delenv("ABEA_HOST_NUMA", raising=False)
+        else:
+            monkeypatch.setenv("ABEA_HOST_NUMA", off)
+        assert abea.plan_host_threads(256, 8, dev_node, NODES)[1] == [""] * 8
     with pytest.raises(abea.AbeaError):
         abea.plan_host_threads(0, 1)
 

@@ -16,6 +16,14 @@ if "--reads" in sys.argv:
 k, model = load_model_f32("tests/golden/r9.4_450bps.6mer.f32")
 b = synth.make_batch(cfg["n_reads"], model, k, seed=cfg["seed"], law=cfg["law"], workers=32)
 d = abea.AbeaContext.upload(b)
+# host memory: the 100k-read batch is 60 GB of event tables + 30 GB of pair buffers; a first version also built two more
+# 21-GB copies of the pairs per build and took the box down.  After the upload only the index arrays are needed here, and the
+# pair lists are compared through the blocked per-read hash of tests/pairhash.py.
+pair_ptr = b["pair_ptr"].copy()
+for key in ("events", "reads"):
+    b[key] = None
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+from pairhash import hash_pair_lists
 ref = None
 for a in args:
     name, path = a.split("=", 1)
@@ -26,12 +34,8 @@ for a in args:
         ctx.align_db_device(d); ms.append(ctx.stats()["fill_ms"])
     pairs, n_pairs, dg = ctx.download(d)
     out = dict(n_pairs=n_pairs.copy(), sum_emission=dg["sum_emission"].copy(), max_score=dg["max_score"].copy())
-    pv = pairs.view(np.int32).reshape(-1, 2)
-    keep = np.zeros(len(pv), bool)                               # only the pairs of reads that passed QC are defined
-    for s, n in zip(b["pair_ptr"], n_pairs):
-        keep[s:s + n] = True
-    out["pairs_sha"] = hashlib.sha256(np.ascontiguousarray(pv[keep]).tobytes()).hexdigest()
-    del ctx
+    out["pairs_sha"] = hashlib.sha256(hash_pair_lists(pairs, pair_ptr, n_pairs).tobytes()).hexdigest()   # only defined pairs
+    del ctx, pairs
     line = f"{name} kernel ms " + " ".join(f"{x:.3f}" for x in ms) + f" | min {min(ms[1:]):.3f}"
     if ref is None:
         ref = out

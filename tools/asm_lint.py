@@ -303,8 +303,8 @@ def lint(lines, name, undef=()):
 
 # Findings that hold on a path the data flow cannot rule out but the values do, each with its reason.
 WAIVERS = {
-    ("abea_walk.inc", "U1", "s_cselect_b64 s[94:95], s[90:91], s[88:89]"):
-        "the first step always branches to reload_lp, which loads s[88:91]: s86 starts at -1 and a lane pair (0..49) never equals it",
+    ("abea_walk.inc", "U1", "s_lshr_b64 s[94:95], s[90:91], s96"):
+        "the first step of a group always branches to reload_lp_hi / _lo, which loads s[88:91]: s86 is set to -1 at group_top and a lane pair (0..49) never equals it",
 }
 
 

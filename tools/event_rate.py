@@ -13,10 +13,13 @@ sigs, sc = synth.make_signals(b, seed=1)
 seqs = [b["reads"][int(b["read_ptr"][i]):int(b["read_ptr"][i]) + int(b["read_len"][i])].tobytes() for i in range(n)]
 ns = sum(len(s) for s in sigs)
 ctx = abea.AbeaContext(model, k, mem_frac=0.6)
+RNA = os.environ.get("RNA", "0") == "1"      # the RNA parameter set (events.c:59-65) on the same signals: kernel times only
 for rep in range(2):
-    evs, ne, scal = ctx.detect_events_device(sigs, sc, seqs=seqs)
+    evs, ne, scal = ctx.detect_events_device(sigs, sc, seqs=seqs, rna=RNA)
     ms = ctx.stats()["event_ms"]
     print(f"device: {n} reads, {ns/1e6:.1f} Msamples, {int(ne.sum())/1e6:.2f} Mevents: kernel {ms:.2f} ms = {ns/ms/1e3:.1f} Msamples/s, {ne.sum()/ms/1e3:.1f} Mevents/s")
+if RNA:
+    sys.exit(0)
 # whole device chain: raw signal -> events + scalings -> ABEA -> scaling_single, event tables resident in HBM
 import torch
 for rep in range(2):

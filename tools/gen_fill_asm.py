@@ -22,42 +22,24 @@ Hazards honoured by construction (gfx940/950, no assembler help inside inline as
 """
 import os
 
-# Experimental layout switches (next-round A/B, never the shipped build): ABEA_VBASE moves the fixed VGPR window,
-# ABEA_TIED=1 binds the loop state to the C++ values with physical-register constraints instead of entry/exit copies.
-# Either one writes abea_fill_exp.inc / abea_walk_exp.inc (compiled under -DABEA_EXP) and leaves the shipped files alone.
-VB = int(os.environ.get("ABEA_VBASE", "64"))  # first fixed VGPR (v64..v121 in the shipped build)
-TIED = os.environ.get("ABEA_TIED", "0") == "1"
-# ABEA_PK=1: packed-f32 instructions of gfx90a+ where the two cells of a lane do the same f32 operation on operands that can
-# sit in one aligned VGPR pair (a*a, the two tie-break differences) and v_pk_mov_b32 for the event shift of a down move:
-# -4 VALU on a down-move band, -3 on a right-move band, same arithmetic (v_pk_add/mul_f32 round like v_add/mul_f32).
-PK = os.environ.get("ABEA_PK", "0") in ("1", "2")
-# ABEA_PK=2: the same instructions, but the ten that do not depend on the emission (doubles of the previous scores, the
-# constant adds, the rounded skip score) are issued BETWEEN the steps of the emission chain instead of after it; needs 6 more
-# fixed VGPRs (a, a*a / lp and the second skip sum get registers of their own).
-PKS = os.environ.get("ABEA_PK", "0") == "2"
-# ABEA_SCHED=1: the schedule of ABEA_PK=2 with plain instructions (no packed f32): the independent work between the steps of the
-# emission chain.  Nothing for four waves per SIMD (the other waves fill the gaps anyway); meant for a wave alone on its SIMD.
-SCHED = os.environ.get("ABEA_SCHED", "0") == "1"
-# ABEA_EARLY=1: the move decision of the next band (v_readlane of the lower-left score, v_cmp with the upper-right one) is
-# issued right after the two v_max3 instead of behind the trace packing: the scalar test and branch at the end of the band no
-# longer wait for the compare.  Same instructions, other order (interior loop, plain cell_ops path).
-EARLY = os.environ.get("ABEA_EARLY", "0") == "1"
-if SCHED:
-    PK = PKS = True
-# ABEA_FIFO=1: no LDS rings.  The idle lanes 52..63 hold the NEXT 24 events (in the event registers themselves: a down move
-# shifts them with wave_ror, so lane 63's cell 1 arrives in lane 0) and the next 24 k-mers (offsets 104..127, as before); every
-# 24th move of a kind overwrites those twelve lanes under an EXEC mask from registers that a global load filled 24 moves
-# earlier.  Per band this removes the ring read(s), the M0 set-up and the lgkmcnt wait: -3 instructions on a down move, -6 on a
-# right move; the refill trigger stays two scalar instructions (a countdown).
-FIFO = os.environ.get("ABEA_FIFO", "0") == "1"
-# ABEA_WALK2=1: the traceback walk with fewer scalar instructions per step (46.9 -> 42.6): the step loop exists twice, once for the
-# upper 16 bands of a trace group (from-codes in s[90:91]) and once for the lower 16 (s[88:89]), so the half is not selected
-# per step; the band-move word is kept shifted to the current band; the gap counter is reset with a multiply; the band
-# index of the lower-left corner is updated through a popcount.
-WALK2 = os.environ.get("ABEA_WALK2", "0") == "1"
-EXPERIMENT = VB != 64 or TIED or PK or FIFO or WALK2 or EARLY
-assert not (EARLY and PK), "ABEA_EARLY re-orders the plain cell_ops tail"
-assert not (FIFO and (PKS or TIED)), "ABEA_FIFO takes the registers of ABEA_PK=2 / is not wired to ABEA_TIED"
+# Round 4 settled the candidates of round 3 on the GPU (profiles/r04/candidates_ab.txt, >= 10 launches each on configs[1] and
+# [2], every output bit compared): the three that held outside the noise are now the design and their switches are gone —
+#   * no LDS rings: the idle lanes 52..63 hold the NEXT 24 events (in the event registers themselves: a down move shifts them
+#     with wave_ror, so lane 63's cell 1 arrives in lane 0) and the next 24 k-mers (offsets 104..127); every 24th move of a
+#     kind overwrites those twelve lanes under an EXEC mask from registers that a global load filled 24 moves earlier.  Per
+#     band no ring read, no M0 set-up, no lgkmcnt wait: -3 instructions on a down move, -6 on a right move; the refill
+#     trigger is a two-instruction countdown;
+#   * the move decision of the next band (v_readlane of the lower-left score, v_cmp with the upper-right one) is issued right
+#     after the two v_max3 instead of behind the trace packing: the scalar test and branch at the end of the band no longer
+#     wait for the compare;
+#   * the traceback walk's step loop exists twice, once for the upper 16 bands of a trace group (from-codes in s[90:91]) and
+#     once for the lower 16 (s[88:89]), so the half is not selected per step; the band-move word is kept shifted to the
+#     current band; the gap counter is reset with a multiply; the lower-left corner is updated through a popcount
+#     (46.9 -> 42.6 scalar instructions per step).
+# Measured and dropped (their generator paths are deleted; the records are in profiles/r03/experiments/ and DESIGN.md §4.3):
+# packed f32 (v_pk_mul/add/mov: fewer instructions, same time), the emission-chain interleave for a lone wave (-0.6 % on a
+# 512-read batch), the loop state tied to physical registers for 5-7 waves per SIMD, the LDS rings, the one-loop walk.
+VB = 64            # first fixed VGPR (v64..v127)
 assert VB % 2 == 0
 MF0, MF1, SHR, SHD = VB + 0, VB + 1, VB + 2, VB + 3
 TR = [dict(c0=VB + 4, c1=VB + 6, cs=VB + 8), dict(c0=VB + 10, c1=VB + 12, cs=VB + 14)]
@@ -71,8 +53,7 @@ G0, C0, I0 = KQ[0], KQ[0] + 1, KQ[0] + 2
 G1, C1, I1 = KQ[1], KQ[1] + 1, KQ[1] + 2
 NK = KQ[2]         # v[90:93] = incoming k-mer {gpm, ck, istd} at rs = 0
 NX = VB + 30
-EPEND = VB + 31
-KPEND = VB + 32    # v[96:99]
+KPEND = VB + 32    # v[96:99]: pending k-mer quad of the FIFO lanes' cell 0
 A0, A1, A2, ACC = VB + 36, VB + 37, VB + 38, VB + 39
 NINF = VB + 40
 LANE = VB + 41
@@ -84,17 +65,11 @@ TMP = VB + 54      # 32-bit address temp
 TOFF = VB + 55     # trace store offset (lane*16 + group*1024)
 F = [VB + 47, VB + 49]     # from codes: high halves of the TD pairs (free once sd is rounded)
 O0, O1 = VB + 56, VB + 57   # band offsets owned by the lane (border variant only)
-VEND = VB + 58     # one past the last fixed VGPR
-if PKS:
-    PA, PSQ, SK = VB + 58, VB + 60, [VB + 56, VB + 62]      # SK[0] takes the border variant's offset pair (unused in the interior loop)
-    VEND = VB + 64
-if FIFO:
-    PX = VB + 58           # v[122:123]: pending events of the FIFO lanes (-> X1, X0)
-    PKA, PKB = KPEND, VB + 60   # v[96:99], v[124:127]: pending k-mer quads of the FIFO lanes' cell 0 / cell 1
-    VEND = VB + 64
+PX = VB + 58           # v[122:123]: pending events of the FIFO lanes (-> X1, X0)
+PKA, PKB = KPEND, VB + 60   # v[96:99], v[124:127]: pending k-mer quads of the FIFO lanes' cell 0 / cell 1
+VEND = VB + 64
 FIFO_EXEC_HI = "0xFFF00000"   # lanes 52..63
 DPP_ROR = "wave_ror:1 row_mask:0xf bank_mask:0xf"
-TIED_HOME = {"L0": TR[1]['c0'], "L1": TR[1]['c1'], "U1": TR[1]['cs'], "U0": TR[0]['c0']}   # exit homes of the row doubles
 BORDER = False     # generator mode: True adds validity masks + the online end-point scan
 # extra per-cell 32-bit temps reuse the low halves of f64 temps where noted
 
@@ -196,83 +171,6 @@ def cell_ops(j, D, U, L, quad):
     return ops
 
 
-def cells_pks(D, U, L, quads, pre):
-    """cells_pk with the emission chain and the independent work interleaved (ABEA_PK=2); pre = the converts of the previous
-    band's scores that body() would have issued first."""
-    g = [quads[0], quads[1]]; ck = [quads[0] + 1, quads[1] + 1]; ii = [quads[0] + 2, quads[1] + 2]
-    A = [f"v_sub_f32 {v(PA + j)}, {v(X0 + j)}, {v(g[j])}" for j in (0, 1)]
-    A += [f"v_cvt_f64_f32 {vp(LPD[j])}, {v(PA + j)}" for j in (0, 1)]
-    A += [f"v_mul_f64 {vp(LPD[j])}, {vp(LPD[j])}, {vp(ii[j])}" for j in (0, 1)]
-    A += [f"v_cvt_f32_f64 {v(PA + j)}, {vp(LPD[j])}" for j in (0, 1)]
-    if SCHED:
-        A += [f"v_mul_f32 {v(PSQ + j)}, {v(PA + j)}, {v(PA + j)}" for j in (0, 1)]
-    else:
-        A += [f"v_pk_mul_f32 {vp(PSQ)}, {vp(PA)}, {vp(PA)}"]
-    A += [f"v_fma_f32 {v(PSQ + j)}, -0.5, {v(PSQ + j)}, {v(ck[j])}" for j in (0, 1)]
-    A += [f"v_cvt_f64_f32 {vp(LPD[j])}, {v(PSQ + j)}" for j in (0, 1)]
-    B = list(pre)
-    B += [f"v_add_f64 {vp(TD[j])}, {vp(D[j])}, %[lp_step]" for j in (0, 1)]
-    B += [f"v_add_f64 {vp(TU[j])}, {vp(U[j])}, %[lp_stay]" for j in (0, 1)]
-    B += [f"v_add_f64 {vp(SK[j])}, {vp(L[j])}, %[lp_skip]" for j in (0, 1)]
-    B += [f"v_cvt_f32_f64 {v(SK[0])}, {vp(SK[0])}", f"v_cvt_f32_f64 {v(SK[0] + 1)}, {vp(SK[1])}"]     # sl pair = v[SK0]
-    ops = interleave(A, B)
-    ops += [f"v_add_f64 {vp(TD[j])}, {vp(TD[j])}, {vp(LPD[j])}" for j in (0, 1)]
-    ops += [f"v_add_f64 {vp(TU[j])}, {vp(TU[j])}, {vp(LPD[j])}" for j in (0, 1)]
-    for base, src in ((TD[0], TD), (TU[0], TU)):
-        for j in (0, 1):
-            ops.append(f"v_cvt_f32_f64 {v(base + j)}, {vp(src[j])}")
-    for j in (0, 1):
-        ops.append(f"v_max3_f32 {v(MF0 + j)}, {v(TD[0] + j)}, {v(TU[0] + j)}, {v(SK[0] + j)}")
-    if SCHED:
-        ops += [f"v_sub_f32 {v(TD[1] + j)}, {v(TU[0] + j)}, {v(TD[0] + j)}" for j in (0, 1)]
-        ops += [f"v_sub_f32 {v(TU[1] + j)}, {v(SK[0] + j)}, {v(MF0 + j)}" for j in (0, 1)]
-        return ops
-    ops.append(f"v_pk_add_f32 {vp(TD[1])}, {vp(TU[0])}, {vp(TD[0])} neg_lo:[0,1] neg_hi:[0,1]")     # su - sd
-    ops.append(f"v_pk_add_f32 {vp(TU[1])}, {vp(SK[0])}, {vp(MF0)} neg_lo:[0,1] neg_hi:[0,1]")       # sl - max
-    return ops
-
-
-def cells_pk(D, U, L, quads):
-    """Interior band, both cells of the lane, with packed f32 where the operands pair up (ABEA_PK=1).  Pairs: a = v[TD0],
-    a*a / lp = v[TU0], then sd = v[TD0] (lo = cell 0, hi = cell 1), su = v[TU0], sl = v[LPD0]; the differences land in
-    v[TD1] = su - sd and v[TU1] = sl - mf."""
-    g = [quads[0], quads[1]]; ck = [quads[0] + 1, quads[1] + 1]; ii = [quads[0] + 2, quads[1] + 2]
-    A = TD[0]; SQ = TU[0]
-    ops = []
-    for j in (0, 1):
-        ops.append(f"v_sub_f32 {v(A + j)}, {v(X0 + j)}, {v(g[j])}")
-    for j in (0, 1):
-        ops.append(f"v_cvt_f64_f32 {vp(LPD[j])}, {v(A + j)}")
-    for j in (0, 1):
-        ops.append(f"v_mul_f64 {vp(LPD[j])}, {vp(LPD[j])}, {vp(ii[j])}")
-    for j in (0, 1):
-        ops.append(f"v_cvt_f32_f64 {v(A + j)}, {vp(LPD[j])}")
-    ops.append(f"v_pk_mul_f32 {vp(SQ)}, {vp(A)}, {vp(A)}")
-    for j in (0, 1):
-        ops.append(f"v_fma_f32 {v(SQ + j)}, -0.5, {v(SQ + j)}, {v(ck[j])}")
-    for j in (0, 1):
-        ops.append(f"v_cvt_f64_f32 {vp(LPD[j])}, {v(SQ + j)}")
-    for j in (0, 1):
-        ops.append(f"v_add_f64 {vp(TD[j])}, {vp(D[j])}, %[lp_step]")
-    for j in (0, 1):
-        ops.append(f"v_add_f64 {vp(TU[j])}, {vp(U[j])}, %[lp_stay]")
-    for j in (0, 1):
-        ops.append(f"v_add_f64 {vp(TD[j])}, {vp(TD[j])}, {vp(LPD[j])}")
-    for j in (0, 1):
-        ops.append(f"v_add_f64 {vp(TU[j])}, {vp(TU[j])}, {vp(LPD[j])}")
-    for j in (0, 1):
-        ops.append(f"v_add_f64 {vp(LPD[j])}, {vp(L[j])}, %[lp_skip]")
-    # rounded scores into pairs: cell 0's convert frees the high dword that cell 1's convert then takes
-    for base, src in ((TD[0], TD), (TU[0], TU), (LPD[0], LPD)):
-        for j in (0, 1):
-            ops.append(f"v_cvt_f32_f64 {v(base + j)}, {vp(src[j])}")
-    for j in (0, 1):
-        ops.append(f"v_max3_f32 {v(MF0 + j)}, {v(TD[0] + j)}, {v(TU[0] + j)}, {v(LPD[0] + j)}")
-    ops.append(f"v_pk_add_f32 {vp(TD[1])}, {vp(TU[0])}, {vp(TD[0])} neg_lo:[0,1] neg_hi:[0,1]")     # su - sd
-    ops.append(f"v_pk_add_f32 {vp(TU[1])}, {vp(LPD[0])}, {vp(MF0)} neg_lo:[0,1] neg_hi:[0,1]")      # sl - max
-    return ops
-
-
 def interleave(a, b):
     """Alternate two independent instruction streams (fills dependent-issue and hazard slots)."""
     res = []
@@ -336,37 +234,20 @@ def body(p, ml, m, rs):
     if m == 'R':
         c0q, inq = KQ[rs], KQ[(rs + 2) % 3]
         rs = (rs + 1) % 3                                    # roles after the move: cell 0 = old cell 1, cell 1 = old incoming
-        if FIFO:                                            # before ll_k moves: the refill wants the frame of the previous band
-            emit("s_sub_u32 %[k_cnt], %[k_cnt], 1")
-            emit(f"s_cbranch_scc1 krefill_{tag}_%=")
-            emit(f"kcont_{tag}_%=:")
+        emit("s_sub_u32 %[k_cnt], %[k_cnt], 1")             # before ll_k moves: the refill wants the frame of the previous band
+        emit(f"s_cbranch_scc1 krefill_{tag}_%=")
+        emit(f"kcont_{tag}_%=:")
         emit("s_add_u32 %[ll_k], %[ll_k], 1")
         emit(f"v_mov_b32_dpp {v(SHR)}, {v(MF0)} {DPP_SHL}")
         # lanes >= 50 are the k-mer FIFO and their "scores" are garbage; the only one a band cell ever reads is lane 50's
         # slot 0 = offset 100, through this shift into lane 49: pin THAT to -inf (the band ends at offset 99).  Round 2
         # masked slot 0 of every band with a v_cndmask; a down move never looks at it.
         emit(f"v_writelane_b32 {v(SHR)}, %[ninf], 49")
-        if not FIFO:
-            emit("s_waitcnt lgkmcnt(1)" if ml == 'D' else "s_waitcnt lgkmcnt(0)")     # incoming k-mer landed
-        # every offset takes the k-mer of the offset above: cell 0's quad slides down one lane INTO the incoming quad,
-        # whose lane 63 keeps the pre-read incoming k-mer (DPP `old`); cell 1's quad becomes cell 0's by renaming
+        # every offset takes the k-mer of the offset above: cell 0's quad slides down one lane INTO the incoming quad (its
+        # lane 63 keeps what it has: nothing reads offsets beyond the FIFO lanes); cell 1's quad becomes cell 0's by renaming
         for j in range(4):
             emit(f"v_mov_b32_dpp {v(inq + j)}, {v(c0q + j)} {DPP_SHL}")
-        # k_addr = LDS address of the next incoming k-mer (bits 15:0) | its position in the 64-entry chunk (bits 31:26):
-        # the add carries out exactly when a new chunk is entered, and the ring wrap is done there too — two scalar
-        # instructions per move instead of four (every instruction of the loop costs one issue slot, SALU included)
-        if not FIFO:
-            emit("s_add_u32 %[k_addr], %[k_addr], 0x04000010")
-            emit(f"s_cbranch_scc1 krefill_{tag}_%=")
-            emit(f"kcont_{tag}_%=:")
-            # the next incoming k-mer lands in the old cell-0 quad (dead now); only LANE 63 of it matters (the DPP `old` lane of
-            # the next right move), so it is read with ds_read_addtid_b32 (LDS address = M0 + offset + 4*lane, no address VGPR,
-            # no VALU): M0 = k_addr - 252
-            emit("s_sub_u32 m0, %[k_addr], 252")
         emit(f"v_cvt_f64_f32 {vp(T['c0'])}, {v(MF0)}")
-        if not FIFO:
-            for j in range(4):
-                emit(f"ds_read_addtid_b32 {v(KQ[(rs + 2) % 3] + j)} offset:{4 * j}")
         sh = SHR
         U = (T['c1'], T['cs']); L = (T['c0'], T['c1'])
         D = (Tp['c1'], Tp['cs']) if ml == 'R' else (Tp['c0'], Tp['c1'])
@@ -374,36 +255,19 @@ def body(p, ml, m, rs):
         if BORDER:                                          # the border masks need ll_e every band; the interior loop brings
             emit("s_add_u32 %[ll_e], %[ll_e], 1")           # it up to date at the tick (popcount of the recorded moves)
         emit(f"v_mov_b32_dpp {v(SHD)}, {v(MF1)} {DPP_SHR}")
-        if FIFO:
-            emit("s_sub_u32 %[e_cnt], %[e_cnt], 1")
-            emit(f"s_cbranch_scc1 erefill_{tag}_%=")
-            emit(f"econt_{tag}_%=:")
-            emit(f"v_mov_b32_dpp {v(NX)}, {v(X1)} {DPP_ROR}")     # lane 0 <- lane 63's cell 1: the next event
-        else:
-            emit("s_waitcnt lgkmcnt(4)" if ml == 'R' else "s_waitcnt lgkmcnt(0)")     # incoming event landed (a right move's four k-mer reads may still be out)
-            emit(f"v_mov_b32_dpp {v(NX)}, {v(X1)} {DPP_SHR}")
-        if PK and not SCHED and not BORDER:
-            # lo result = src0's dword picked by op_sel[0], hi result = src1's dword picked by op_sel_hi[1]: X0 = NX, X1 = old X0
-            emit(f"v_pk_mov_b32 {vp(X0)}, {vp(NX)}, {vp(X0)} op_sel:[0,0] op_sel_hi:[0,0]")
-        else:
-            emit(f"v_mov_b32 {v(X1)}, {v(X0)}")
-            emit(f"v_mov_b32 {v(X0)}, {v(NX)}")
-        if not FIFO:
-            emit("s_add_u32 %[e_addr], %[e_addr], 0x04000004")  # LDS address of the next incoming event | position in chunk << 26
-            emit(f"s_cbranch_scc1 erefill_{tag}_%=")
-            emit(f"econt_{tag}_%=:")
-            emit("s_mov_b32 m0, %[e_addr]")                     # lane 0 (the DPP `old` lane of the next down move) reads ring[e_addr]
+        emit("s_sub_u32 %[e_cnt], %[e_cnt], 1")
+        emit(f"s_cbranch_scc1 erefill_{tag}_%=")
+        emit(f"econt_{tag}_%=:")
+        emit(f"v_mov_b32_dpp {v(NX)}, {v(X1)} {DPP_ROR}")         # lane 0 <- lane 63's cell 1: the next event
+        emit(f"v_mov_b32 {v(X1)}, {v(X0)}")
+        emit(f"v_mov_b32 {v(X0)}, {v(NX)}")
         emit(f"v_cvt_f64_f32 {vp(T['c0'])}, {v(MF0)}")
-        if not FIFO:
-            emit(f"ds_read_addtid_b32 {v(NX)}")
         sh = SHD
         U = (T['c0'], T['c1']); L = (T['cs'], T['c0'])
         D = (Tp['c0'], Tp['c1']) if ml == 'R' else (Tp['cs'], Tp['c0'])
     # exact doubles of the previous band's scores (c0 issued above)
-    pre = [f"v_cvt_f64_f32 {vp(T['c1'])}, {v(MF1)}", f"v_cvt_f64_f32 {vp(T['cs'])}, {v(sh)}"]
-    if not (PKS and not BORDER):
-        for ins in pre:
-            emit(ins)
+    emit(f"v_cvt_f64_f32 {vp(T['c1'])}, {v(MF1)}")
+    emit(f"v_cvt_f64_f32 {vp(T['cs'])}, {v(sh)}")
     if BORDER:
         # in-matrix offsets [min_off, max_off) (align.c:337-346)
         emit("s_sub_u32 %[t2], %[ll_e], %[Em1]")
@@ -421,17 +285,14 @@ def body(p, ml, m, rs):
         emit(f"v_subrev_u32 {v(F[1])}, %[t2], {v(O1)}")
         emit(f"v_cmp_gt_u32 %[cv0], %[t3], {v(F[0])}")
         emit(f"v_cmp_gt_u32 %[cv1], %[t3], {v(F[1])}")
-    if PK and not BORDER:
-        qs = (KQ[rs], KQ[(rs + 1) % 3])
-        ops0 = cells_pks(D, U, L, qs, pre) if PKS else cells_pk(D, U, L, qs); ops1 = []
-    else:
-        ops0 = cell_ops(0, D[0], U[0], L[0], KQ[rs]); ops1 = cell_ops(1, D[1], U[1], L[1], KQ[(rs + 1) % 3])
+    ops0 = cell_ops(0, D[0], U[0], L[0], KQ[rs]); ops1 = cell_ops(1, D[1], U[1], L[1], KQ[(rs + 1) % 3])
     if BORDER:
         # split off the two trailing from-code selects of each cell (and the s_nop before them)
         tail0, tail1 = ops0[-2:], ops1[-2:]
         for ins in interleave(ops0[:-3], ops1[:-3]):
             emit(ins)
-    elif EARLY:
+    else:
+        # the next band's move decision rides in the tail of the cells: issued as soon as the two new scores exist
         il = interleave(ops0, ops1)
         for ins in il[:-4]:                                  # ... v_max3 cell 0, v_max3 cell 1
             emit(ins)
@@ -439,9 +300,6 @@ def body(p, ml, m, rs):
         emit(il[-4]); emit(il[-3])                          # the two [su < sd] differences
         emit(f"v_cmp_lt_f32 vcc, %[t0], {v(MF1)}")          # t0 written three instructions ago
         emit(il[-2]); emit(il[-1])                          # the two [sl < max] differences
-    else:
-        for ins in interleave(ops0, ops1):
-            emit(ins)
     if BORDER:
         emit("s_nop 0")
         emit(tail0[0]); emit(tail1[0]); emit(tail0[1]); emit(tail1[1])
@@ -506,15 +364,11 @@ def body(p, ml, m, rs):
         # trace bits, oldest first: cell 1 [sl<max], cell 1 [su<sd], cell 0 [sl<max], cell 0 [su<sd]; each v_alignbit
         # is acc = acc << 1 | sign(difference).  Complemented per dword they read f = 2*[sl==max] + [su>=sd]:
         # 0 FROM_D, 1 FROM_U, 2 or 3 FROM_L (align.c:386-392 priority).
-        b_l1, b_u1, b_l0, b_u0 = (TU[1] + 1, TD[1] + 1, TU[1], TD[1]) if PK else (TD[1], F[1], TD[0], F[0])
+        b_l1, b_u1, b_l0, b_u0 = TD[1], F[1], TD[0], F[0]
         emit(f"v_alignbit_b32 {v(ACC)}, {v(ACC)}, {v(b_l1)}, 31")
         emit(f"v_alignbit_b32 {v(ACC)}, {v(ACC)}, {v(b_u1)}, 31")
-        if not EARLY:
-            emit(f"v_readlane_b32 %[t0], {v(MF0)}, 0")      # mf0 was written 3 instructions ago
         emit(f"v_alignbit_b32 {v(ACC)}, {v(ACC)}, {v(b_l0)}, 31")
         emit(f"v_alignbit_b32 {v(ACC)}, {v(ACC)}, {v(b_u0)}, 31")
-        if not EARLY:
-            emit(f"v_cmp_lt_f32 vcc, %[t0], {v(MF1)}")      # t0 written 3 instructions ago
     # %[cnt] counts the bands to the next "tick" (a trace dword completes every 8th band; the run ends at b_end): the
     # band index itself is only brought up to date there
     emit(f"s_lshl1_add_u32 %[cnt], %[cnt], {1 if m == 'R' else 0}")
@@ -557,8 +411,8 @@ def body(p, ml, m, rs):
     emit(f"s_cbranch_scc1 exit_{p ^ 1}{m}{rs}_%=")
     countdown()
     emit(f"s_branch rotret_{tag}_%=")
-    # ---- out-of-line: ring refills
-    if FIFO and m == 'R':
+    # ---- out-of-line: the FIFO lanes are topped up
+    if m == 'R':
         c0q_in, c1q_in = KQ[(rs + 2) % 3], KQ[rs]             # rs is already the state AFTER the move: cell 0 / cell 1 quads before it
         emit(f"krefill_{tag}_%=:")                       # 24 right moves since the last one: lanes 52..63 hold nothing useful
         emit("s_waitcnt vmcnt(0)")
@@ -580,7 +434,7 @@ def body(p, ml, m, rs):
         emit("s_mov_b32 %[k_cnt], 23")
         emit("s_nop 1")
         emit(f"s_branch kcont_{tag}_%=")
-    elif FIFO:
+    else:
         emit(f"erefill_{tag}_%=:")                       # 24 down moves since the last one
         emit("s_waitcnt vmcnt(0)")
         if BORDER:
@@ -610,73 +464,12 @@ def body(p, ml, m, rs):
         emit("s_mov_b32 %[e_cnt], 23")
         emit("s_nop 1")
         emit(f"s_branch econt_{tag}_%=")
-    elif m == 'R':
-        emit(f"krefill_{tag}_%=:")                       # entering chunk c = k_next >> 6: land chunk c+1, fetch c+2
-        emit("s_waitcnt vmcnt(0)")
-        emit("s_add_u32 %[t0], %[ll_k], 128")               # k_next = ll_k + 128 (k-mer entering at offset 127)
-        emit("s_lshr_b32 %[t0], %[t0], 6")
-        emit("s_and_b32 %[t1], %[t0], 1")                   # the chunk being entered: its half of the ring (this is the wrap)
-        emit("s_lshl_b32 %[t1], %[t1], 10")
-        emit("s_add_u32 %[k_addr], %[t1], %[kring]")
-        emit("s_add_u32 %[t1], %[t0], 1")
-        emit("s_and_b32 %[t1], %[t1], 1")
-        emit("s_lshl_b32 %[t1], %[t1], 10")
-        emit("s_add_u32 %[t1], %[t1], %[kring]")
-        emit(f"v_lshl_add_u32 {v(TMP)}, {v(LANE)}, 4, %[t1]")
-        emit("s_nop 1")
-        emit(f"ds_write_b128 {v(TMP)}, {vq(KPEND)}")
-        emit("s_add_u32 %[t0], %[t0], 2")
-        emit("s_lshl_b32 %[t0], %[t0], 6")
-        emit(f"v_add_u32 {v(TMP)}, %[t0], {v(LANE)}")
-        emit(f"v_min_i32 {v(TMP)}, %[Km1], {v(TMP)}")
-        emit(f"v_lshlrev_b32 {v(TMP)}, 4, {v(TMP)}")
-        emit("s_waitcnt lgkmcnt(0)")
-        emit("s_nop 1")
-        emit(f"global_load_dwordx4 {vq(KPEND)}, {v(TMP)}, %[kpar]")
-        emit(f"s_branch kcont_{tag}_%=")
-    else:
-        emit(f"erefill_{tag}_%=:")
-        emit("s_waitcnt vmcnt(0)")
-        if BORDER:
-            emit("s_add_u32 %[t0], %[ll_e], 1")             # e_next = ll_e + 1 (event entering at offset 0)
-        else:
-            # ll_e is as of the last tick: add the down moves since, this band included.  cnt = sentinel at bit
-            # (32 - per + done) over `done` recorded moves: done = per - 1 - leading zeros, rights = popcount - 1
-            emit("s_flbit_i32_b32 %[t0], %[cnt]")
-            emit("s_sub_u32 %[t0], %[per], %[t0]")          # done + 1
-            emit("s_bcnt1_i32_b32 %[t1], %[cnt]")           # rights + 1
-            emit("s_sub_u32 %[t0], %[t0], %[t1]")           # downs before this band
-            emit("s_add_u32 %[t0], %[t0], %[ll_e]")
-            emit("s_add_u32 %[t0], %[t0], 2")               # + this band's down move, + 1 for e_next
-        emit("s_lshr_b32 %[t0], %[t0], 6")
-        emit("s_and_b32 %[t1], %[t0], 1")
-        emit("s_lshl_b32 %[t1], %[t1], 8")
-        emit("s_add_u32 %[e_addr], %[t1], %[ering]")
-        emit("s_add_u32 %[t1], %[t0], 1")
-        emit("s_and_b32 %[t1], %[t1], 1")
-        emit("s_lshl_b32 %[t1], %[t1], 8")
-        emit("s_add_u32 %[t1], %[t1], %[ering]")
-        emit(f"v_lshl_add_u32 {v(TMP)}, {v(LANE)}, 2, %[t1]")
-        emit("s_nop 1")
-        emit(f"ds_write_b32 {v(TMP)}, {v(EPEND)}")
-        emit("s_add_u32 %[t0], %[t0], 2")
-        emit("s_lshl_b32 %[t0], %[t0], 6")
-        emit(f"v_add_u32 {v(TMP)}, %[t0], {v(LANE)}")
-        emit(f"v_min_i32 {v(TMP)}, %[Em1], {v(TMP)}")
-        emit(f"v_lshlrev_b32 {v(TMP)}, 2, {v(TMP)}")
-        emit("s_waitcnt lgkmcnt(0)")
-        emit("s_nop 1")
-        emit(f"global_load_dword {v(EPEND)}, {v(TMP)}, %[evm]")
-        emit(f"s_branch econt_{tag}_%=")
 
 
 def exit_stub(p, ml, rs):
     tag = f"{p}{ml}{rs}"
     Tl = TR[p ^ 1]
     emit(f"exit_{tag}_%=:")
-    # the incoming k-mer quad (four ds_read_addtid of the last right move) and the pending event may formally still be in
-    # flight: a down move's lgkmcnt(4) leaves the quad's reads outstanding on purpose.  They must have landed before the
-    # quads are shuffled back to the entry layout (found by tools/asm_lint.py; in practice they land ~200 cycles earlier)
     emit("s_waitcnt lgkmcnt(0)")
     if rs:
         # back to the entry layout: cell 0 -> KQ[0], cell 1 -> KQ[1], incoming -> KQ[2], through the per-cell temps
@@ -691,16 +484,8 @@ def exit_stub(p, ml, rs):
         mv = [("L0", Tl['c0']), ("L1", Tl['c1']), ("U0", Tl['c1']), ("U1", Tl['cs'])]
     else:
         mv = [("U0", Tl['c0']), ("U1", Tl['c1']), ("L0", Tl['cs']), ("L1", Tl['c0'])]
-    if TIED:
-        # the operands live in fixed pairs (TIED_HOME); sources and homes overlap, so go through four free temp pairs
-        tmp = [LPD[0], LPD[1], TD[0], TD[1]]
-        for t, (name, reg) in zip(tmp, mv):
-            emit(f"v_mov_b64 {vp(t)}, {vp(reg)}")
-        for t, (name, reg) in zip(tmp, mv):
-            emit(f"v_mov_b64 {vp(TIED_HOME[name])}, {vp(t)}")
-    else:
-        for name, reg in mv:
-            emit(f"v_mov_b64 %[{name}], {vp(reg)}")
+    for name, reg in mv:
+        emit(f"v_mov_b64 %[{name}], {vp(reg)}")
     emit("s_branch done_%=")
 
 
@@ -730,63 +515,43 @@ def variant_code(border):
 
 def main():
     # ---- entry: operands -> fixed registers (common to both variants)
+    # the incoming quad and NX are dead between bands; the pending refill registers of the FIFO lanes travel with the state
     ent = [
         (MF0, "Pf0"), (MF1, "Pf1"), (X0, "x0"), (X1, "x1"), (G0, "g0"), (C0, "c0"), (G1, "g1"), (C1, "c1"),
-        (NK, "nkg"), (NK + 1, "nkc"), (NX, "nx"), (EPEND, "e_pend"), (KPEND, "kpg"), (KPEND + 1, "kpc"),
         (A0, "a1"), (A1, "a2"), (A2, "a3"), (ACC, "acc"), (TOFF, "toff"), (LANE, "lane"),
+        (PX, "px1"), (PX + 1, "px0"), (PKA, "kag"), (PKA + 1, "kac"), (PKB, "kbg"), (PKB + 1, "kbc"),
     ]
-    wide = [(I0, "i0"), (I1, "i1"), (NK + 2, "nki"), (KPEND + 2, "kpi")]
-    if FIFO:       # the incoming quad and NX are dead between bands; the pending refill registers travel instead
-        ent = [e for e in ent if e[1] not in ("nkg", "nkc", "nx", "e_pend", "kpg", "kpc")]
-        ent += [(PX, "px1"), (PX + 1, "px0"), (PKA, "kag"), (PKA + 1, "kac"), (PKB, "kbg"), (PKB + 1, "kbc")]
-        wide = [(I0, "i0"), (I1, "i1"), (PKA + 2, "kai"), (PKB + 2, "kbi")]
+    wide = [(I0, "i0"), (I1, "i1"), (PKA + 2, "kai"), (PKB + 2, "kbi")]
     head = []
-    if not TIED:
-        for reg, name in ent:
-            head.append(f"v_mov_b32 {v(reg)}, %[{name}]")
-        for reg, name in wide + [(TR[1]['c0'], "L0"), (TR[1]['c1'], "L1"), (TR[1]['cs'], "U1")]:
-            head.append(f"v_mov_b64 {vp(reg)}, %[{name}]")
-    if FIFO:       # the incoming quad's lane 63 keeps what it has on every right move: give it a defined value once
-        head += [f"v_mov_b64 {vp(NK)}, 0", f"v_mov_b64 {vp(NK + 2)}, 0"]
+    for reg, name in ent:
+        head.append(f"v_mov_b32 {v(reg)}, %[{name}]")
+    for reg, name in wide + [(TR[1]['c0'], "L0"), (TR[1]['c1'], "L1"), (TR[1]['cs'], "U1")]:
+        head.append(f"v_mov_b64 {vp(reg)}, %[{name}]")
+    # the incoming quad's lane 63 keeps what it has on every right move: give it a defined value once
+    head += [f"v_mov_b64 {vp(NK)}, 0", f"v_mov_b64 {vp(NK + 2)}, 0"]
     head += [f"v_mov_b32 {v(NINF)}, 0xff800000", f"v_mov_b32 {v(SHR)}, 0xff800000", f"v_mov_b32 {v(SHD)}, 0xff800000",
              f"v_lshlrev_b32 {v(O0)}, 1, {v(LANE)}", f"v_lshl_or_b32 {v(O1)}, {v(LANE)}, 1, 1",
              "s_cmp_eq_u32 %[mode], 0", "s_cbranch_scc0 border_start_%="]
     interior = variant_code(False)
     border = ["border_start_%=:"] + variant_code(True)
     tail = ["done_%=:", "s_waitcnt vmcnt(0) lgkmcnt(0)"]
-    if not TIED:
-        for reg, name in ent:
-            if name in ("lane",):
-                continue
-            tail.append(f"v_mov_b32 %[{name}], {v(reg)}")
-        for reg, name in wide:
-            tail.append(f"v_mov_b64 %[{name}], {vp(reg)}")
+    for reg, name in ent:
+        if name in ("lane",):
+            continue
+        tail.append(f"v_mov_b32 %[{name}], {v(reg)}")
+    for reg, name in wide:
+        tail.append(f"v_mov_b64 %[{name}], {vp(reg)}")
     tail.append("s_nop 1")
     lines = head + interior + border + tail
     text = "\n".join(f'    "{ln}\\n\\t"' for ln in lines)
-    tied_regs = set()
-    extra = ""
-    if TIED:
-        vouts, vins = [], []
-        for reg, name in ent:
-            if name == "lane":
-                vins.append(f'[lane] "{{v{reg}}}"(lane)')
-            else:
-                vouts.append(f'[{name}] "+{{v{reg}}}"({name})')
-            tied_regs.add(reg)
-        for reg, name in wide + [(TIED_HOME[n], n) for n in ("L0", "L1", "U0", "U1")]:
-            vouts.append(f'[{name}] "+{{v[{reg}:{reg+1}]}}"({name})')
-            tied_regs.update((reg, reg + 1))
-        extra = ("#define ABEA_FILL_TIED_VOUTS " + ", ".join(vouts) + "\n" +
-                 "#define ABEA_FILL_TIED_VINS " + ", ".join(vins) + "\n")
-    clob = ", ".join(f'"v{i}"' for i in range(VB, VEND) if i not in tied_regs)
+    clob = ", ".join(f'"v{i}"' for i in range(VB, VEND))
     inc = f"""/* GENERATED by tools/gen_fill_asm.py — do not edit. See that file for the register map and hazards.
  * One statement, two variants selected by %[mode]: 0 = interior (no masks), 1 = border (masks + end-point scan). */
 #define ABEA_FILL_ASM \\
 {text.replace(chr(10), " " + chr(92) + chr(10))}
 #define ABEA_FILL_CLOBBERS {clob}, "vcc", "scc", "memory"
-{extra}"""
-    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "f5c_amd", "csrc", "abea_fill_exp.inc" if EXPERIMENT else "abea_fill.inc")
+"""
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "f5c_amd", "csrc", "abea_fill.inc")
     _emit_file(path, inc, len(lines))
 
 
@@ -798,7 +563,7 @@ if __name__ == "__main__":
 # Traceback walk (align.c:452-499) on the scalar unit: one inline-asm statement, ~40 SALU per step.
 # Fixed SGPRs s72..s99, VGPRs v64..v75 (the fill statement's range; the two statements never overlap).
 # =====================================================================================================
-WALK_RADIUS = int(os.environ.get("ABEA_WALK_RADIUS", "12"))     # lane pairs either side of the path that a prefetch covers
+WALK_RADIUS = 12     # lane pairs either side of the path that a prefetch covers (measured at 4 / 8 / 12: DESIGN.md §4.3)
 
 
 def gen_walk():
@@ -847,94 +612,12 @@ def gen_walk():
     e(f"v_readlane_b32 s92, {CW[0]}, 50")                                  # band moves of this group ...
     e(f"v_readlane_b32 s93, {CW[1]}, 50")                                  # ... and of the group below
     e(f"s_mov_b32 {LP}, -1")
-    if WALK2:
-        _walk2_loops(e, locals())
-        _finish_walk(o)
-        return
-    e("step_%=:")
-    e(f"s_sub_u32 {T}, {K}, {LLK}")                                         # band offset of (e,k)
-    e(f"s_lshr_b32 {U}, {T}, 1")
-    e(f"s_cmp_eq_u32 {U}, {LP}")
-    e("s_cbranch_scc0 reload_lp_%=")
-    e("step_cont_%=:")
-    e(f"s_and_b32 {T}, {T}, 1"); e(f"s_lshl_b32 {T}, {T}, 1")
-    e(f"s_xor_b32 {X}, {BI}, 7")                                          # newest band in the LOW nibble of its dword
-    e(f"s_lshl2_add_u32 {T}, {X}, {T}")                                   # bit position
-    e(f"s_bitcmp1_b32 {T}, 6")
-    e(f"s_cselect_b64 {T64}, {THI}, {TLO}")
-    e(f"s_lshr_b64 {T64}, {T64}, {T}")
-    e(f"s_and_b32 {U}, {T64LO}, 3")
-    e(f"s_min_u32 {U}, {U}, 2")                                            # from code: 0 D, 1 U, 2 L (3 = L and U tie)
-    e(f"s_sub_u32 {T}, 31, {BI}")
-    e(f"s_lshr_b64 {T64}, {MV}, {T}")
-    e(f"s_and_b32 {T}, {T64LO}, 3")                                        # bit0 = move(b), bit1 = move(b-1)
-    e(f"s_lshl_b32 {X}, {U}, {SH2}"); e(f"s_or_b32 {CWD}, {CWD}, {X}"); e(f"s_add_u32 {SH2}, {SH2}, 2")
-    e(f"s_bitcmp1_b32 {SH2}, 5")
-    e("s_cbranch_scc1 flush_%=")
-    e("flush_ret_%=:")
-    e(f"s_and_b32 {DK}, {U}, 1"); e(f"s_xor_b32 {DK}, {DK}, 1")            # D,L step the k-mer
-    e(f"s_lshr_b32 {X}, {U}, 1")                                           # isL
-    e(f"s_xor_b32 {Y}, {X}, 1")                                            # de: D,U step the event
-    e(f"s_add_u32 {GAP}, {GAP}, 1"); e(f"s_cmp_eq_u32 {X}, 0"); e(f"s_cselect_b32 {GAP}, 0, {GAP}")
-    e(f"s_max_i32 {MAXGAP}, {MAXGAP}, {GAP}")
-    e(f"s_and_b32 {U}, {DK}, {Y}")                                         # isD
-    e(f"s_lshr_b32 {X}, {T}, 1"); e(f"s_and_b32 {X}, {X}, {U}")            # move(b-1) counts only on a diagonal step
-    e(f"s_and_b32 {T}, {T}, 1"); e(f"s_add_u32 {T}, {T}, {X}")
-    e(f"s_sub_u32 {LLK}, {LLK}, {T}")
-    e(f"s_sub_u32 {K}, {K}, {DK}"); e("s_cbranch_scc1 done_%=")            # borrow: ran off k-mer 0
-    e(f"s_sub_u32 {E}, {E}, {Y}"); e("s_cbranch_scc1 done_%=")             # borrow: ran off event 0
-    e(f"s_add_u32 {T}, {DK}, {Y}")
-    e(f"s_sub_u32 {BI}, {BI}, {T}")
-    e("s_cbranch_scc0 step_%=")                                            # no borrow: still in this 32-band group
-    e(f"s_add_u32 {BI}, {BI}, 32"); e(f"s_sub_u32 {G}, {G}, 1")
-    e("s_waitcnt vmcnt(0)")
-    for a, b in zip(CW, NXG):
-        e(f"v_mov_b32 {a}, {b}")
-    e(f"s_mov_b32 {WC}, {NWC}"); e(f"s_mov_b32 {WR}, {W}")                  # the group just entered holds lanes WC +- W only
-    e("s_branch group_top_%=")
-    # ---- out of line
-    e("reload_lp_%=:")
-    e(f"s_mov_b32 {LP}, {U}")
-    e(f"s_sub_i32 {X}, {U}, {WC}"); e(f"s_abs_i32 {X}, {X}")
-    e(f"s_cmp_le_u32 {X}, {WR}")
-    e("s_cbranch_scc0 full_reload_%=")
-    e("reload_ret_%=:")
-    e(f"v_readlane_b32 s88, {CW[0]}, {U}"); e(f"v_readlane_b32 s89, {CW[1]}, {U}")
-    e(f"v_readlane_b32 s90, {CW[2]}, {U}"); e(f"v_readlane_b32 s91, {CW[3]}, {U}")
-    e("s_branch step_cont_%=")
-    e("full_reload_%=:")                                                    # the path left the prefetched window: load group G whole
-    e(f"s_lshl_b32 {X}, {G}, 10")
-    e(f"s_mov_b64 {T64}, %[trace]"); e(f"s_add_u32 s94, s94, {X}"); e("s_addc_u32 s95, s95, 0")
-    e("s_waitcnt vmcnt(0)")                                                 # the prefetch of G-1 (other registers) is in, nothing else in flight
-    e(f"global_load_dwordx4 v[{VB}:{VB + 3}], {L16}, {T64}")
-    e(f"s_mov_b32 {WR}, 64"); e(f"s_add_u32 {RLD}, {RLD}, 1")
-    e("s_waitcnt vmcnt(0)")
-    e("s_branch reload_ret_%=")
-    e("flush_%=:")                                                          # 16 codes complete: dword nfl -> lane nfl & 63
-    e(f"s_and_b32 {X}, {NFL}, 63")
-    e(f"v_cmp_eq_u32 vcc, {X}, %[lane]")
-    e(f"v_mov_b32 {VT}, {CWD}")
-    e(f"s_mov_b32 {CWD}, 0"); e(f"s_mov_b32 {SH2}, 0")
-    e(f"v_cndmask_b32 {CV}, {CV}, {VT}, vcc")
-    e(f"s_add_u32 {NFL}, {NFL}, 1")
-    e(f"s_and_b32 {X}, {NFL}, 63")
-    e("s_cbranch_scc1 flush_ret_%=")
-    e(f"s_sub_u32 {X}, {NFL}, 64"); e(f"s_lshl_b32 {X}, {X}, 2")
-    e(f"v_add_u32 {VT}, {X}, {L4}")
-    e("s_nop 1")
-    e(f"global_store_dword {VT}, {CV}, %[codes]")
-    e("s_branch flush_ret_%=")
-    e("done_%=:")
-    e("s_waitcnt vmcnt(0)")
-    e(f"s_add_u32 %[last_k], {K}, {DK}")
-    e(f"s_mov_b32 %[o_cwd], {CWD}"); e(f"s_mov_b32 %[o_sh2], {SH2}"); e(f"s_mov_b32 %[o_nfl], {NFL}")
-    e(f"s_mov_b32 %[o_maxgap], {MAXGAP}"); e(f"s_mov_b32 %[o_reloads], {RLD}")
-    e(f"v_mov_b32 %[o_cv], {CV}")
+    _walk_loops(e, locals())
     _finish_walk(o)
 
 
-def _walk2_loops(e, r):
-    """The two step loops of ABEA_WALK2 and their out-of-line blocks; r = gen_walk's register names."""
+def _walk_loops(e, r):
+    """The two step loops (upper / lower 16 bands of the trace group) and their out-of-line blocks; r = gen_walk's register names."""
     K, E, BI, LLK, G, GAP, MAXGAP, CWD, SH2, NFL, LP, DK = (r[n] for n in "K E BI LLK G GAP MAXGAP CWD SH2 NFL LP DK".split())
     TLO, THI, MV, T64, T64LO, T, U, X, Y = (r[n] for n in "TLO THI MV T64 T64LO T U X Y".split())
     WC, WR, NWC, RLD, CW, NXG, CV, VT, L16, L4, W = (r[n] for n in "WC WR NWC RLD CW NXG CV VT L16 L4 W".split())
@@ -1033,7 +716,7 @@ def _finish_walk(o):
 {text.replace(chr(10), " " + chr(92) + chr(10))}
 #define ABEA_WALK_CLOBBERS {clob}, "vcc", "scc", "memory"
 """
-    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "f5c_amd", "csrc", "abea_walk_exp.inc" if EXPERIMENT else "abea_walk.inc")
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "f5c_amd", "csrc", "abea_walk.inc")
     _emit_file(path, inc, len(o))
 
 
