@@ -255,7 +255,7 @@ struct abea_host_slot {
     hipStream_t stream_hi = nullptr;                    /* highest priority: what follows the alignment kernel of a chunk */
     bool hi_always = false, hi_never = false;
     hipStream_t post = nullptr;                         /* the stream the chunk in flight ends on */
-    hipEvent_t k0 = nullptr, k1 = nullptr, k2 = nullptr, k3 = nullptr, kdone = nullptr, done = nullptr;
+    hipEvent_t k0 = nullptr, k1 = nullptr, k2 = nullptr, k2b = nullptr, k3 = nullptr, kdone = nullptr, done = nullptr;
     uint8_t* up = nullptr;  size_t up_cap = 0;          /* pinned, host -> device: [desc][reads][evm] */
     uint8_t* dn = nullptr;  size_t dn_cap = 0;          /* pinned, device -> host */
     bool busy = false;
@@ -292,7 +292,8 @@ static int slot_create(abea_host_slot** out) {
     const char* hi = getenv("ABEA_HOST_HI_STREAM");           /* "0": never, "1": always, default: only when scaling_single is fused */
     s->hi_never = hi && hi[0] == '0';
     s->hi_always = hi && hi[0] == '1';
-    HIP_TRY(hipEventCreate(&s->k0)); HIP_TRY(hipEventCreate(&s->k1)); HIP_TRY(hipEventCreate(&s->k2)); HIP_TRY(hipEventCreate(&s->k3));
+    HIP_TRY(hipEventCreate(&s->k0)); HIP_TRY(hipEventCreate(&s->k1)); HIP_TRY(hipEventCreate(&s->k2)); HIP_TRY(hipEventCreate(&s->k2b));
+    HIP_TRY(hipEventCreate(&s->k3));
     HIP_TRY(hipEventCreateWithFlags(&s->kdone, hipEventDisableTiming | (getenv("ABEA_HOST_SPIN") ? 0 : hipEventBlockingSync)));
     HIP_TRY(hipEventCreateWithFlags(&s->done, hipEventDisableTiming | (getenv("ABEA_HOST_SPIN") ? 0 : hipEventBlockingSync)));
     return ABEA_OK;
@@ -392,7 +393,7 @@ void abea_host_release(abea_ctx* c) {
         if (!s) continue;
         if (s->stream_hi && s->stream_hi != s->stream) { hipStreamSynchronize(s->stream_hi); hipStreamDestroy(s->stream_hi); }
         if (s->stream) { hipStreamSynchronize(s->stream); hipStreamDestroy(s->stream); }
-        for (hipEvent_t e : {s->k0, s->k1, s->k2, s->k3, s->kdone, s->done}) if (e) hipEventDestroy(e);
+        for (hipEvent_t e : {s->k0, s->k1, s->k2, s->k2b, s->k3, s->kdone, s->done}) if (e) hipEventDestroy(e);
         hipHostFree(s->up); hipHostFree(s->dn);
         delete s;
     }
@@ -687,7 +688,11 @@ static int slot_retire(host_run_state& S, abea_host_slot& sl) {
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, sl.k0, sl.k1)); S.st.pre_ms += ms;
     HIP_TRY(hipEventElapsedTime(&ms, sl.k1, sl.k2)); S.st.fill_ms += ms;
-    if (scaling) { HIP_TRY(hipEventElapsedTime(&ms, sl.k2, sl.k3)); S.st.trace_ms += ms; }
+    if (scaling) {
+        HIP_TRY(hipEventElapsedTime(&ms, sl.k2, sl.k3)); S.st.trace_ms += ms;
+        HIP_TRY(hipEventElapsedTime(&ms, sl.k2, sl.k2b)); S.st.scaling_ms += ms;
+        HIP_TRY(hipEventElapsedTime(&ms, sl.k2b, sl.k3)); S.st.recalib_ms += ms;
+    }
     for (int32_t j = 0; j < sl.m; ++j) S.st.sum_pairs += npairs[j];
     sl.busy = false;
     return ABEA_OK;
@@ -971,6 +976,7 @@ static int host_run(abea_ctx* c, const abea_host_batch* H, const int32_t* mine, 
             hipLaunchKernelGGL(abea_scaling_kernel, dim3((unsigned)m), dim3(64), 0, post,
                                d_desc, d_reads, c->d_model, (int)c->k, d_evm, d_pairs, d_np, d_b2e,
                                (double*)(d_dn + sl.o_epb), (int32_t*)(d_dn + sl.o_flag), (int32_t*)(d_dn + sl.o_nal), d_mrec, d_nm);
+            HIP_TRY(hipEventRecord(sl.k2b, post));
             hipLaunchKernelGGL(abea_recalib_kernel, dim3((unsigned)((m + 63) / 64)), dim3(64), 0, post,
                                d_desc, (int)m, d_mrec, d_nm, (abea_scalings_t*)(d_dn + sl.o_sc),
                                (const double*)(d_dn + sl.o_epb), (int32_t*)(d_dn + sl.o_flag), min_rescale);
@@ -1026,6 +1032,7 @@ extern "C" int abea_lpt_split(const int64_t* weight, int32_t n, int32_t n_bins, 
 static void stats_add(abea_stats& a, const abea_stats& b) {
     /* kernel / host times: the devices work at the same time, the batch waits for the slowest */
     a.pre_ms = std::max(a.pre_ms, b.pre_ms); a.fill_ms = std::max(a.fill_ms, b.fill_ms); a.trace_ms = std::max(a.trace_ms, b.trace_ms);
+    a.scaling_ms = std::max(a.scaling_ms, b.scaling_ms); a.recalib_ms = std::max(a.recalib_ms, b.recalib_ms);
     a.host_ms = std::max(a.host_ms, b.host_ms); a.flatten_ms = std::max(a.flatten_ms, b.flatten_ms);
     a.unflatten_ms = std::max(a.unflatten_ms, b.unflatten_ms); a.wait_ms = std::max(a.wait_ms, b.wait_ms);
     a.n_reads_gpu += b.n_reads_gpu; a.n_reads_skipped += b.n_reads_skipped; a.n_sub_batches += b.n_sub_batches;

@@ -327,6 +327,10 @@ typedef struct {
     double wait_ms;                       /* time the calling thread spent waiting for the GPU */
     uint64_t h2d_bytes, d2h_bytes;        /* PCIe traffic of the call */
     int32_t n_devices, host_threads;
+    /* host batch with scaling_single fused: trace_ms split at the boundary between the two kernels.  Each part runs from the
+     * end of the previous kernel of the chunk to its own end, so it includes the time the kernel's workgroups waited for wave
+     * slots that other chunks' alignment kernels held. */
+    double scaling_ms, recalib_ms;
 } abea_stats;
 int abea_get_stats(abea_ctx* ctx, abea_stats* out);
 /* Multi-device context: the share of the last host batch that ran on device_ids[device]; abea_get_stats() gives the

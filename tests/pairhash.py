@@ -9,6 +9,12 @@ Position-dependent (a swap of two pairs changes it), vectorisable with numpy ove
 The pair (0, 0) alone contributes 0 (mix(0) = 0); the tests compare n_pairs beside the hash, so a list is never mistaken
 for an empty one.
 """
+import ctypes
+import os
+import subprocess
+import tempfile
+from concurrent.futures import ThreadPoolExecutor
+
 import numpy as np
 
 _C1 = np.uint64(0x9E3779B97F4A7C15)
@@ -45,4 +51,48 @@ def hash_pair_lists(pairs, pair_ptr, n_pairs, block=1 << 24):
                 y = y * (pos.astype(np.uint64) * np.uint64(2) + np.uint64(1))
                 out[i + nz] = np.add.reduceat(y, starts)
             i = j
+    return out
+
+
+_FAST = None
+
+
+def _fast_lib():
+    """tests/pairhash.c compiled into a temp directory (None if no compiler)."""
+    global _FAST
+    if _FAST is None:
+        _FAST = False
+        try:
+            src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "pairhash.c")
+            so = os.path.join(tempfile.mkdtemp(prefix="pairhash_"), "libpairhash.so")
+            subprocess.check_call(["gcc", "-O2", "-shared", "-fPIC", "-o", so, src])
+            lib = ctypes.CDLL(so)
+            lib.pairhash_range.restype = None
+            lib.pairhash_range.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p]
+            _FAST = lib
+        except Exception:
+            _FAST = False
+    return _FAST or None
+
+
+def hash_pair_lists_fast(pairs, pair_ptr, n_pairs, threads=None):
+    """The same hash through tests/pairhash.c on `threads` threads (ctypes releases the GIL); numpy when gcc is missing."""
+    lib = _fast_lib()
+    if lib is None:
+        return hash_pair_lists(pairs, pair_ptr, n_pairs)
+    p = np.ascontiguousarray(pairs).view(np.int32)
+    ptr = np.ascontiguousarray(pair_ptr, dtype=np.int64)
+    npr = np.ascontiguousarray(n_pairs, dtype=np.int32)
+    n = len(npr)
+    out = np.zeros(n, dtype=np.uint64)
+    threads = threads or max(1, min(16, len(os.sched_getaffinity(0))))
+    # equal shares of PAIRS, not of reads
+    cum = np.concatenate([[0], np.cumsum(np.maximum(npr, 0).astype(np.int64))])
+    cuts = np.unique(np.searchsorted(cum, np.linspace(0, cum[-1], threads + 1)[1:-1]))
+    bounds = [0] + [int(c) for c in cuts if 0 < c < n] + [n]
+
+    def run(k):
+        lib.pairhash_range(p.ctypes.data, ptr.ctypes.data, npr.ctypes.data, bounds[k], bounds[k + 1], out.ctypes.data)
+    with ThreadPoolExecutor(max_workers=threads) as ex:
+        list(ex.map(run, range(len(bounds) - 1)))
     return out

@@ -5,7 +5,7 @@ import os
 import numpy as np
 import pytest
 
-from pairhash import hash_pair_lists
+from pairhash import hash_pair_lists, hash_pair_lists_fast
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -33,6 +33,7 @@ def test_goldens_are_the_oracle_on_a_slice(orc, r9, config, lo):
     h = hash_pair_lists(pairs, b["pair_ptr"], n_pairs)
     assert (h == g["pair_hash"][idx]).all()
     assert (hash_pair_lists(pairs, b["pair_ptr"], n_pairs, block=5000) == h).all()      # independent of the blocking
+    assert (hash_pair_lists_fast(pairs, b["pair_ptr"], n_pairs, threads=3) == h).all()   # the C twin the full-size tests use
     assert (g["n_pairs"] > 0).mean() > 0.95 and (g["pair_hash"][g["n_pairs"] == 0] == 0).all()
 
 

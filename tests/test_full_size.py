@@ -17,14 +17,14 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 def check_against_config_goldens(config, batch, pairs, n_pairs, diag):
     """Every read of a synthetic BASELINE config against the oracle's committed per-read record."""
-    from pairhash import hash_pair_lists
+    from pairhash import hash_pair_lists_fast
     g = np.load(os.path.join(ROOT, "tests", "golden", f"config_goldens_{config}.npz"))
     n = len(g["n_pairs"])
     assert len(n_pairs) == n
     assert (batch["n_events"] == g["n_events"]).all() and (batch["read_len"] == g["read_len"]).all()   # the same batch
     bad = np.nonzero(n_pairs != g["n_pairs"])[0]
     assert len(bad) == 0, ("n_pairs", bad[:10])
-    h = hash_pair_lists(pairs, batch["pair_ptr"], n_pairs)
+    h = hash_pair_lists_fast(pairs, batch["pair_ptr"], n_pairs)       # tests/pairhash.c; == the numpy definition (test_config_goldens.py)
     bad = np.nonzero(h != g["pair_hash"])[0]
     assert len(bad) == 0, ("pair list hash", bad[:10])
     if diag is not None:

@@ -480,5 +480,5 @@ def test_bench_under_torchrun_world_size_1_runs_rccl(tmp_path):
     assert set(j["per_rank"][0]["host_ms_per_step"]) == {"flatten", "unflatten", "wait_for_gpu"}
     assert j["roofline"]["target_frac"] == 0.40 and j["roofline"]["target_met"] is False
     vr = j["roofline"]["valu_roofline"]                          # 1500 reads fill a third of the wave slots: far below the ceiling
-    assert vr["issue_slots"]["simds"] == 1024 and vr["issue_slots"]["valu_wave_instr_per_launch"] > 0
+    assert vr["class_floor"]["right_move_bands"] > 0 and vr["measured_ms"] > 0
     assert 0.0 < vr["class_floor"]["frac"] < 1.0 and vr["frac"] == vr["class_floor"]["frac"]
