@@ -366,8 +366,9 @@ def fused_scaling(ctx, batch, view):
     cal = int(((v["read_stat_flag"] & 1) == 0).sum())
     return {"mevents_per_s": round(ev / t / 1e6, 1), "ms_per_step": round(t * 1e3, 2),
             "scaling_kernels_ms_sum_over_chunks": round(st["trace_ms"], 2),
-            "scaling_kernels_split_ms": {"abea_scaling_kernel": round(st["scaling_ms"], 2), "abea_recalib_kernel": round(st["recalib_ms"], 2),
-                                         "note": "end of the previous kernel of the chunk to the end of this one: includes waiting for wave slots"},
+            "align_kernels_ms_sum_over_chunks": round(st["fill_ms"], 2),
+            "scaling_note": "round 4: scaling_single runs inside abea_align_kernel (the wavefront that aligned a read recalibrates it); "
+                            "no separate scaling kernels are launched, so their sum is 0 by construction",
             "pcie_bytes_per_step": {"h2d": int(st["h2d_bytes"]), "d2h": int(st["d2h_bytes"])},
             "n_pairs_equal_alignment_only": same, "reads_calibrated": cal,
             "note": "pairs = NULL; the walk (2 bit/step) crosses PCIe and the host expands it into base_to_event_map"}

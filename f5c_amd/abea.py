@@ -102,7 +102,7 @@ class Stats(C.Structure):
                 ("bytes_moved", C.c_uint64),
                 ("flatten_ms", C.c_double), ("unflatten_ms", C.c_double), ("wait_ms", C.c_double),
                 ("h2d_bytes", C.c_uint64), ("d2h_bytes", C.c_uint64), ("n_devices", C.c_int32),
-                ("host_threads", C.c_int32), ("scaling_ms", C.c_double), ("recalib_ms", C.c_double)]
+                ("host_threads", C.c_int32)]
 
     def asdict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -285,24 +285,11 @@ extern "C" int abea_align_batch_device(abea_ctx* c, const abea_device_batch* B) 
     while (pos < seq.size()) {
         /* ---- carve a sub-batch that fits the arena ---- */
         size_t end = pos, bytes = 4096;
-        size_t mr_done = 0; int32_t mr_in = 0, mr_kmax = 0;   /* 'M' records: 64 consecutive reads interleaved, padded to the longest */
         while (end < seq.size()) {
             const plan_read& r = reads[(size_t)seq[end]];
-            size_t need = (r.run ? scratch_bytes(r) : sizeof(abea_read_desc)) + 4;
-            size_t mr = 0;
-            if (B->base_to_event_map) {
-                const int32_t k = std::max(r.run ? r.K : 0, 1);
-                mr = (mr_in == 64 || mr_in == 0) ? mr_done + (mr_in == 64 ? (size_t)mr_kmax * 64 : 0) + (size_t)k * 64
-                                                 : mr_done + (size_t)std::max(mr_kmax, k) * 64;
-                mr = mr * sizeof(abea_mrec) + 256;
-            }
-            if (bytes + need + mr + 65536 > c->arena_bytes) break;
+            const size_t need = (r.run ? scratch_bytes(r) : sizeof(abea_read_desc)) + 4;
+            if (bytes + need + 65536 > c->arena_bytes) break;
             bytes += need; ++end;
-            if (B->base_to_event_map) {
-                const int32_t k = std::max(r.run ? r.K : 0, 1);
-                if (mr_in == 64) { mr_done += (size_t)mr_kmax * 64; mr_in = 0; mr_kmax = 0; }
-                mr_kmax = std::max(mr_kmax, k); ++mr_in;
-            }
         }
         if (end == pos)
             return abea_fail(ABEA_ENOMEM, "read %d (L=%d, E=%d) needs more scratch than the %zu-byte arena",
@@ -313,7 +300,6 @@ extern "C" int abea_align_batch_device(abea_ctx* c, const abea_device_batch* B) 
 
         /* ---- arena layout: [desc][kpar][evm][codes][trace] ---- */
         sub_layout lay;
-        size_t n_mrec = 0;
         for (size_t j = 0; j < m; ++j) {
             const plan_read& r = reads[(size_t)seq[pos + j]];
             abea_read_desc& d = c->h_desc[j];
@@ -321,13 +307,6 @@ extern "C" int abea_align_batch_device(abea_ctx* c, const abea_device_batch* B) 
             d.read_off = B->read_ptr[r.idx]; d.event_off = B->event_ptr[r.idx]; d.pair_off = B->pair_ptr[r.idx];
             d.kmer_off = B->kmer_ptr ? B->kmer_ptr[r.idx] : 0;
         }
-        if (B->base_to_event_map)                            /* 'M'-state records: 64 consecutive descriptors interleaved */
-            for (size_t j0 = 0; j0 < m; j0 += 64) {
-                int32_t kmax = 1;
-                for (size_t j = j0; j < std::min(m, j0 + 64); ++j) kmax = std::max(kmax, c->h_desc[j].n_groups ? c->h_desc[j].n_kmers : 1);
-                for (size_t j = j0; j < std::min(m, j0 + 64); ++j) c->h_desc[j].pad64 = (int64_t)(n_mrec + (j - j0));
-                n_mrec += (size_t)kmax * 64;
-            }
         const size_t n_kpar = lay.n_kpar, n_evm = lay.n_evm, n_code = lay.n_code, n_trace = lay.n_trace;
         uint8_t* p = c->arena;
         abea_read_desc* d_desc = (abea_read_desc*)p;        p += align_up(m * sizeof(abea_read_desc), 256);
@@ -335,8 +314,6 @@ extern "C" int abea_align_batch_device(abea_ctx* c, const abea_device_batch* B) 
         float* d_evm = (float*)p;                           p += align_up(n_evm * 4 + 512, 256);
         uint32_t* d_codes = (uint32_t*)p;                   p += align_up(n_code * 4, 256);
         uint4* d_trace = (uint4*)p;                         p += n_trace * sizeof(uint4);
-        abea_mrec* d_mrec = (abea_mrec*)p;                  p += align_up(n_mrec * sizeof(abea_mrec), 256);
-        int32_t* d_nm = (int32_t*)p;                        p += align_up(m * 4, 256);
         if ((size_t)(p - c->arena) > c->arena_bytes)
             return abea_fail(ABEA_ENOMEM, "internal: sub-batch layout %zu exceeds arena %zu", (size_t)(p - c->arena), c->arena_bytes);
 
@@ -345,25 +322,24 @@ extern "C" int abea_align_batch_device(abea_ctx* c, const abea_device_batch* B) 
         hipLaunchKernelGGL(abea_pre_kernel, dim3((unsigned)m), dim3(256), 0, c->stream,
                            d_desc, B->reads, B->events, c->d_model, (int)c->k, d_kpar, d_evm);
         HIP_TRY(hipEventRecord(c->ev[1], c->stream));
+        abea_fused_scaling fs;                               /* row N1: scaling_single as the last phase of the kernel */
+        memset(&fs, 0, sizeof fs);
+        if (B->base_to_event_map) {
+            fs.reads = B->reads; fs.model = c->d_model; fs.b2e = B->base_to_event_map; fs.sc_io = B->scalings_io;
+            fs.epb = B->events_per_base; fs.flag_io = B->read_stat_flag; fs.nalign = B->n_event_alignment;
+            fs.kmer_size = (int32_t)c->k;
+            fs.min_rescale = B->min_num_events_to_rescale > 0 ? B->min_num_events_to_rescale : 200;
+        }
         hipLaunchKernelGGL(abea_align_kernel, dim3((unsigned)m), dim3(64), 0, c->stream,
                            d_desc, d_evm, d_kpar, d_trace, d_codes, B->pairs, B->n_pairs, B->diag,
-                           (unsigned long long*)nullptr, (int64_t*)nullptr);
+                           (unsigned long long*)nullptr, (int64_t*)nullptr, fs);
         HIP_TRY(hipEventRecord(c->ev[2], c->stream));
-        if (B->base_to_event_map) {                          /* row N1: scaling_single on the device */
-            hipLaunchKernelGGL(abea_scaling_kernel, dim3((unsigned)m), dim3(64), 0, c->stream,
-                               d_desc, B->reads, c->d_model, (int)c->k, d_evm, B->pairs, B->n_pairs,
-                               B->base_to_event_map, B->events_per_base, B->read_stat_flag, B->n_event_alignment, d_mrec, d_nm);
-            hipLaunchKernelGGL(abea_recalib_kernel, dim3((unsigned)((m + 63) / 64)), dim3(64), 0, c->stream,
-                               d_desc, (int)m, d_mrec, d_nm, B->scalings_io, B->events_per_base, B->read_stat_flag,
-                               B->min_num_events_to_rescale > 0 ? B->min_num_events_to_rescale : 200);
-        }
         HIP_TRY(hipEventRecord(c->ev[3], c->stream));
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(c->stream));            /* h_desc and the arena are reused by the next sub-batch */
         float ms = 0;
         HIP_TRY(hipEventElapsedTime(&ms, c->ev[0], c->ev[1])); st.pre_ms += ms;
-        HIP_TRY(hipEventElapsedTime(&ms, c->ev[1], c->ev[2])); st.fill_ms += ms;   /* fused fill + traceback */
-        HIP_TRY(hipEventElapsedTime(&ms, c->ev[2], c->ev[3])); st.trace_ms += ms;  /* optional scaling kernel */
+        HIP_TRY(hipEventElapsedTime(&ms, c->ev[1], c->ev[2])); st.fill_ms += ms;   /* fused fill + traceback (+ scaling_single) */
         st.n_sub_batches += 1; st.fill_launches += 1;
         pos = end;
     }

@@ -27,7 +27,7 @@ typedef struct __attribute__((aligned(16))) {
     int64_t trace_off;    /* uint4  into the trace scratch (n_groups * 64 uint4) */
     int64_t code_off;     /* uint32 into the traceback-code scratch */
     int64_t kmer_off;     /* abea_index_pair_t into base_to_event_map (optional scaling outputs) */
-    int64_t pad64;        /* abea_mrec into the 'M'-state record scratch of the scaling kernels (n_kmers slots) */
+    int64_t pad64;        /* unused since round 4 (was: the 'M'-state record scratch of the separate scaling kernels) */
     int32_t read_len, n_events, n_kmers, n_groups;
     float   scale, shift;
     int32_t out_idx;      /* index of the read in the caller's n_pairs[] / diag[] */
@@ -35,12 +35,18 @@ typedef struct __attribute__((aligned(16))) {
     double  lp_skip, lp_stay, lp_step, lp_trim;   /* align.c:212-216 */
 } abea_read_desc;
 
-/* one 'M' state of recalibrate_model (align.c:688-753): what its sums read, in k order.  Records of the 64 reads that
- * share a wavefront of abea_recalib_kernel are INTERLEAVED: record m of the read in lane l sits at index
- * desc.pad64 + 64 * m (desc.pad64 = 64 * wave base + l), so the lane-per-read kernel's loads are coalesced.  Two 16-byte
- * halves, one per pass of that kernel (each pass keeps a ring of 16-byte loads in flight per lane): the normal-equation
- * sums read {1/(stdv*stdv), level_mean, event mean}, the variance sum {stdv*stdv (exact in fp64), level_mean, event mean}. */
-struct __attribute__((aligned(16))) abea_mrec { double inv_var; float mu; float e; double sd2; float mu2; float e2; };
-#define ABEA_MREC_STRIDE 64
+/* scaling_single() fused behind the alignment, inside abea_align_kernel (round 4): the wavefront that aligned a read also runs
+ * postalign + recalibrate_model + the FAILED_* flags for it (src/f5c.c:736-807, src/align.c:561-773).  Passed by value; b2e ==
+ * NULL switches the stage off.  The pair lists must be materialised (pairs_all != NULL): the stage reads them back. */
+typedef struct {
+    const char* reads;                  /* sequences of the launch (desc.read_off) */
+    const abea_model_t* model;          /* k-mer model on the device */
+    abea_index_pair_t* b2e;             /* base_to_event_map: entry k of a read at b2e[desc.kmer_off + k] */
+    abea_scalings_t* sc_io;             /* [out_idx] estimated scalings in, recalibrated shift / scale / var out */
+    double* epb;                        /* [out_idx] events_per_base */
+    int32_t* flag_io;                   /* [out_idx] FAILED_* bits OR-ed in */
+    int32_t* nalign;                    /* [out_idx] n_event_alignment */
+    int32_t kmer_size, min_rescale;
+} abea_fused_scaling;
 
 #endif

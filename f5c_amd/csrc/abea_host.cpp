@@ -255,7 +255,7 @@ struct abea_host_slot {
     hipStream_t stream_hi = nullptr;                    /* highest priority: what follows the alignment kernel of a chunk */
     bool hi_always = false, hi_never = false;
     hipStream_t post = nullptr;                         /* the stream the chunk in flight ends on */
-    hipEvent_t k0 = nullptr, k1 = nullptr, k2 = nullptr, k2b = nullptr, k3 = nullptr, kdone = nullptr, done = nullptr;
+    hipEvent_t k0 = nullptr, k1 = nullptr, k2 = nullptr, kdone = nullptr, done = nullptr;
     uint8_t* up = nullptr;  size_t up_cap = 0;          /* pinned, host -> device: [desc][reads][evm] */
     uint8_t* dn = nullptr;  size_t dn_cap = 0;          /* pinned, device -> host */
     bool busy = false;
@@ -289,11 +289,10 @@ static int slot_create(abea_host_slot** out) {
      * stream their workgroups queue for wave slots behind the alignment kernels of the OTHER slots, which hold all 4096 of
      * them for milliseconds at a time (measured: 25 ms per chunk for 1 ms of work).  A queue of higher priority is served first
      * whenever slots free up. */
-    const char* hi = getenv("ABEA_HOST_HI_STREAM");           /* "0": never, "1": always, default: only when scaling_single is fused */
+    const char* hi = getenv("ABEA_HOST_HI_STREAM");           /* "1": the copy-out of a chunk goes through a high-priority stream; default: the slot's own */
     s->hi_never = hi && hi[0] == '0';
     s->hi_always = hi && hi[0] == '1';
-    HIP_TRY(hipEventCreate(&s->k0)); HIP_TRY(hipEventCreate(&s->k1)); HIP_TRY(hipEventCreate(&s->k2)); HIP_TRY(hipEventCreate(&s->k2b));
-    HIP_TRY(hipEventCreate(&s->k3));
+    HIP_TRY(hipEventCreate(&s->k0)); HIP_TRY(hipEventCreate(&s->k1)); HIP_TRY(hipEventCreate(&s->k2));
     HIP_TRY(hipEventCreateWithFlags(&s->kdone, hipEventDisableTiming | (getenv("ABEA_HOST_SPIN") ? 0 : hipEventBlockingSync)));
     HIP_TRY(hipEventCreateWithFlags(&s->done, hipEventDisableTiming | (getenv("ABEA_HOST_SPIN") ? 0 : hipEventBlockingSync)));
     return ABEA_OK;
@@ -393,7 +392,7 @@ void abea_host_release(abea_ctx* c) {
         if (!s) continue;
         if (s->stream_hi && s->stream_hi != s->stream) { hipStreamSynchronize(s->stream_hi); hipStreamDestroy(s->stream_hi); }
         if (s->stream) { hipStreamSynchronize(s->stream); hipStreamDestroy(s->stream); }
-        for (hipEvent_t e : {s->k0, s->k1, s->k2, s->k2b, s->k3, s->kdone, s->done}) if (e) hipEventDestroy(e);
+        for (hipEvent_t e : {s->k0, s->k1, s->k2, s->kdone, s->done}) if (e) hipEventDestroy(e);
         hipHostFree(s->up); hipHostFree(s->dn);
         delete s;
     }
@@ -514,7 +513,7 @@ struct chunk_span { size_t begin, end; size_t events; bool whole_arena; };
 static size_t chunk_io_bytes(const plan_read& r, bool pairs_on_device, bool scaling) {
     size_t b = align_up((size_t)r.L + 1, 16) + 4 + sizeof(abea_read_diag) + 8;
     if (pairs_on_device) b += ((size_t)r.E + (size_t)r.L) * sizeof(abea_pair_t);
-    /* map (device scratch) + per-read scalars; the 'M' records are charged per 64-read wave by mrec_wave_bytes() */
+    /* map (device scratch) + per-read scalars */
     if (scaling) b += (size_t)r.K * sizeof(abea_index_pair_t) + sizeof(abea_scalings_t) + 8 + 4 + 4 + 4;
     return b + 64;
 }
@@ -523,23 +522,6 @@ static size_t chunk_io_bytes(const plan_read& r, bool pairs_on_device, bool scal
  * chunk_reads_min reads AND chunk_events events (the first two chunks a quarter / half of that, so the GPU starts
  * early), at chunk_reads_max reads, or when the next read would not fit the slot's share of the arena; a read that
  * does not fit a share on its own gets the whole arena, alone. */
-/* 'M'-state records of the scaling kernels: the reads of a chunk are taken 64 at a time (one abea_recalib_kernel
- * wavefront) and each group's records are interleaved, padded to the group's longest read.  Running cost of a chunk while
- * reads are appended: */
-struct mrec_meter {
-    size_t done = 0; int32_t in_wave = 0, kmax = 0;
-    size_t with(int32_t K) const {                       /* bytes if a read of K k-mers were appended */
-        const int32_t k = std::max(K, 1);
-        if (in_wave == 64 || in_wave == 0) return done + (in_wave == 64 ? (size_t)kmax * 64 * sizeof(abea_mrec) : 0) + (size_t)k * 64 * sizeof(abea_mrec);
-        return done + (size_t)std::max(kmax, k) * 64 * sizeof(abea_mrec);
-    }
-    void add(int32_t K) {
-        const int32_t k = std::max(K, 1);
-        if (in_wave == 64) { done += (size_t)kmax * 64 * sizeof(abea_mrec); in_wave = 0; kmax = 0; }
-        kmax = std::max(kmax, k); ++in_wave;
-    }
-};
-
 static std::vector<chunk_span> carve_chunks(const std::vector<plan_read>& reads, const std::vector<int32_t>& order,
                                             const host_opts& opt, size_t slot_arena, bool pairs_on_device, bool scaling) {
     std::vector<chunk_span> out;
@@ -550,16 +532,14 @@ static std::vector<chunk_span> carve_chunks(const std::vector<plan_read>& reads,
         const int32_t want_reads = std::max(1, opt.chunk_reads_min / ramp);
         size_t bytes = 65536, ev = 0, end = pos;
         bool whole_arena = false;
-        mrec_meter mm;
         while (end < order.size()) {
             const plan_read& r = reads[(size_t)order[end]];
             const size_t need = scratch_bytes(r) + chunk_io_bytes(r, pairs_on_device, scaling);
-            if (bytes + need + (scaling ? mm.with(r.K) + 256 : 0) > slot_arena) {
+            if (bytes + need > slot_arena) {
                 if (end > pos) break;
                 whole_arena = true;                      /* an over-long read: give it the whole arena, alone */
             }
             bytes += need; ev += (size_t)r.E; ++end;
-            if (scaling) mm.add(r.K);
             const int32_t cnt = (int32_t)(end - pos);
             if (whole_arena || (cnt >= want_reads && ev >= want_ev) || cnt >= opt.chunk_reads_max) break;
         }
@@ -688,11 +668,6 @@ static int slot_retire(host_run_state& S, abea_host_slot& sl) {
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, sl.k0, sl.k1)); S.st.pre_ms += ms;
     HIP_TRY(hipEventElapsedTime(&ms, sl.k1, sl.k2)); S.st.fill_ms += ms;
-    if (scaling) {
-        HIP_TRY(hipEventElapsedTime(&ms, sl.k2, sl.k3)); S.st.trace_ms += ms;
-        HIP_TRY(hipEventElapsedTime(&ms, sl.k2, sl.k2b)); S.st.scaling_ms += ms;
-        HIP_TRY(hipEventElapsedTime(&ms, sl.k2b, sl.k3)); S.st.recalib_ms += ms;
-    }
     for (int32_t j = 0; j < sl.m; ++j) S.st.sum_pairs += npairs[j];
     sl.busy = false;
     return ABEA_OK;
@@ -808,7 +783,7 @@ static int host_run(abea_ctx* c, const abea_host_batch* H, const int32_t* mine, 
     /* check every read against the arena before anything is launched */
     for (int32_t q : order) {
         const plan_read& r = S.reads[(size_t)q];
-        if (scratch_bytes(r) + io_bytes(r) + (scaling ? (size_t)r.K * 64 * sizeof(abea_mrec) : 0) + 65536 > lane.arena_bytes)
+        if (scratch_bytes(r) + io_bytes(r) + 65536 > lane.arena_bytes)
             return abea_fail(ABEA_ENOMEM, "read %d (L=%d, E=%d) needs more scratch than the %zu-byte arena", r.idx, r.L, r.E,
                              lane.arena_bytes);
     }
@@ -864,15 +839,6 @@ static int host_run(abea_ctx* c, const abea_host_batch* H, const int32_t* mine, 
                 ko += (size_t)r.K;
             }
         }
-        /* 'M'-state records of the scaling kernels: the 64 reads of one abea_recalib_kernel wavefront interleaved */
-        size_t n_mrec = 0;
-        if (scaling)
-            for (int32_t j0 = 0; j0 < m; j0 += 64) {
-                int32_t kmax = 1;
-                for (int32_t j = j0; j < std::min(m, j0 + 64); ++j) kmax = std::max(kmax, descs[j].n_kmers);
-                for (int32_t j = j0; j < std::min(m, j0 + 64); ++j) descs[j].pad64 = (int64_t)(n_mrec + (size_t)(j - j0));
-                n_mrec += (size_t)kmax * 64;
-            }
         /* `dn` = [npairs][diag][codes | poff, cursor][scaling outputs] mirrors the arena block behind the scratch */
         size_t o = 0;
         sl.o_np = o;      o = align_up(o + (size_t)m * 4, 256);
@@ -898,11 +864,9 @@ static int host_run(abea_ctx* c, const abea_host_batch* H, const int32_t* mine, 
         if (S.device_pairs) { d_codes_scratch = (uint32_t*)p; p += align_up(lay.n_code * 4, 256); }
         abea_pair_t* d_pairs = nullptr;
         if (pairs_on_device) { d_pairs = (abea_pair_t*)p; p += align_up(n_pair * sizeof(abea_pair_t), 256); }
-        abea_index_pair_t* d_b2e = nullptr; abea_mrec* d_mrec = nullptr; int32_t* d_nm = nullptr;
-        if (scaling) {                                      /* device-only scratch of the two scaling kernels */
+        abea_index_pair_t* d_b2e = nullptr;
+        if (scaling) {                                      /* device-only scratch of the fused scaling_single stage: the map */
             d_b2e = (abea_index_pair_t*)p;  p += align_up(n_kmer * sizeof(abea_index_pair_t), 256);
-            d_mrec = (abea_mrec*)p;         p += align_up(n_mrec * sizeof(abea_mrec), 256);
-            d_nm = (int32_t*)p;             p += align_up((size_t)m * 4, 256);
         }
         if ((size_t)(p - arena) > (whole_arena ? lane.arena_bytes : slot_arena))
             return abea_fail(ABEA_ENOMEM, "internal: chunk layout %zu exceeds its arena share %zu", (size_t)(p - arena),
@@ -961,27 +925,27 @@ static int host_run(abea_ctx* c, const abea_host_batch* H, const int32_t* mine, 
         hipLaunchKernelGGL(abea_pre_kernel, dim3((unsigned)m), dim3(256), 0, sl.stream,
                            d_desc, d_reads, (const abea_event_t*)nullptr, c->d_model, (int)c->k, d_kpar, d_evm);
         HIP_TRY(hipEventRecord(sl.k1, sl.stream));
+        /* scaling_single, when requested, is the last phase of the alignment kernel: the wavefront that aligned a read builds
+         * its base_to_event_map and recalibrates its scalings (round 4; rounds 1-3 launched one / two kernels behind it, which
+         * queued for wave slots behind the other chunks' alignment kernels and cost 4-15 ms per chunk) */
+        abea_fused_scaling fs;
+        memset(&fs, 0, sizeof fs);
+        if (scaling) {
+            fs.reads = d_reads; fs.model = c->d_model; fs.b2e = d_b2e;
+            fs.sc_io = (abea_scalings_t*)(d_dn + sl.o_sc); fs.epb = (double*)(d_dn + sl.o_epb);
+            fs.flag_io = (int32_t*)(d_dn + sl.o_flag); fs.nalign = (int32_t*)(d_dn + sl.o_nal);
+            fs.kmer_size = (int32_t)c->k; fs.min_rescale = min_rescale;
+        }
         hipLaunchKernelGGL(abea_align_kernel, dim3((unsigned)m), dim3(64), 0, sl.stream,
                            d_desc, d_evm, d_kpar, d_trace, d_codes, d_pairs, d_np, d_diag,
-                           S.device_pairs ? d_cursor : (unsigned long long*)nullptr, S.device_pairs ? d_poff : (int64_t*)nullptr);
+                           S.device_pairs ? d_cursor : (unsigned long long*)nullptr, S.device_pairs ? d_poff : (int64_t*)nullptr, fs);
         HIP_TRY(hipEventRecord(sl.k2, sl.stream));
-        /* the rest of the chunk jumps the queue (slot_create) when scaling_single is fused: its two kernels are the bulk of
-         * the chunk's latency then.  With the alignment alone only the copy-out follows, and the measurements do not show a
-         * gain that outweighs one more busy queue on a host-bound box, so it stays on the slot's stream. */
+        /* only the small copy-out follows the kernel; it stays on the slot's stream unless ABEA_HOST_HI_STREAM=1 asks for the
+         * high-priority queue (the measurements do not show a gain that outweighs one more busy queue) */
         hipStream_t post = sl.stream;
-        if ((scaling || sl.hi_always) && (rc = slot_hi_stream(sl, &post))) return rc;
+        if (sl.hi_always && (rc = slot_hi_stream(sl, &post))) return rc;
         sl.post = post;
         if (post != sl.stream) HIP_TRY(hipStreamWaitEvent(post, sl.k2, 0));
-        if (scaling) {
-            hipLaunchKernelGGL(abea_scaling_kernel, dim3((unsigned)m), dim3(64), 0, post,
-                               d_desc, d_reads, c->d_model, (int)c->k, d_evm, d_pairs, d_np, d_b2e,
-                               (double*)(d_dn + sl.o_epb), (int32_t*)(d_dn + sl.o_flag), (int32_t*)(d_dn + sl.o_nal), d_mrec, d_nm);
-            HIP_TRY(hipEventRecord(sl.k2b, post));
-            hipLaunchKernelGGL(abea_recalib_kernel, dim3((unsigned)((m + 63) / 64)), dim3(64), 0, post,
-                               d_desc, (int)m, d_mrec, d_nm, (abea_scalings_t*)(d_dn + sl.o_sc),
-                               (const double*)(d_dn + sl.o_epb), (int32_t*)(d_dn + sl.o_flag), min_rescale);
-            HIP_TRY(hipEventRecord(sl.k3, post));
-        }
         /* the result block goes down by a kernel, not by an SDMA copy: a copy queued behind the alignment kernel would
          * hold its SDMA ring until that kernel ends and stall the next chunks' H2D copies (abea_copy_out_kernel) */
         if (S.opt.sdma_d2h) HIP_TRY(hipMemcpyAsync(sl.dn, d_dn, dn_copy, hipMemcpyDeviceToHost, post));
@@ -1032,7 +996,6 @@ extern "C" int abea_lpt_split(const int64_t* weight, int32_t n, int32_t n_bins, 
 static void stats_add(abea_stats& a, const abea_stats& b) {
     /* kernel / host times: the devices work at the same time, the batch waits for the slowest */
     a.pre_ms = std::max(a.pre_ms, b.pre_ms); a.fill_ms = std::max(a.fill_ms, b.fill_ms); a.trace_ms = std::max(a.trace_ms, b.trace_ms);
-    a.scaling_ms = std::max(a.scaling_ms, b.scaling_ms); a.recalib_ms = std::max(a.recalib_ms, b.recalib_ms);
     a.host_ms = std::max(a.host_ms, b.host_ms); a.flatten_ms = std::max(a.flatten_ms, b.flatten_ms);
     a.unflatten_ms = std::max(a.unflatten_ms, b.unflatten_ms); a.wait_ms = std::max(a.wait_ms, b.wait_ms);
     a.n_reads_gpu += b.n_reads_gpu; a.n_reads_skipped += b.n_reads_skipped; a.n_sub_batches += b.n_sub_batches;

@@ -19,14 +19,8 @@ extern "C" {
 __global__ void abea_selftest_kernel(int* out);
 __global__ void abea_pre_kernel(const abea_read_desc*, const char*, const abea_event_t*, const abea_model_t*, int,
                                 abea_kpar_t*, float*);
-struct abea_mrec;            /* 32-byte 'M'-state record, abea_device.h */
-__global__ void abea_scaling_kernel(const abea_read_desc*, const char*, const abea_model_t*, int, const float*,
-                                    const abea_pair_t*, const int32_t*, abea_index_pair_t*, double*, int32_t*, int32_t*,
-                                    abea_mrec*, int32_t*);
-__global__ void abea_recalib_kernel(const abea_read_desc*, int, const abea_mrec*, const int32_t*, abea_scalings_t*,
-                                    const double*, int32_t*, int);
 __global__ void abea_align_kernel(const abea_read_desc*, const float*, const abea_kpar_t*, uint4*, uint32_t*,
-                                  abea_pair_t*, int32_t*, abea_read_diag*, unsigned long long*, int64_t*);
+                                  abea_pair_t*, int32_t*, abea_read_diag*, unsigned long long*, int64_t*, const abea_fused_scaling);
 __global__ void abea_copy_out_kernel(const uint4*, uint4*, size_t);
 }
 

@@ -140,6 +140,158 @@ static __device__ __forceinline__ void abea_cell(float x, float gpm, float ck, d
     from = (sl >= m1) ? 2u : f;
 }
 
+/* ================================================================ scaling_single, per read, by the wavefront that aligned it
+ * postalign (align.c:561-661) + recalibrate_model (align.c:666-773) + the flags of scaling_single (f5c.c:736-807).
+ * Rounds 1-3 ran this as one / two kernels behind the alignment kernel of a chunk; on a GPU whose 4096 wave slots are held
+ * by the alignment kernels of the other chunks those small kernels waited milliseconds for slots, and the lane-per-read
+ * chains of the recalibration took 4-15 ms per chunk (rocprofv3 timeline, profiles/r04/e_fused_20k_kernel_trace.csv).
+ * Now it is the tail of abea_align_kernel: no launch, no queueing, no 'M'-state records through HBM.
+ *   base_to_event_map: every k-mer owns one contiguous run of pairs; its first pair repeats the previous event iff it was
+ *     reached by a skip (FROM_L), all later pairs of the run are new events.  Parallel over pairs.
+ *   'M' states = first event of each k-mer that has events and whose rank differs from the previous such k-mer
+ *     (hmm_state, align.c:637; counted at align.c:677-686), found 64 k-mers at a time with ballots.
+ *   recalibrate_model's five normal-equation sums and its variance sum are sequential fp64 chains in k order whose terms are
+ *     full-mantissa doubles: no re-association is exact, the chains stay sequential.  But the TERMS are independent: the 64
+ *     lanes compute them in parallel (the fp64 division included), park them in LDS in 'M'-state order, and then lanes 0..4
+ *     (one per sum) add their column in order — a step of the chain is one LDS read (pipelined eight deep) and one v_add_f64,
+ *     not a trip to HBM.  Same operations, same order, same bits as align.c:688-753. */
+static __device__ __forceinline__ abea_pair_t load_pair_l2(const abea_pair_t* p) {
+    /* written by this wavefront a moment ago: read past the CU's L1, which may hold a neighbour's stale copy of a shared line */
+    const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    abea_pair_t r; r.ref_pos = (int32_t)(uint32_t)v; r.read_pos = (int32_t)(uint32_t)(v >> 32);
+    return r;
+}
+static __device__ __forceinline__ abea_index_pair_t load_map_l2(const abea_index_pair_t* p) {
+    const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    abea_index_pair_t r; r.start = (int32_t)(uint32_t)v; r.stop = (int32_t)(uint32_t)(v >> 32);
+    return r;
+}
+
+static __device__ void abea_fused_not_aligned(const abea_fused_scaling& fs, int out_idx, int lane) {
+    if (lane == 0) {                                     /* f5c.c:786-794: could not align */
+        fs.flag_io[out_idx] |= ABEA_FAILED_ALIGNMENT; fs.epb[out_idx] = 0.0; fs.nalign[out_idx] = 0;
+    }
+}
+
+/* n = the read's pair count after QC (> 0), pairs = its list in HBM, lds = 64 x 5 doubles of wave-private LDS */
+static __device__ void abea_scaling_single_wave(const abea_read_desc* d, const abea_fused_scaling& fs, int lane, int n,
+                                                const abea_pair_t* __restrict__ pairs, const float* __restrict__ evm,
+                                                double* lds) {
+    const int out_idx = d->out_idx;
+    const int K = d->n_kmers;
+    const int kmer_size = fs.kmer_size;
+    abea_index_pair_t* map = fs.b2e + d->kmer_off;
+    const char* __restrict__ seq = fs.reads + d->read_off;
+    const abea_model_t* __restrict__ model = fs.model;
+
+    /* ---- base_to_event_map (align.c:571-596) ---- */
+    for (int i = lane; i < n; i += 64) {
+        const abea_pair_t p = load_pair_l2(pairs + i);
+        abea_pair_t pm, pn; pm.ref_pos = pm.read_pos = -1; pn = pm;
+        if (i > 0) pm = load_pair_l2(pairs + i - 1);
+        if (i < n - 1) pn = load_pair_l2(pairs + i + 1);
+        const bool run_start = (i == 0) || (pm.ref_pos != p.ref_pos);
+        const bool run_end = (i == n - 1) || (pn.ref_pos != p.ref_pos);
+        const bool is_new = (i == 0) || (p.read_pos != pm.read_pos);
+        if (run_start) map[p.ref_pos].start = is_new ? p.read_pos : (!run_end ? pn.read_pos : -1);
+        if (run_end) map[p.ref_pos].stop = (!run_start || is_new) ? p.read_pos : -1;
+    }
+    const abea_pair_t p_first = load_pair_l2(pairs), p_last = load_pair_l2(pairs + n - 1);
+    const double events_per_base = (double)(p_last.read_pos - p_first.read_pos) / K;   /* align.c:602 */
+    __syncthreads();                                     /* the map is complete (and in L2) before it is swept */
+
+    /* ---- one sweep over the k-mers in k order, 64 at a time: the 'M' states and, in their order, term(s) of a sum.
+     *      PASS 0: the five normal-equation sums + the counts; PASS 1: the variance sum (needs shift / scale). ---- */
+    int n_M = 0, n_align = 0;
+    double acc = 0.0;                                    /* lanes 0..4: A00, A01, A11, b0, b1 (pass 0); lane 0: var (pass 1) */
+    double shift = 0, scale = 0;
+    for (int pass = 0; pass < 2; ++pass) {
+        int carry_rank = -1;
+        if (pass == 1) acc = 0.0;
+        for (int k0 = 0; k0 < K; k0 += 64) {
+            const int k = k0 + lane;
+            abea_index_pair_t m; m.start = -1; m.stop = -1;
+            int rank = 0;
+            if (k < K) {
+                m = load_map_l2(map + k);
+                for (int j = 0; j < kmer_size; ++j) rank = (rank << 2) | (int)base_code(seq[k + j]);
+            }
+            const bool valid = m.start != -1;
+            const unsigned long long vm = __ballot(valid);
+            const unsigned long long lower = vm & ((1ull << lane) - 1ull);
+            const int src = lower ? 63 - __clzll(lower) : 0;
+            const int below = __shfl(rank, src, 64);      /* every lane takes part: the source lane may have lower == 0 */
+            const int prev_rank = lower ? below : carry_rank;
+            const bool isM = valid && (rank != prev_rank);
+            const unsigned long long mm = __ballot(isM);
+            const int cnt = __popcll(mm);
+            const int pos = __popcll(mm & ((1ull << lane) - 1ull));   /* this 'M' state's place among the block's */
+            if (isM) {
+                const abea_model_t mo = model[rank];
+                const double level_stdv = mo.level_stdv, level_mean = mo.level_mean, raw_event = evm[m.start];
+                if (pass == 0) {                          /* align.c:697-706 */
+                    const double inv_var = 1. / (level_stdv * level_stdv);
+                    const double mu = level_mean, e = raw_event;
+                    lds[pos * 5 + 0] = inv_var;
+                    lds[pos * 5 + 1] = mu * inv_var;
+                    lds[pos * 5 + 2] = mu * mu * inv_var;
+                    lds[pos * 5 + 3] = e * inv_var;
+                    lds[pos * 5 + 4] = mu * e * inv_var;
+                } else {                                  /* align.c:738-751 */
+                    const double yi = (raw_event - shift - scale * level_mean);
+                    lds[pos] = yi * yi / (level_stdv * level_stdv);
+                }
+            }
+            if (pass == 0) { n_M += cnt; n_align += valid ? (m.stop - m.start + 1) : 0; }
+            if (vm) carry_rank = __shfl(rank, 63 - __clzll(vm), 64);
+            __syncthreads();
+            /* the chains: lane t adds column t of the block's terms, in 'M'-state order; reads issued eight ahead */
+            const int col = pass == 0 ? lane : 0, stride = pass == 0 ? 5 : 1;
+            if (lane < (pass == 0 ? 5 : 1)) {
+                int i = 0;
+                for (; i + 8 <= cnt; i += 8) {
+                    const double v0 = lds[(i + 0) * stride + col], v1 = lds[(i + 1) * stride + col];
+                    const double v2 = lds[(i + 2) * stride + col], v3 = lds[(i + 3) * stride + col];
+                    const double v4 = lds[(i + 4) * stride + col], v5 = lds[(i + 5) * stride + col];
+                    const double v6 = lds[(i + 6) * stride + col], v7 = lds[(i + 7) * stride + col];
+                    acc += v0; acc += v1; acc += v2; acc += v3; acc += v4; acc += v5; acc += v6; acc += v7;
+                }
+                for (; i < cnt; ++i) acc += lds[i * stride + col];
+            }
+            __syncthreads();
+        }
+        if (pass == 0) {
+            if (n_M < fs.min_rescale) break;             /* align.c:688: not enough 'M' states, no recalibration */
+            const double A00 = __shfl(acc, 0, 64), A01 = __shfl(acc, 1, 64), A11 = __shfl(acc, 2, 64);
+            const double b0 = __shfl(acc, 3, 64), b1 = __shfl(acc, 4, 64);
+            const double A10 = A01;
+            const double div = A00 * A11 - A01 * A10;     /* align.c:721-723 */
+            shift = -(A01 * b1 - A11 * b0) / div;
+            scale = (A00 * b1 - A10 * b0) / div;
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) n_align += __shfl_xor(n_align, off, 64);
+    if (lane == 0) {
+        const bool calibrated = n_M >= fs.min_rescale;
+        int flag = 0;
+        float fvar = fs.sc_io[out_idx].var;
+        if (calibrated) {
+            double var = acc / n_M;                       /* align.c:752-753 */
+            var = sqrt(var);
+            abea_scalings_t o = fs.sc_io[out_idx];
+            o.shift = (float)shift; o.scale = (float)scale; o.var = (float)var;
+            fs.sc_io[out_idx] = o;
+            fvar = o.var;
+        }
+        if (!calibrated || fvar > 2.5) flag |= ABEA_FAILED_CALIBRATION;       /* f5c.c:776-782 */
+        else if (events_per_base > 5.0) flag |= ABEA_FAILED_QUALITY_CHK;      /* f5c.c:799-805 */
+        fs.flag_io[out_idx] |= flag;
+        fs.epb[out_idx] = events_per_base;
+        fs.nalign[out_idx] = n_align;
+    }
+}
+
+
 /* ================================================================ the fused alignment kernel
  * One wavefront = one read, from band 2 to the finished pair list:
  *   phase 1  band fill + adaptive band movement + online end-point scan      (VALU/DPP bound)
@@ -181,7 +333,8 @@ void abea_align_kernel(const abea_read_desc* __restrict__ descs,
                        uint4* __restrict__ trace_all, uint32_t* __restrict__ codes_all,
                        abea_pair_t* __restrict__ pairs_all, int32_t* __restrict__ n_pairs,
                        abea_read_diag* __restrict__ diag,
-                       unsigned long long* __restrict__ pair_cursor, int64_t* __restrict__ pair_off_out) {
+                       unsigned long long* __restrict__ pair_cursor, int64_t* __restrict__ pair_off_out,
+                       const abea_fused_scaling fs) {
     /* pairs_all == nullptr: the pair lists are not materialised on the device (the host entry expands them from the
      * walk codes).  pair_cursor != nullptr: pair lists are packed back to back in completion order (atomic bump
      * allocation of n entries per read, offset reported in pair_off_out[]) instead of at desc.pair_off. */
@@ -204,6 +357,7 @@ void abea_align_kernel(const abea_read_desc* __restrict__ descs,
     dg.max_gap = 0; dg.spanned = 0; dg.flags = 0; dg.pad = 0;
     if (n_groups == 0) {                               /* align_single guards (f5c.c:813-814) */
         if (lane == 0) { n_pairs[out_idx] = 0; dg.flags = ABEA_RF_SKIPPED; if (diag) diag[out_idx] = dg; }
+        if (fs.b2e) abea_fused_not_aligned(fs, out_idx, lane);
         return;
     }
     const int E = d->n_events, K = d->n_kmers;
@@ -467,6 +621,7 @@ void abea_align_kernel(const abea_read_desc* __restrict__ descs,
     /* ============================================================ phase 2: traceback walk */
     if (best == NINF) {                                  /* no in-band end cell, SURVEY §9-I */
         if (lane == 0) { n_pairs[out_idx] = 0; dg.flags = ABEA_RF_NO_END; if (diag) diag[out_idx] = dg; }
+        if (fs.b2e) abea_fused_not_aligned(fs, out_idx, lane);
         return;
     }
     uint32_t* codes = codes_all + d->code_off;
@@ -618,6 +773,15 @@ void abea_align_kernel(const abea_read_desc* __restrict__ descs,
             diag[out_idx] = dg;
         }
     }
+
+    /* ============================================================ phase 4 (optional): scaling_single for this read */
+    if (fs.b2e) {
+        if (fail) abea_fused_not_aligned(fs, out_idx, lane);
+        else {
+            __syncthreads();                             /* phase 3's pair stores are complete */
+            abea_scaling_single_wave(d, fs, lane, n, pairs, evm, reinterpret_cast<double*>(smem));
+        }
+    }
 }
 
 
@@ -633,207 +797,6 @@ void abea_copy_out_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst
     u32x4* d = reinterpret_cast<u32x4*>(dst);
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x)
         __builtin_nontemporal_store(s[i], d + i);
-}
-
-
-/* ================================================================ scaling_single on the device (row N1)
- * postalign (align.c:561-661) + recalibrate_model (align.c:666-773) + the QC flags of scaling_single
- * (f5c.c:736-807), run after abea_align_kernel while pairs/evm are still resident.  Two kernels:
- *   abea_scaling_kernel (one wavefront per read, parallel over pairs / k-mers)
- *     base_to_event_map: every k-mer owns one contiguous run of pairs; its first pair repeats the previous
- *       event iff it was reached by a skip (FROM_L), all later pairs of the run are new events.
- *     'M' states = first event of each k-mer that has events and whose rank differs from the previous such
- *       k-mer.  Each one becomes a 16-byte record {1/(stdv*stdv) fp64, level_mean, event mean} in k order.
- *   abea_recalib_kernel (one LANE per read)
- *     the five normal-equation sums and the variance sum are sequential fp64 chains in k order in the reference
- *     (align.c:703-716, 738-751) and their terms are full-mantissa doubles, so no re-association is exact: the chains
- *     stay sequential, but 64 reads run them side by side in one wavefront instead of one read serialising 64 lanes
- *     through LDS (round 2: a 50 kb read held a wave slot for milliseconds). */
-extern "C" __global__ __launch_bounds__(64)
-void abea_scaling_kernel(const abea_read_desc* __restrict__ descs, const char* __restrict__ reads,
-                         const abea_model_t* __restrict__ model, int kmer_size,
-                         const float* __restrict__ evm_all, const abea_pair_t* __restrict__ pairs_all,
-                         const int32_t* __restrict__ n_pairs, abea_index_pair_t* __restrict__ b2e_all,
-                         double* __restrict__ epb_out, int32_t* __restrict__ flag_io, int32_t* __restrict__ nalign_out,
-                         abea_mrec* __restrict__ mrec_all, int32_t* __restrict__ n_m_out) {
-    __builtin_amdgcn_s_setprio(2);                       /* short, and on its chunk's critical path */
-    const abea_read_desc* d = descs + blockIdx.x;
-    const int lane = threadIdx.x;
-    const int out_idx = d->out_idx;
-    const int n = n_pairs[out_idx];
-    if (d->n_groups == 0 || n <= 0) {                    /* f5c.c:786-794: could not align */
-        if (lane == 0) {
-            flag_io[out_idx] |= ABEA_FAILED_ALIGNMENT; epb_out[out_idx] = 0.0; nalign_out[out_idx] = 0;
-            n_m_out[blockIdx.x] = -1;
-        }
-        return;
-    }
-    const int K = d->n_kmers;
-    const abea_pair_t* __restrict__ pairs = pairs_all + d->pair_off;
-    abea_index_pair_t* map = b2e_all + d->kmer_off;
-    const float* __restrict__ evm = evm_all + d->evm_off;
-    const char* __restrict__ seq = reads + d->read_off;
-    abea_mrec* __restrict__ mrec = mrec_all + d->pad64;   /* record m of this read at mrec[64 * m] (interleaved, abea_device.h) */
-
-    /* ---- base_to_event_map (align.c:571-596) ---- */
-    for (int i = lane; i < n; i += 64) {
-        const abea_pair_t p = pairs[i];
-        abea_pair_t pm, pn; pm.ref_pos = pm.read_pos = -1; pn = pm;
-        if (i > 0) pm = pairs[i - 1];
-        if (i < n - 1) pn = pairs[i + 1];
-        const bool run_start = (i == 0) || (pm.ref_pos != p.ref_pos);
-        const bool run_end = (i == n - 1) || (pn.ref_pos != p.ref_pos);
-        const bool is_new = (i == 0) || (p.read_pos != pm.read_pos);
-        if (run_start) map[p.ref_pos].start = is_new ? p.read_pos : (!run_end ? pn.read_pos : -1);
-        if (run_end) map[p.ref_pos].stop = (!run_start || is_new) ? p.read_pos : -1;
-    }
-    const double events_per_base = (double)(pairs[n - 1].read_pos - pairs[0].read_pos) / K;   /* align.c:602 */
-    __syncthreads();
-
-    /* ---- the 'M' states in k order (hmm_state, align.c:637; counted at align.c:677-686) ---- */
-    int n_M = 0, n_align = 0, carry_rank = -1;
-    for (int k0 = 0; k0 < K; k0 += 64) {
-        const int k = k0 + lane;
-        abea_index_pair_t m; m.start = -1; m.stop = -1;
-        int rank = 0;
-        if (k < K) {
-            m = map[k];
-            for (int j = 0; j < kmer_size; ++j) rank = (rank << 2) | (int)base_code(seq[k + j]);
-        }
-        const bool valid = m.start != -1;
-        const unsigned long long vm = __ballot(valid);
-        const unsigned long long lower = vm & ((1ull << lane) - 1ull);
-        const int src = lower ? 63 - __clzll(lower) : 0;
-        const int below = __shfl(rank, src, 64);          /* every lane takes part: the source lane may have lower == 0 */
-        const int prev_rank = lower ? below : carry_rank;
-        const bool isM = valid && (rank != prev_rank);
-        const unsigned long long mm = __ballot(isM);
-        if (isM) {
-            const abea_model_t mo = model[rank];
-            abea_mrec r;
-            const double sd = mo.level_stdv;
-            r.sd2 = sd * sd;                                 /* exact: two 24-bit significands */
-            r.inv_var = 1. / r.sd2;                          /* align.c:697: the division is done here, in parallel */
-            r.mu = r.mu2 = mo.level_mean; r.e = r.e2 = evm[m.start];
-            mrec[(size_t)(n_M + __popcll(mm & ((1ull << lane) - 1ull))) * ABEA_MREC_STRIDE] = r;   /* compacted: record m = the m-th 'M' state */
-        }
-        n_M += __popcll(mm);
-        n_align += valid ? (m.stop - m.start + 1) : 0;
-        if (vm) carry_rank = __shfl(rank, 63 - __clzll(vm), 64);
-    }
-    for (int off = 32; off > 0; off >>= 1) n_align += __shfl_xor(n_align, off, 64);
-    if (lane == 0) {
-        epb_out[out_idx] = events_per_base;
-        nalign_out[out_idx] = n_align;
-        n_m_out[blockIdx.x] = n_M;
-    }
-}
-
-/* recalibrate_model's arithmetic (align.c:688-765) and scaling_single's flags (f5c.c:770-805): lane = read.  Reads of a
- * wavefront are neighbours in the launch order (longest first), so their chains have similar lengths.
- *
- * Round 4.  A step of either chain is ~60-100 cycles of arithmetic, an HBM round trip ~0.5-1 us under the load of the
- * alignment kernels; with one record per lane in flight (round 3) every one of a 50-kb read's 45 k steps waited for memory.
- * Hiding the latency needs ~40 steps = 40 KiB per wavefront in flight, and the wavefront must still fit beside three
- * alignment waves (122 VGPRs each, a SIMD's file holds four), so the ring cannot be registers.  Each pass streams its 16-byte
- * half of the records through a 32-step ring in LDS by LDS-DMA (global_load_lds_dwordx4: 64 lanes x 16 B = one 1-KiB
- * step per instruction, written at M0 + 16 * lane, no VGPR destination): slot (m & 31) is read with one ds_read_b128 and
- * at once re-issued for step m + 32.  The loads return in order, so "step m has landed" is vmcnt(31).  hipcc does not count
- * asm loads, hence the waits are written out (and its own waits can only over-wait: it has no VMEM in the loops).  The sums
- * themselves are unchanged: one lane adds its read's terms in k order, in fp64, the division by the compiler's IEEE
- * expansion. */
-#define ABEA_RECALIB_RING 32
-static __device__ __forceinline__ void recalib_issue(unsigned lds_dst, unsigned v_off, const void* step_base) {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(lds_dst), "v"(v_off), "s"(step_base) : "memory");
-}
-/* wait for the oldest step of the ring, read this lane's 16 bytes of it, and re-issue the slot for a later step */
-static __device__ __forceinline__ uint4 recalib_take(unsigned v_lds, unsigned lds_dst, unsigned v_off, const void* next_base) {
-    uint4 v;
-    asm volatile("s_waitcnt vmcnt(%5)\n\tds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)\n\t"
-                 "s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %4"
-                 : "=&v"(v) : "v"(v_lds), "s"(lds_dst), "v"(v_off), "s"(next_base), "n"(ABEA_RECALIB_RING - 1) : "memory");
-    return v;
-}
-
-extern "C" __global__ __launch_bounds__(64)
-void abea_recalib_kernel(const abea_read_desc* __restrict__ descs, int n_desc, const abea_mrec* __restrict__ mrec_all,
-                         const int32_t* __restrict__ n_m_in, abea_scalings_t* __restrict__ sc_io,
-                         const double* __restrict__ epb_in, int32_t* __restrict__ flag_io, int min_rescale) {
-    __shared__ __attribute__((aligned(1024))) uint4 ring[ABEA_RECALIB_RING * 64];
-    /* a handful of wavefronts with long serial chains, sharing their SIMDs with the fill loops of other chunks: they are
-     * the latency of their chunk, so they issue first */
-    __builtin_amdgcn_s_setprio(3);
-    const unsigned lane = threadIdx.x;
-    const int j = blockIdx.x * 64 + (int)lane;
-    const bool live = j < n_desc;
-    const int n_M = live ? n_m_in[j] : -1;               /* < 0: not aligned, flagged by abea_scaling_kernel */
-    const bool calibrated = n_M >= min_rescale;
-    const int nm = calibrated ? n_M : 0;                 /* steps this lane takes */
-    int nmax = nm;
-    for (int off = 32; off > 0; off >>= 1) nmax = max(nmax, __shfl_xor(nmax, off, 64));
-    nmax = uni(nmax);
-    /* the group's records: record m of lane l at grp[m * 64 + l] (lane 0 of a group always exists) */
-    const abea_mrec* grp = (const abea_mrec*)uni_p(mrec_all + descs[blockIdx.x * 64].pad64);
-    const unsigned ring_a = (unsigned)uni((int)(unsigned)(uintptr_t)ring);
-    const unsigned v_lds = ring_a + lane * 16u;
-    double shift = 0, scale = 0, var = 0;
-    if (nmax > 0) {
-        const int smax = nmax - 1;                       /* steps past the group's last re-load it (never consumed) */
-        double A00 = 0, A01 = 0, A11 = 0, b0 = 0, b1 = 0;
-        const unsigned off1 = lane * (unsigned)sizeof(abea_mrec);
-        for (int s = 0; s < ABEA_RECALIB_RING; ++s)
-            recalib_issue(ring_a + (unsigned)s * 1024u, off1, grp + (size_t)min(s, smax) * ABEA_MREC_STRIDE);
-        for (int m = 0; m < nmax; ++m) {
-            const unsigned slot = ((unsigned)m & (ABEA_RECALIB_RING - 1)) * 1024u;
-            const uint4 v = recalib_take(v_lds + slot, ring_a + slot, off1,
-                                         grp + (size_t)min(m + ABEA_RECALIB_RING, smax) * ABEA_MREC_STRIDE);
-            if (m < nm) {
-                const double inv_var = __hiloint2double((int)v.y, (int)v.x);   /* align.c:697-706, in this order */
-                const double mu = (double)__uint_as_float(v.z), e = (double)__uint_as_float(v.w);
-                A00 += inv_var;
-                A01 += mu * inv_var;
-                A11 += mu * mu * inv_var;
-                b0 += e * inv_var;
-                b1 += mu * e * inv_var;
-            }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   /* the ring is idle before the second pass refills it */
-        const double A10 = A01;
-        const double div = A00 * A11 - A01 * A10;
-        shift = -(A01 * b1 - A11 * b0) / div;
-        scale = (A00 * b1 - A10 * b0) / div;
-        const unsigned off2 = off1 + 16u;                /* second half of the record: {stdv * stdv, level_mean, event mean} */
-        for (int s = 0; s < ABEA_RECALIB_RING; ++s)
-            recalib_issue(ring_a + (unsigned)s * 1024u, off2, grp + (size_t)min(s, smax) * ABEA_MREC_STRIDE);
-        for (int m = 0; m < nmax; ++m) {
-            const unsigned slot = ((unsigned)m & (ABEA_RECALIB_RING - 1)) * 1024u;
-            const uint4 v = recalib_take(v_lds + slot, ring_a + slot, off2,
-                                         grp + (size_t)min(m + ABEA_RECALIB_RING, smax) * ABEA_MREC_STRIDE);
-            if (m < nm) {                                                        /* align.c:738-751 */
-                const double sd2 = __hiloint2double((int)v.y, (int)v.x);         /* level_stdv * level_stdv */
-                const double mu = (double)__uint_as_float(v.z), e = (double)__uint_as_float(v.w);
-                const double yi = (e - shift - scale * mu);
-                var += yi * yi / sd2;
-            }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        var /= n_M;
-        var = sqrt(var);
-    }
-    if (!live || n_M < 0) return;
-    const int out_idx = descs[j].out_idx;
-    const double events_per_base = epb_in[out_idx];
-    int flag = 0;
-    float fvar = sc_io[out_idx].var;
-    if (calibrated) {
-        abea_scalings_t o = sc_io[out_idx];
-        o.shift = (float)shift; o.scale = (float)scale; o.var = (float)var;
-        sc_io[out_idx] = o;
-        fvar = o.var;
-    }
-    if (!calibrated || fvar > 2.5) flag |= ABEA_FAILED_CALIBRATION;       /* f5c.c:776-782 */
-    else if (events_per_base > 5.0) flag |= ABEA_FAILED_QUALITY_CHK;      /* f5c.c:799-805 */
-    flag_io[out_idx] |= flag;
 }
 
 

@@ -310,7 +310,9 @@ int abea_hmm_score_batch_device(abea_ctx* ctx, const abea_hmm_job_t* jobs, int32
 /* ---- timing / accounting of the last batch (core_t timing fields, src/f5c.h:457-466) ---- */
 typedef struct {
     double pre_ms, fill_ms, trace_ms;     /* HIP-event kernel times on the library's stream, summed over sub-batches
-                                             (fill = fused fill+traceback kernel, trace = optional scaling kernel) */
+                                             (fill = the fused fill + traceback kernel, which since round 4 also runs
+                                             scaling_single for its read when that is requested; trace_ms = 0, kept for
+                                             the layout) */
     double h2d_ms, d2h_ms, host_ms;       /* host batch only */
     double event_ms;                      /* abea_detect_events_device: kernel time of the last call */
     double hmm_ms;                        /* abea_hmm_score_batch_host: kernel time of the last call */
@@ -327,10 +329,6 @@ typedef struct {
     double wait_ms;                       /* time the calling thread spent waiting for the GPU */
     uint64_t h2d_bytes, d2h_bytes;        /* PCIe traffic of the call */
     int32_t n_devices, host_threads;
-    /* host batch with scaling_single fused: trace_ms split at the boundary between the two kernels.  Each part runs from the
-     * end of the previous kernel of the chunk to its own end, so it includes the time the kernel's workgroups waited for wave
-     * slots that other chunks' alignment kernels held. */
-    double scaling_ms, recalib_ms;
 } abea_stats;
 int abea_get_stats(abea_ctx* ctx, abea_stats* out);
 /* Multi-device context: the share of the last host batch that ran on device_ids[device]; abea_get_stats() gives the
