@@ -10,6 +10,9 @@ from f5c_amd import abea, synth, load_model_f32
 args = [a for a in sys.argv[1:] if "=" in a and not a.startswith("--")]
 cfg_name = sys.argv[sys.argv.index("--config") + 1] if "--config" in sys.argv else "r9_10k_8kb"
 launches = int(sys.argv[sys.argv.index("--launches") + 1]) if "--launches" in sys.argv else 4
+# --scaling-launches N: after the plain launches of a build whose name starts with "r04" (the in-kernel scaling_single of round 4),
+# N more device-resident launches with scaling_single fused: what the last phase of abea_align_kernel costs on the GPU alone
+scal_launches = int(sys.argv[sys.argv.index("--scaling-launches") + 1]) if "--scaling-launches" in sys.argv else 0
 cfg = dict(synth.CONFIGS[cfg_name])
 if "--reads" in sys.argv:
     cfg["n_reads"] = int(sys.argv[sys.argv.index("--reads") + 1])
@@ -35,7 +38,16 @@ for a in args:
     pairs, n_pairs, dg = ctx.download(d)
     out = dict(n_pairs=n_pairs.copy(), sum_emission=dg["sum_emission"].copy(), max_score=dg["max_score"].copy())
     out["pairs_sha"] = hashlib.sha256(hash_pair_lists(pairs, pair_ptr, n_pairs).tobytes()).hexdigest()   # only defined pairs
-    del ctx, pairs
+    del pairs
+    if scal_launches and name.startswith("r04"):
+        sm = []
+        for _ in range(scal_launches):
+            ctx.align_db_device(d, want_diag=False, scaling=True); sm.append(ctx.stats()["fill_ms"])
+        cal = int(((d["read_stat_flag"].cpu().numpy()[:len(n_pairs)] & 1) == 0).sum())
+        print(f"{name} with scaling_single fused, kernel ms " + " ".join(f"{x:.3f}" for x in sm) + f" | {cal} reads calibrated", flush=True)
+        for key in ("b2e", "scalings_io", "events_per_base", "read_stat_flag", "n_event_alignment"):
+            d.pop(key, None)
+    del ctx
     line = f"{name} kernel ms " + " ".join(f"{x:.3f}" for x in ms) + f" | min {min(ms[1:]):.3f}"
     if ref is None:
         ref = out

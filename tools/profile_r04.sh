@@ -41,7 +41,7 @@ if [ "$STAGE" = "n2" ]; then
   pass n2 240 --stats -- python tools/n2_profile.py 2048
 fi
 if [ "$STAGE" = "ab100" ]; then
-  timeout -k 10 560 python tools/ab_quick.py r03=build/libabea_r03.so r04=f5c_amd/libabea_hip.so r03b=build/libabea_r03.so --config r9_100k_mixed --launches 11 > $O/ab_100k.log 2> $O/ab_100k.err
+  timeout -k 10 600 python tools/ab_quick.py r03=build/libabea_r03.so r04=f5c_amd/libabea_hip.so r03b=build/libabea_r03.so --config r9_100k_mixed --launches 11 --scaling-launches 4 > $O/ab_100k.log 2> $O/ab_100k.err
   echo "ab100 rc=$?" >> $O/steps.txt; cat $O/ab_100k.log
 fi
 find $O -name "*kernel_trace.csv" -size +20M -delete
