@@ -37,7 +37,7 @@ typedef struct __attribute__((aligned(16))) {
 
 /* scaling_single() fused behind the alignment, inside abea_align_kernel (round 4): the wavefront that aligned a read also runs
  * postalign + recalibrate_model + the FAILED_* flags for it (src/f5c.c:736-807, src/align.c:561-773).  Passed by value; b2e ==
- * NULL switches the stage off.  The pair lists must be materialised (pairs_all != NULL): the stage reads them back. */
+ * NULL switches the stage off.  The pair lists need not be materialised for it (pairs_all may be NULL). */
 typedef struct {
     const char* reads;                  /* sequences of the launch (desc.read_off) */
     const abea_model_t* model;          /* k-mer model on the device */

@@ -726,7 +726,7 @@ static int host_run(abea_ctx* c, const abea_host_batch* H, const int32_t* mine, 
     S.want_pairs = H->pairs != nullptr;
     S.device_pairs = S.want_pairs && S.opt.device_pairs && !S.scaling;
     const bool scaling = S.scaling;
-    const bool pairs_on_device = S.device_pairs || scaling;       /* the scaling kernel reads the pair lists in HBM */
+    const bool pairs_on_device = S.device_pairs;                  /* fused scaling_single builds its map from the walk, not from pair lists */
 
     /* ---- worker pool and slots (persistent across calls) ---- */
     S.st.host_threads = lane.pool->threads();

@@ -147,7 +147,8 @@ static __device__ __forceinline__ void abea_cell(float x, float gpm, float ck, d
  * chains of the recalibration took 4-15 ms per chunk (rocprofv3 timeline, profiles/r04/e_fused_20k_kernel_trace.csv).
  * Now it is the tail of abea_align_kernel: no launch, no queueing, no 'M'-state records through HBM.
  *   base_to_event_map: every k-mer owns one contiguous run of pairs; its first pair repeats the previous event iff it was
- *     reached by a skip (FROM_L), all later pairs of the run are new events.  Parallel over pairs.
+ *     reached by a skip (FROM_L), all later pairs of the run are new events.  Written by phase 3 of the kernel while it expands
+ *     the walk (two codes per pair decide), so the pair lists themselves need not exist in HBM.
  *   'M' states = first event of each k-mer that has events and whose rank differs from the previous such k-mer
  *     (hmm_state, align.c:637; counted at align.c:677-686), found 64 k-mers at a time with ballots.
  *   recalibrate_model's five normal-equation sums and its variance sum are sequential fp64 chains in k order whose terms are
@@ -155,12 +156,7 @@ static __device__ __forceinline__ void abea_cell(float x, float gpm, float ck, d
  *     lanes compute them in parallel (the fp64 division included), park them in LDS in 'M'-state order, and then lanes 0..4
  *     (one per sum) add their column in order — a step of the chain is one LDS read (pipelined eight deep) and one v_add_f64,
  *     not a trip to HBM.  Same operations, same order, same bits as align.c:688-753. */
-static __device__ __forceinline__ abea_pair_t load_pair_l2(const abea_pair_t* p) {
-    /* written by this wavefront a moment ago: read past the CU's L1, which may hold a neighbour's stale copy of a shared line */
-    const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    abea_pair_t r; r.ref_pos = (int32_t)(uint32_t)v; r.read_pos = (int32_t)(uint32_t)(v >> 32);
-    return r;
-}
+/* written by this wavefront a moment ago: read past the CU's L1, which may hold a neighbour's stale copy of a shared line */
 static __device__ __forceinline__ abea_index_pair_t load_map_l2(const abea_index_pair_t* p) {
     const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     abea_index_pair_t r; r.start = (int32_t)(uint32_t)v; r.stop = (int32_t)(uint32_t)(v >> 32);
@@ -173,32 +169,17 @@ static __device__ void abea_fused_not_aligned(const abea_fused_scaling& fs, int 
     }
 }
 
-/* n = the read's pair count after QC (> 0), pairs = its list in HBM, lds = 64 x 5 doubles of wave-private LDS */
-static __device__ void abea_scaling_single_wave(const abea_read_desc* d, const abea_fused_scaling& fs, int lane, int n,
-                                                const abea_pair_t* __restrict__ pairs, const float* __restrict__ evm,
-                                                double* lds) {
+/* The map has been written by phase 3 of the alignment kernel; event_span = read_pos of the list's last pair minus that of its
+ * first (align.c:602); lds = 64 x 5 doubles of wave-private LDS */
+static __device__ void abea_scaling_single_wave(const abea_read_desc* d, const abea_fused_scaling& fs, int lane, int event_span,
+                                                const float* __restrict__ evm, double* lds) {
     const int out_idx = d->out_idx;
     const int K = d->n_kmers;
     const int kmer_size = fs.kmer_size;
-    abea_index_pair_t* map = fs.b2e + d->kmer_off;
+    const abea_index_pair_t* map = fs.b2e + d->kmer_off;
     const char* __restrict__ seq = fs.reads + d->read_off;
     const abea_model_t* __restrict__ model = fs.model;
-
-    /* ---- base_to_event_map (align.c:571-596) ---- */
-    for (int i = lane; i < n; i += 64) {
-        const abea_pair_t p = load_pair_l2(pairs + i);
-        abea_pair_t pm, pn; pm.ref_pos = pm.read_pos = -1; pn = pm;
-        if (i > 0) pm = load_pair_l2(pairs + i - 1);
-        if (i < n - 1) pn = load_pair_l2(pairs + i + 1);
-        const bool run_start = (i == 0) || (pm.ref_pos != p.ref_pos);
-        const bool run_end = (i == n - 1) || (pn.ref_pos != p.ref_pos);
-        const bool is_new = (i == 0) || (p.read_pos != pm.read_pos);
-        if (run_start) map[p.ref_pos].start = is_new ? p.read_pos : (!run_end ? pn.read_pos : -1);
-        if (run_end) map[p.ref_pos].stop = (!run_start || is_new) ? p.read_pos : -1;
-    }
-    const abea_pair_t p_first = load_pair_l2(pairs), p_last = load_pair_l2(pairs + n - 1);
-    const double events_per_base = (double)(p_last.read_pos - p_first.read_pos) / K;   /* align.c:602 */
-    __syncthreads();                                     /* the map is complete (and in L2) before it is swept */
+    const double events_per_base = (double)event_span / K;   /* align.c:602 */
 
     /* ---- one sweep over the k-mers in k order, 64 at a time: the 'M' states and, in their order, term(s) of a sum.
      *      PASS 0: the five normal-equation sums + the counts; PASS 1: the variance sum (needs shift / scale). ---- */
@@ -327,7 +308,8 @@ static __device__ __forceinline__ int wave_excl_scan(int v, int lane, int& total
     return s - v;
 }
 
-extern "C" __global__ __launch_bounds__(64)
+/* four waves per SIMD: 128 VGPRs, of which the fill statement's fixed window takes v64..v127 */
+extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
 void abea_align_kernel(const abea_read_desc* __restrict__ descs,
                        const float* __restrict__ evm_all, const abea_kpar_t* __restrict__ kpar_all,
                        uint4* __restrict__ trace_all, uint32_t* __restrict__ codes_all,
@@ -718,10 +700,20 @@ void abea_align_kernel(const abea_read_desc* __restrict__ descs,
     }
     double sum = 0.0;
     int base_k = K - 1, base_e = best_e;
+    /* fused scaling_single: base_to_event_map (postalign, align.c:571-596) is written from here, straight from the walk — the pair
+     * lists need not exist in HBM for it.  In walk order (step t = 0 at the end cell) code[t] is the move from pair t to pair t + 1,
+     * i.e. to its PREDECESSOR in the list: 1 = same k-mer ("up"), 2 = same event ("left").  A pair opens its k-mer's run of the list
+     * iff code[t] != 1 (or it is the last step), closes it iff code[t-1] != 1 (or t = 0), and is a new event iff code[t] != 2:
+     * the rules of the pair-list formulation with prev / next replaced by the two codes (checked on the CPU against postalign). */
+    abea_index_pair_t* const map = fs.b2e ? fs.b2e + d->kmer_off : nullptr;
+    uint32_t carry_code = 0;                             /* code 15 of lane 63 of the previous 1024-step stretch */
+    int e_first = -1;                                    /* read_pos of the list's first pair (walk step n - 1) */
     for (int c0 = 0; c0 < n; c0 += 1024) {
         const int i0 = c0 + 16 * lane;
         const int cnt = max(0, min(16, n - i0));
         const uint32_t w = (cnt > 0) ? codes[(c0 >> 4) + lane] : 0u;
+        uint32_t prev_top = (uint32_t)__shfl_up((int)(w >> 30), 1, 64);   /* code[t-1] of this lane's first step */
+        if (lane == 0) prev_top = carry_code;
         int dk = 0, de = 0;
         #pragma unroll
         for (int j = 0; j < 16; ++j) {
@@ -742,6 +734,17 @@ void abea_align_kernel(const abea_read_desc* __restrict__ descs,
                 const float a = (float)((double)dx * kp.istd);
                 lp = __fadd_rn(kp.ck, __fmul_rn(__fmul_rn(-0.5f, a), a));
                 const uint32_t cd = (w >> (2 * j)) & 3u;
+                if (map) {
+                    const int t = i0 + j;
+                    const uint32_t cprev = j ? (w >> (2 * (j - 1))) & 3u : prev_top;
+                    const bool run_start = (t == n - 1) || cd != 1u;
+                    const bool run_end = (t == 0) || cprev != 1u;
+                    const bool is_new = (t == n - 1) || cd != 2u;
+                    const int next_e = ee + ((t > 0 && cprev != 2u) ? 1 : 0);        /* read_pos of the successor in the list */
+                    if (run_start) map[kk].start = is_new ? ee : (!run_end ? next_e : -1);
+                    if (run_end) map[kk].stop = (!run_start || is_new) ? ee : -1;
+                    if (t == n - 1) e_first = ee;
+                }
                 kk -= (cd != 1u); ee -= (cd != 2u);
             }
             lp_s[j * 64 + lane] = lp;                 /* [j][lane]: conflict-free stores */
@@ -752,6 +755,7 @@ void abea_align_kernel(const abea_read_desc* __restrict__ descs,
         for (int i = 0; i < m; ++i) sum += (double)lp_s[(i & 15) * 64 + (i >> 4)];   /* uniform, strictly in walk order */
         __syncthreads();
         base_k -= tk; base_e -= te;
+        carry_code = (uint32_t)__shfl((int)(w >> 30), 63, 64);
     }
 
     /* ---- QC (align.c:526-543) ---- */
@@ -776,10 +780,13 @@ void abea_align_kernel(const abea_read_desc* __restrict__ descs,
 
     /* ============================================================ phase 4 (optional): scaling_single for this read */
     if (fs.b2e) {
-        if (fail) abea_fused_not_aligned(fs, out_idx, lane);
-        else {
-            __syncthreads();                             /* phase 3's pair stores are complete */
-            abea_scaling_single_wave(d, fs, lane, n, pairs, evm, reinterpret_cast<double*>(smem));
+        if (fail) {                                      /* f5c.c:786-794; the map of a read that failed QC stays {-1, -1} */
+            for (int kq = lane; kq < K; kq += 64) { abea_index_pair_t z; z.start = -1; z.stop = -1; map[kq] = z; }
+            abea_fused_not_aligned(fs, out_idx, lane);
+        } else {
+            for (int off = 32; off > 0; off >>= 1) e_first = max(e_first, __shfl_xor(e_first, off, 64));   /* one lane had it */
+            __syncthreads();                             /* phase 3's map stores are complete (and in L2) before the sweeps */
+            abea_scaling_single_wave(d, fs, lane, best_e - e_first, evm, reinterpret_cast<double*>(smem));
         }
     }
 }
