@@ -18,7 +18,7 @@ EXPORTS = ["abea_init", "abea_init_multi", "abea_device_count", "abea_free", "ab
            "abea_device_info", "abea_selftest", "abea_rsq_format", "abea_lpt_split", "abea_hmm_score_batch_host", "abea_expand_walk_codes", "abea_expand_walk_codes_to_map",
            "abea_host_plan_chunks", "abea_host_plan_threads", "abea_set_inflight", "abea_align_batch_host_submit",
            "abea_align_batch_host_wait", "abea_events_batch_host", "abea_process_batch_host", "abea_rsq_format_batch",
-           "abea_hmm_score_batch_device"]
+           "abea_hmm_score_batch_device", "abea_expand_kmer_counts_to_map"]
 SHIM_EXPORTS = ["abea_f5c_init", "abea_f5c_align", "abea_f5c_align_scale", "abea_f5c_free", "abea_f5c_align_submit",
                 "abea_f5c_align_wait", "abea_f5c_event_db", "abea_f5c_process"]      # include/abea_f5c_shim.h
 

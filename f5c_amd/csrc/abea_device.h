@@ -46,6 +46,8 @@ typedef struct {
     double* epb;                        /* [out_idx] events_per_base */
     int32_t* flag_io;                   /* [out_idx] FAILED_* bits OR-ed in */
     int32_t* nalign;                    /* [out_idx] n_event_alignment */
+    uint8_t* kcnt;                      /* optional: events of every k-mer's map entry (stop - start + 1, 0 = {-1,-1}, 255 = more),
+                                           at kcnt[desc.kmer_off + k]: the form in which the host entry takes the map over PCIe */
     int32_t kmer_size, min_rescale;
 } abea_fused_scaling;
 

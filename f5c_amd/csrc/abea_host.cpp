@@ -264,7 +264,7 @@ struct abea_host_slot {
     std::vector<int32_t> rd;                            /* caller index of descriptor j */
     bool scaling = false, device_pairs = false, staged = false;
     size_t o_np = 0, o_diag = 0, o_codes = 0, o_poff = 0, o_cursor = 0, o_pairs = 0;      /* offsets in `dn` */
-    size_t o_sc = 0, o_epb = 0, o_flag = 0, o_nal = 0;
+    size_t o_sc = 0, o_epb = 0, o_flag = 0, o_nal = 0, o_cnt = 0;
     abea_pair_t* d_pairs = nullptr;                     /* device-pairs mode: compacted lists to copy at stage A */
     size_t pair_cap = 0;
 };
@@ -471,6 +471,33 @@ static void expand_codes_to_map(const uint32_t* codes, int32_t n, int32_t k, int
     _mm_sfence();
 }
 
+/* The same map from the per-k-mer event counts the fused scaling_single phase leaves (abea_fused_scaling.kcnt): the entries of
+ * base_to_event_map tile the events of the path in k order — every event is NEW for exactly one k-mer (postalign, align.c:571-596)
+ * and a k-mer's entry is {first, last} new event of its run — so entry k is the `count[k]` events ending where entry k + 1's
+ * begin, the last non-empty one ending at the alignment's end event.  Two adds and a store per k-mer (the walk needs a tzcnt
+ * chain with a serial dependency: 142 ms per 100 k reads against 110 ms for the pair lists; this: see DESIGN.md §6).  Returns false
+ * at a count of 255 ("255 or more"): the caller rebuilds that read's map from the walk. */
+static bool expand_counts_to_map(const uint8_t* count, int32_t K, int32_t end_event, abea_index_pair_t* map) {
+    long long* m64 = reinterpret_cast<long long*>(map);
+    int32_t cur = end_event;
+    for (int32_t k = K - 1; k >= 0; --k) {
+        const int32_t c = count[k];
+        if (c == 255) return false;
+        const int32_t start = c ? cur - c + 1 : -1, stop = c ? cur : -1;
+        _mm_stream_si64(m64 + k, (long long)(((uint64_t)(uint32_t)stop << 32) | (uint32_t)start));
+        cur -= c;
+    }
+    _mm_sfence();
+    return true;
+}
+
+/* host-only entry over the same routine (unit tests); returns ABEA_EINVAL for a table that holds the escape value */
+extern "C" int abea_expand_kmer_counts_to_map(const uint8_t* count, int32_t n_kmers, int32_t end_event, abea_index_pair_t* map) {
+    if (n_kmers < 1 || !count || !map) return abea_fail(ABEA_EINVAL, "abea_expand_kmer_counts_to_map: bad argument");
+    if (!expand_counts_to_map(count, n_kmers, end_event, map)) return abea_fail(ABEA_EINVAL, "a k-mer holds 255 or more events: use the walk");
+    return ABEA_OK;
+}
+
 extern "C" int abea_expand_walk_codes_to_map(const uint32_t* codes, int32_t n_steps, int32_t last_kmer, int32_t end_event,
                                              abea_index_pair_t* map) {
     if (n_steps < 1 || !codes || !map || last_kmer < 0) return abea_fail(ABEA_EINVAL, "abea_expand_walk_codes_to_map: bad argument");
@@ -514,7 +541,7 @@ static size_t chunk_io_bytes(const plan_read& r, bool pairs_on_device, bool scal
     size_t b = align_up((size_t)r.L + 1, 16) + 4 + sizeof(abea_read_diag) + 8;
     if (pairs_on_device) b += ((size_t)r.E + (size_t)r.L) * sizeof(abea_pair_t);
     /* map (device scratch) + per-read scalars */
-    if (scaling) b += (size_t)r.K * sizeof(abea_index_pair_t) + sizeof(abea_scalings_t) + 8 + 4 + 4 + 4;
+    if (scaling) b += (size_t)r.K * (sizeof(abea_index_pair_t) + 1) + sizeof(abea_scalings_t) + 8 + 4 + 4 + 4;   /* + one count byte per k-mer */
     return b + 64;
 }
 
@@ -641,6 +668,7 @@ static int slot_retire(host_run_state& S, abea_host_slot& sl) {
     const double* epb = (const double*)(sl.dn + sl.o_epb);
     const int32_t* flag = (const int32_t*)(sl.dn + sl.o_flag);
     const int32_t* nal = (const int32_t*)(sl.dn + sl.o_nal);
+    const uint8_t* kcnt = (const uint8_t*)(sl.dn + sl.o_cnt);
     t0 = abea_now_ms();
     const bool want_pairs = S.want_pairs, dev_pairs = sl.device_pairs, scaling = sl.scaling;
     S.lane->pool->run(sl.m, 1, [&](int64_t lo, int64_t hi) {
@@ -654,7 +682,10 @@ static int slot_retire(host_run_state& S, abea_host_slot& sl) {
                 else expand_codes(codes + descs[j].code_off, np, descs[j].n_kmers - 1, diag[j].best_event, H->pairs[i]);
             }
             if (scaling) {
-                if (np > 0 && H->base_to_event_map[i])        /* the map is expanded from the walk, like the pairs: 0.4 B per event on the wire */
+                /* the map comes down as one byte per k-mer (0.5 B per event on the wire) and is rebuilt with two adds per entry;
+                 * a read with a k-mer of 255+ events falls back to the walk (0.4 B per event, which comes down anyway) */
+                if (np > 0 && H->base_to_event_map[i] &&
+                    !expand_counts_to_map(kcnt + descs[j].kmer_off, descs[j].n_kmers, diag[j].best_event, H->base_to_event_map[i]))
                     expand_codes_to_map(codes + descs[j].code_off, np, descs[j].n_kmers - 1, diag[j].best_event, H->base_to_event_map[i]);
                 if (H->scalings_out) H->scalings_out[i] = sc[j];
                 if (H->events_per_base) H->events_per_base[i] = epb[j];
@@ -850,6 +881,7 @@ static int host_run(abea_ctx* c, const abea_host_batch* H, const int32_t* mine, 
         sl.o_epb = o;     if (scaling) o = align_up(o + (size_t)m * 8, 256);
         sl.o_flag = o;    if (scaling) o = align_up(o + (size_t)m * 4, 256);
         sl.o_nal = o;     if (scaling) o = align_up(o + (size_t)m * 4, 256);
+        sl.o_cnt = o;     if (scaling) o = align_up(o + n_kmer, 256);   /* events per k-mer, one byte each: the map as it crosses PCIe */
         const size_t dn_copy = o;                         /* one D2H copy of [0, dn_copy) */
         sl.o_pairs = o;   if (S.device_pairs) o = align_up(o + n_pair * sizeof(abea_pair_t), 256);
         if ((rc = ensure_pinned((void**)&sl.dn, &sl.dn_cap, o))) return rc;
@@ -934,6 +966,7 @@ static int host_run(abea_ctx* c, const abea_host_batch* H, const int32_t* mine, 
             fs.reads = d_reads; fs.model = c->d_model; fs.b2e = d_b2e;
             fs.sc_io = (abea_scalings_t*)(d_dn + sl.o_sc); fs.epb = (double*)(d_dn + sl.o_epb);
             fs.flag_io = (int32_t*)(d_dn + sl.o_flag); fs.nalign = (int32_t*)(d_dn + sl.o_nal);
+            fs.kcnt = (uint8_t*)(d_dn + sl.o_cnt);
             fs.kmer_size = (int32_t)c->k; fs.min_rescale = min_rescale;
         }
         hipLaunchKernelGGL(abea_align_kernel, dim3((unsigned)m), dim3(64), 0, sl.stream,

@@ -198,6 +198,11 @@ static __device__ void abea_scaling_single_wave(const abea_read_desc* d, const a
                 for (int j = 0; j < kmer_size; ++j) rank = (rank << 2) | (int)base_code(seq[k + j]);
             }
             const bool valid = m.start != -1;
+            /* the map's entries tile the events of the path in k order (every event is new for exactly one k-mer), so the number
+             * of events per k-mer IS the map: one byte per k-mer for the host entry instead of eight (255 = "255 or more": the
+             * host then rebuilds that read's map from the walk) */
+            if (pass == 0 && fs.kcnt && k < K)
+                fs.kcnt[d->kmer_off + k] = valid ? (uint8_t)min(m.stop - m.start + 1, 255) : (uint8_t)0;
             const unsigned long long vm = __ballot(valid);
             const unsigned long long lower = vm & ((1ull << lane) - 1ull);
             const int src = lower ? 63 - __clzll(lower) : 0;

@@ -346,6 +346,11 @@ int abea_expand_walk_codes(const uint32_t* codes, int32_t n_steps, int32_t last_
  * what the host entry does when scaling_single is fused — the map never crosses PCIe either.  Host-only. */
 int abea_expand_walk_codes_to_map(const uint32_t* codes, int32_t n_steps, int32_t last_kmer, int32_t end_event,
                                   abea_index_pair_t* map);
+/* And from the form in which the fused scaling_single phase hands the map to the host entry: the number of events of every
+ * k-mer's entry (stop - start + 1; 0 = {-1, -1}).  The entries tile the events of the path in k order, the last non-empty one
+ * ending at end_event, so the counts determine the map.  A count of 255 means "255 or more" and is refused here (the host entry
+ * rebuilds such a read's map from the walk).  Host-only. */
+int abea_expand_kmer_counts_to_map(const uint8_t* count, int32_t n_kmers, int32_t end_event, abea_index_pair_t* map);
 /* The chunk plan abea_align_batch_host() uses for a batch on an arena of arena_bytes (host-only; pairs returned, no
  * fused scaling): chunk_of[i] = launch-order number of the chunk read i goes into, -1 for reads skipped by the
  * align_single guards (src/f5c.c:813-814).  Reads go longest first; a chunk holds >= 2048 reads and >= 48 M events (the

@@ -482,3 +482,39 @@ def test_bench_under_torchrun_world_size_1_runs_rccl(tmp_path):
     vr = j["roofline"]["valu_roofline"]                          # 1500 reads fill a third of the wave slots: far below the ceiling
     assert vr["class_floor"]["right_move_bands"] > 0 and vr["measured_ms"] > 0
     assert 0.0 < vr["class_floor"]["frac"] < 1.0 and vr["frac"] == vr["class_floor"]["frac"]
+
+
+def test_kmer_count_expansion_matches_postalign(orc, r9):
+    """abea_expand_kmer_counts_to_map (what the host entry's un-flatten does with the one-byte-per-k-mer form in which the fused
+    scaling_single phase sends base_to_event_map over PCIe): the entries of the map tile the path's events in k order, so the
+    event count of every entry determines the map.  Against the oracle's postalign on aligned reads, plus the escape value."""
+    import ctypes
+    from f5c_amd import abea, synth
+    k, model = r9
+    lib = abea.load_library()
+    lib.abea_expand_kmer_counts_to_map.restype = ctypes.c_int
+    lib.abea_expand_kmer_counts_to_map.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]
+    batch = synth.make_batch(40, model, k, seed=812, law=1100, bad_frac=0.0)
+    n_ok = 0
+    for i in range(40):
+        s, L = int(batch["read_ptr"][i]), int(batch["read_len"][i])
+        es, E = int(batch["event_ptr"][i]), int(batch["n_events"][i])
+        seq, ev = batch["reads"][s:s + L].tobytes(), batch["events"][es:es + E]
+        if i % 5 == 0:                                               # long stays: k-mers with many events
+            ev = np.concatenate([ev[:50], np.repeat(ev[50:51], 40), ev[50:]])
+        sc = batch["scalings"][i]
+        pairs, d = orc.align(seq, ev, model, k, sc["scale"], sc["shift"])
+        if len(pairs) == 0:
+            continue
+        m = orc.scaling_single(pairs, seq, ev, model, k, sc["scale"], sc["shift"])["base_to_event_map"]
+        K = L - k + 1
+        cnt = np.where(m["start"] >= 0, m["stop"] - m["start"] + 1, 0)
+        assert cnt.max() < 255 and cnt.sum() == pairs["read_pos"][-1] - pairs["read_pos"][0] + 1     # the entries tile the events
+        c8 = cnt.astype(np.uint8)
+        out = np.zeros((K, 2), dtype=np.int32)
+        assert lib.abea_expand_kmer_counts_to_map(c8.ctypes.data, K, int(d["best_event"]), out.ctypes.data) == 0
+        assert (out[:, 0] == m["start"]).all() and (out[:, 1] == m["stop"]).all()
+        c8[K // 2] = 255                                             # "255 or more": refused, the caller falls back to the walk
+        assert lib.abea_expand_kmer_counts_to_map(c8.ctypes.data, K, int(d["best_event"]), out.ctypes.data) != 0
+        n_ok += 1
+    assert n_ok >= 30
