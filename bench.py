@@ -375,7 +375,7 @@ def fused_scaling(ctx, batch, view):
                             "no separate scaling kernels are launched, so their sum is 0 by construction",
             "pcie_bytes_per_step": {"h2d": int(st["h2d_bytes"]), "d2h": int(st["d2h_bytes"])},
             "n_pairs_equal_alignment_only": same, "reads_calibrated": cal,
-            "note": "pairs = NULL; the walk (2 bit/step) crosses PCIe and the host expands it into base_to_event_map"}
+            "note": "pairs = NULL; base_to_event_map crosses PCIe as one event-count byte per k-mer and is rebuilt by the host workers"}
 
 
 def pmc_traffic(config, sum_events, launches):

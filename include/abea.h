@@ -99,10 +99,13 @@ typedef struct {
                                               may be NULL when base_to_event_map is given (pair lists stay on the device) */
     int32_t* n_pairs;                      /* db->n_event_align_pairs[i] */
     abea_read_diag* diag;                  /* optional [n_reads], may be NULL */
-    /* ---- optional: scaling_db() fused behind the alignment (src/f5c.c:736-807 scaling_single = postalign +
+    /* ---- optional: scaling_db() fused with the alignment (src/f5c.c:736-807 scaling_single = postalign +
      *      recalibrate_model, src/align.c:561-773; row N1).  The pair lists have no other consumer in process_db
-     *      (src/f5c.c:907-960: align_db, then pthread_db(scaling_single), then meth_single reads only base_to_event_map / scalings / events_per_base).  What crosses PCIe is still the 2-bit walk (0.4 B per event) plus 36 B of scalars per read: the host workers expand the walk into base_to_event_map (and into the pair lists when pairs != NULL), the device runs the recalibration.
-     *      All NULL = alignment only. ---- */
+     *      (src/f5c.c:907-960: align_db, then pthread_db(scaling_single), then meth_single reads only base_to_event_map /
+     *      scalings / events_per_base).  The wavefront that aligned a read also recalibrates it (last phase of the alignment
+     *      kernel).  What crosses PCIe downwards: the 2-bit walk (0.4 B per event; expanded by the host workers into the pair
+     *      lists when pairs != NULL), one event-count byte per k-mer from which the host rebuilds base_to_event_map (its entries
+     *      tile the path's events in k order), and 36 B of scalars per read.  All NULL = alignment only. ---- */
     abea_index_pair_t* const* base_to_event_map;   /* db->base_to_event_map[i]: caller-allocated, read_len-k+1 entries;
                                                       written only for reads with n_pairs > 0 (the reference leaves NULL otherwise) */
     abea_scalings_t* scalings_out;         /* [n_reads] db->scalings[i] after recalibration (input copied when not recalibrated;
