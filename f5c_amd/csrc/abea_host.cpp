@@ -14,8 +14,8 @@
  *   - what comes down over PCIe is the traceback walk, 2 bits per step (0.4 B per event instead of 8.3): the pairs are
  *     expanded from it on the host while they are written into db->event_align_pairs[i].  ABEA_HOST_PAIRS=device keeps
  *     the expansion on the GPU and copies compacted pair lists instead;
- *   - optional scaling_single on the device right behind the alignment (row N1): base_to_event_map + recalibrated
- *     scalings come back, the pair lists need not.
+ *   - optional scaling_single (row N1) as the last phase of the alignment kernel: recalibrated scalings, flags and
+ *     base_to_event_map come back — the map as one event-count byte per k-mer, rebuilt here — the pair lists need not.
  * With a multi-device context (abea_init_multi) the batch is first split over the devices, longest-processing-time-
  * first on the band count, and each device runs the pipeline above on its share from its own host thread.
  * No CPU alignment fallback exists in this library.

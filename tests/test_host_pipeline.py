@@ -518,3 +518,35 @@ def test_kmer_count_expansion_matches_postalign(orc, r9):
         assert lib.abea_expand_kmer_counts_to_map(c8.ctypes.data, K, int(d["best_event"]), out.ctypes.data) != 0
         n_ok += 1
     assert n_ok >= 30
+
+
+@pytest.mark.gpu
+def test_fused_map_with_kmers_of_255_and_more_events(ctx, orc, r9):
+    """The fused call hands base_to_event_map to the host as one event-count byte per k-mer; 255 means "255 or more" and sends
+    that read's map back to the 2-bit walk.  Reads with a stretch of 240..600 repeated events on one k-mer (they align: a long
+    stay) sit on both sides of the escape value; every map equals the oracle's postalign."""
+    from f5c_amd import synth
+    k, model = r9
+    base = synth.make_batch(8, model, k, seed=4242, law=1500, bad_frac=0.0)
+    seqs, evs, scal, reps = [], [], [], [0, 240, 250, 253, 256, 300, 600, 252]
+    for i in range(8):
+        s, L = int(base["read_ptr"][i]), int(base["read_len"][i])
+        es, E = int(base["event_ptr"][i]), int(base["n_events"][i])
+        seq, ev = base["reads"][s:s + L].tobytes(), base["events"][es:es + E]
+        if reps[i]:
+            ev = np.concatenate([ev[:1000], np.repeat(ev[1000:1001], reps[i]), ev[1000:]])
+        seqs.append(seq); evs.append(np.ascontiguousarray(ev)); scal.append(orc.estimate_scalings(seq, model, k, ev))
+    batch = synth.batch_from_reads(seqs, evs, scal)
+    plist, n_pairs, _, sc = ctx.align_flat_host(batch, scaling=True, want_pairs=False)
+    most = []
+    for i in range(8):
+        o_pairs, _ = orc.align(seqs[i], evs[i], model, k, scal[i][0], scal[i][1])
+        assert len(o_pairs) == n_pairs[i] > 0
+        r = orc.scaling_single(o_pairs, seqs[i], evs[i], model, k, scal[i][0], scal[i][1])
+        m = sc["base_to_event_map"][i]
+        assert (m[:, 0] == r["base_to_event_map"]["start"]).all() and (m[:, 1] == r["base_to_event_map"]["stop"]).all(), i
+        assert sc["read_stat_flag"][i] == r["flag"] and sc["events_per_base"][i] == r["events_per_base"]
+        assert sc["scalings"]["shift"][i] == r["scalings"]["shift"] and sc["scalings"]["var"][i] == r["scalings"]["var"]
+        bm = r["base_to_event_map"]
+        most.append(int(np.where(bm["start"] >= 0, bm["stop"] - bm["start"] + 1, 0).max()))
+    assert max(most) >= 500 and sum(c >= 255 for c in most) >= 2 and sum(200 < c < 255 for c in most) >= 1, most
