@@ -57,8 +57,8 @@ int events_locked(abea_ctx* c, const abea_events_host_batch* B, double* kernel_m
     HIP_TRY(hipSetDevice(c->device));
     const bool want_sc = B->scalings != nullptr;
     std::vector<int32_t> todo;                          /* reads with a signal, in batch order (f5c.c:684) */
+    for (int32_t i = 0; i < n; ++i) { B->events[i] = nullptr; B->n_events[i] = 0; }   /* before any exit: the callers free() these */
     for (int32_t i = 0; i < n; ++i) {
-        B->events[i] = nullptr; B->n_events[i] = 0;
         if (B->n_samples[i] <= 0) continue;              /* f5c.c:727-731: et.n = 0, et.event = NULL */
         if (!B->rawptr[i]) return abea_fail(ABEA_EINVAL, "read %d: null signal", i);
         if (B->n_samples[i] > (int64_t)INT32_MAX - 64) return abea_fail(ABEA_EINVAL, "read %d: %" PRId64 " samples", i, B->n_samples[i]);
@@ -278,7 +278,6 @@ extern "C" int abea_process_batch_host(abea_ctx* c, const abea_process_batch* P)
     int rc = events_locked(event_device(c), &E, &ev_ms);
     if (rc) { release(); return rc; }
     if (P->scalings_estimated) memcpy(P->scalings_estimated, P->scalings, (size_t)n * sizeof(abea_scalings_t));
-    const double t1 = abea_now_ms();
     /* ---- align_db + scaling_db (f5c.c:833-845, 736-807) on the tables just made: what event_single and scaling_single
      *      malloc() per read (f5c.c:722-725, 746) is malloc()ed here ---- */
     std::vector<const abea_event_t*> ev((size_t)n);
@@ -303,7 +302,6 @@ extern "C" int abea_process_batch_host(abea_ctx* c, const abea_process_batch* P)
         if (P->n_pairs[i] <= 0 && P->base_to_event_map[i]) { free(P->base_to_event_map[i]); P->base_to_event_map[i] = nullptr; }
     c->stats.event_ms = ev_ms;
     c->stats.total_ms = abea_now_ms() - t0;
-    (void)t1;
     return ABEA_OK;
 }
 

@@ -216,7 +216,8 @@ int abea_detect_events_device(abea_ctx* ctx, const abea_signal_batch* batch);
  * the device chunk by chunk, and each read's table comes back as a malloc()ed event_t array — where getevents()
  * (src/events.c:562-582) would have put it; the caller releases it with free() as free_db_tmp does.  Reads with
  * n_samples <= 0 get events = NULL, n_events = 0 (f5c.c:727-731).  A read whose table overflows the first guess of its
- * size is redone with the exact size inside the call. */
+ * size is redone with the exact size inside the call.  On failure no table is handed back (all events[i] are NULL), but with
+ * signal_to_pa_in_place the signals of the chunks that had completed are already in pA: the batch cannot simply be re-submitted. */
 typedef struct {
     int32_t n_reads;                       /* db->n_bam_rec */
     float* const* rawptr;                  /* db->sig[i]->rawptr: ADC counts as float; rewritten to pA when signal_to_pa_in_place */
