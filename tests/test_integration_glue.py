@@ -53,7 +53,9 @@ def test_glue_compiles_against_the_reference_headers(tmp_path):
     md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
     m = re.search(r"```c\n(// src/abea_glue\.c.*?)```", md, re.S)
     assert m, "INTEGRATION.md lost its glue block"
-    (tmp_path / "abea_glue.c").write_text(m.group(1))
+    m2 = re.search(r"```c\n(// src/abea_glue\.c, continued.*?)```", md, re.S)      # the process_db_rsq chain (round 4)
+    assert m2, "INTEGRATION.md lost its process_db_rsq glue block"
+    (tmp_path / "abea_glue.c").write_text(m.group(1) + "\n" + m2.group(1))
     (tmp_path / "layout.cpp").write_text(LAYOUT)
     inc = ["-I", str(tmp_path / "stub"), "-I", os.path.join(REF, "src"), "-I", os.path.join(REF, "slow5lib", "include"),
            "-I", os.path.join(ROOT, "include")]
