@@ -12,7 +12,9 @@
  *
  * Kernels:  abea_pre_kernel   (align-pre: k-mer ranks -> read-scaled emission params, event means SoA)
  *           abea_align_kernel (band fill + adaptive band movement + online end-point scan, then the
- *                              align-post traceback walk, pair expansion and ordered QC sums, fused)
+ *                              align-post traceback walk, pair expansion and ordered QC sums and — when
+ *                              asked for — scaling_single of the read: postalign + recalibrate_model; fused)
+ *           abea_copy_out_kernel, and the event-detection kernels abea_ev_* (row N2)
  */
 #include <hip/hip_runtime.h>
 #include <type_traits>
@@ -283,7 +285,8 @@ static __device__ void abea_scaling_single_wave(const abea_read_desc* d, const a
  *   phase 1  band fill + adaptive band movement + online end-point scan      (VALU/DPP bound)
  *   phase 2  traceback walk over the packed trace, on the scalar unit        (SALU bound)
  *   phase 3  expansion of the walk's 2-bit codes into (k-mer, event) pairs,
- *            ordered fp64 emission sum, QC                                   (small, VALU)
+ *            ordered fp64 emission sum, QC; base_to_event_map when phase 4 is on (small, VALU)
+ *   phase 4  (optional) scaling_single: 'M' states, recalibrate_model's chains fed from LDS, flags
  * Fusing the phases lets the scalar-unit-bound walks of finished reads overlap the VALU-bound fills
  * of the other waves resident on the same CU, and removes two kernel boundaries per batch.
  *
