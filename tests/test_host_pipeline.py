@@ -550,3 +550,44 @@ def test_fused_map_with_kmers_of_255_and_more_events(ctx, orc, r9):
         bm = r["base_to_event_map"]
         most.append(int(np.where(bm["start"] >= 0, bm["stop"] - bm["start"] + 1, 0).max()))
     assert max(most) >= 500 and sum(c >= 255 for c in most) >= 2 and sum(200 < c < 255 for c in most) >= 1, most
+
+
+def test_the_walk_code_rules_of_phase_3_are_postalign(orc, r9):
+    """Phase 3 of abea_align_kernel writes base_to_event_map straight from the walk (no pair lists in HBM for the fused call): in
+    walk order code[t] is the move from pair t to its predecessor in the list (1 = same k-mer, 2 = same event), and a pair
+        opens its k-mer's run  iff code[t] != 1 (or it is the last step),   closes it  iff code[t-1] != 1 (or t = 0),
+        is a new event         iff code[t] != 2 (or it is the last step),   and the successor's event is e + [code[t-1] != 2].
+    The same rules in numpy, on oracle alignments, against the oracle's postalign (align.c:571-596)."""
+    from f5c_amd import synth
+    k, model = r9
+    batch = synth.make_batch(30, model, k, seed=577, law=1300, bad_frac=0.0)
+    n_ok = 0
+    for i in range(30):
+        s, L = int(batch["read_ptr"][i]), int(batch["read_len"][i])
+        es, E = int(batch["event_ptr"][i]), int(batch["n_events"][i])
+        seq, ev = batch["reads"][s:s + L].tobytes(), batch["events"][es:es + E]
+        if i % 4 == 0:
+            ev = np.concatenate([ev[:300], np.repeat(ev[300:301], 30), ev[300:]])       # a long stay
+        if i % 4 == 1:
+            ev = np.concatenate([ev[:200], ev[260:]])                                    # dropped events: skips
+        sc = orc.estimate_scalings(seq, model, k, ev)
+        pairs, _ = orc.align(seq, ev, model, k, sc[0], sc[1])
+        if len(pairs) == 0:
+            continue
+        want = orc.scaling_single(pairs, seq, ev, model, k, sc[0], sc[1])["base_to_event_map"]
+        W = pairs.view(np.int32).reshape(-1, 2)[::-1]                                    # walk order: t = 0 at the end cell
+        n, K = len(W), L - k + 1
+        dk, de = W[:-1, 0] - W[1:, 0], W[:-1, 1] - W[1:, 1]
+        code = np.concatenate([np.where((dk == 1) & (de == 1), 0, np.where(dk == 0, 1, 2)), [3]])   # the last step's code is never used
+        t = np.arange(n)
+        cprev = np.concatenate([[0], code[:-1]])
+        run_start = (t == n - 1) | (code != 1)
+        run_end = (t == 0) | (cprev != 1)
+        is_new = (t == n - 1) | (code != 2)
+        next_e = W[:, 1] + ((t > 0) & (cprev != 2))
+        start = np.full(K, -1); stop = np.full(K, -1)
+        start[W[run_start, 0]] = np.where(is_new, W[:, 1], np.where(~run_end, next_e, -1))[run_start]
+        stop[W[run_end, 0]] = np.where(~run_start | is_new, W[:, 1], -1)[run_end]
+        assert (start == want["start"]).all() and (stop == want["stop"]).all(), i
+        n_ok += 1
+    assert n_ok >= 24
