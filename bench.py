@@ -60,6 +60,12 @@ def main():
     ap.add_argument("--batch-cache", default="", help="np.savez cache of the generated batch (profiling runs: generate once, "
                     "then reload under rocprofv3 without the forked generator pool)")
     ap.add_argument("--single-process", action="store_true", help="N GPUs from ONE process (abea_init_multi) instead of one rank per GPU")
+    ap.add_argument("--host-buffers", default="interleave", choices=["interleave", "first-touch"],
+                    help="NUMA placement of the synthetic batch in host memory (outside the timed region).  f5c's per-read event "
+                         "tables are malloc()ed by its worker threads (pthread_db(event_single)), i.e. spread over the sockets; "
+                         "a 60-GB numpy array concatenated by ONE thread lands on that thread's node and the flatten loop then "
+                         "reads through one socket (measured: 170 to 450 ms per step from box to box).  interleave = "
+                         "set_mempolicy(MPOL_INTERLEAVE) while the batch is built; first-touch = whatever the kernel does")
     args = ap.parse_args()
 
     import numpy as np
@@ -82,6 +88,7 @@ def main():
     n_total = args.reads or cfg["n_reads"]
 
     # ---- the batch: every rank builds only the reads it aligns ----
+    interleaved = numa_interleave(True) if args.host_buffers == "interleave" else False
     t0 = time.time()
     workers = max(1, min(16, effective_cpus() // max(1, world)))
     cache = f"{args.batch_cache}.{args.config}.{n_total}.r{rank}of{world}.npz" if args.batch_cache else ""
@@ -102,6 +109,8 @@ def main():
     if cache and not os.path.exists(cache):
         np.savez(cache, **batch)
     t_gen = time.time() - t0
+    if interleaved:
+        numa_interleave(False)                 # the library's threads, staging and the pair buffers get the default policy
     sum_events = int(batch["n_events"].sum())
     n_reads = len(batch["read_len"])
 
@@ -219,6 +228,9 @@ def main():
             "dtype": "f32 scores, f64 sums, 2-bit trace", "data": "synthetic",
             "config": {"workload": name, "reads": int(total_reads), "events": int(total_events), "kmer_size": k,
                        "reads_rank0": n_reads, "events_rank0": sum_events,
+                       "host_buffers": ("event tables NUMA-interleaved over the host's nodes (set_mempolicy while the batch is built), as "
+                                        "f5c's per-thread malloc()s spread them" if interleaved else
+                                        "first-touch placement by the generating thread (one NUMA node)"),
                        "parallelism": (f"one process, {args.gpus} GPUs (abea_init_multi, LPT split in the library)" if args.single_process
                                        else f"{world} ranks x 1 GPU, LPT shards, no data-path collective" if world > 1 else "1 GPU"),
                        "boundary": ("host buffers in, host buffers out: abea_align_batch_host = align_db's GPU branch "
@@ -451,6 +463,29 @@ def valu_roofline(config, sum_events, launch_ms, launches, n_right=0, n_down=0):
         return out
     except Exception:
         return None
+
+
+def numa_interleave(on):
+    """set_mempolicy(MPOL_INTERLEAVE over the online nodes) / (MPOL_DEFAULT) for the calling thread; False when the host has
+    one node or the call is refused.  Only the placement of the synthetic INPUT is affected: it is switched off again before
+    the library's context (threads, pinned staging) and the output buffers exist."""
+    try:
+        import ctypes
+        libc = ctypes.CDLL(None, use_errno=True)
+        if not on:
+            return libc.syscall(238, 0, None, 0) == 0                       # SYS_set_mempolicy (x86-64), MPOL_DEFAULT
+        nodes = []
+        for part in open("/sys/devices/system/node/online").read().strip().split(","):
+            a, _, b = part.partition("-")
+            nodes += list(range(int(a), int(b or a) + 1))
+        if len(nodes) < 2:
+            return False
+        mask = (ctypes.c_ulong * 16)()
+        for nd in nodes:
+            mask[nd // 64] |= 1 << (nd % 64)
+        return libc.syscall(238, 3, mask, 16 * 64 + 1) == 0                 # MPOL_INTERLEAVE
+    except Exception:
+        return False
 
 
 def effective_cpus():
