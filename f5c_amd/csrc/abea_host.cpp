@@ -410,7 +410,62 @@ void abea_host_release(abea_ctx* c) {
  * pairs backwards, then reverses).  Step j of the walk (j = 0 at the end cell (K-1, best_event)) is pair n-1-j;
  * code 0 = diagonal (k-mer and event step), 1 = up (event only), 2 = left (k-mer only) — the same expansion as
  * phase 3 of abea_align_kernel. */
+static inline uint32_t walk_code(const uint32_t* codes, int32_t t) { return (codes[t >> 4] >> ((t & 15) * 2)) & 3u; }
+
+/* 16 steps at a time with AVX2 + BMI2 (every x86 host an MI355X sits in has them; checked at run time): the two decrement
+ * bits of each step (k-mer steps unless the code is 1, event steps unless it is 2) come out of the word with pext, their
+ * exclusive prefix counts with four byte-shift adds, and the 16 pairs leave as four 32-byte non-temporal stores instead of
+ * sixteen 8-byte ones: the un-flatten loop is bound by the store rate of the few worker threads a cgroup quota leaves
+ * (round 4; 1.2 -> 0.45 ns per pair on one core of the build box). */
+__attribute__((target("avx2,bmi2")))
+static inline __m128i walk_prefix16(uint32_t bits, __m128i rev) {                         /* byte s = steps before s that moved */
+    const __m128i x = _mm_set_epi64x((long long)_pdep_u64(bits >> 8, 0x0101010101010101ull),
+                                     (long long)_pdep_u64(bits & 0xFFu, 0x0101010101010101ull));
+    __m128i p = _mm_add_epi8(x, _mm_slli_si128(x, 1));
+    p = _mm_add_epi8(p, _mm_slli_si128(p, 2));
+    p = _mm_add_epi8(p, _mm_slli_si128(p, 4));
+    p = _mm_add_epi8(p, _mm_slli_si128(p, 8));
+    return _mm_shuffle_epi8(_mm_sub_epi8(p, x), rev);                                      /* exclusive, step 15 first */
+}
+
+__attribute__((target("avx2,bmi2")))
+static void expand_codes_avx2(const uint32_t* codes, int32_t n, int32_t k, int32_t e, abea_pair_t* out) {
+    int32_t t = 0;
+    /* scalar steps until the end of the block to be written is 32-byte aligned (the lists are written back to front) */
+    for (; t < n && (reinterpret_cast<uintptr_t>(out + (n - t)) & 31u); ++t) {
+        _mm_stream_si64(reinterpret_cast<long long*>(out + (n - 1 - t)), (long long)(((uint64_t)(uint32_t)e << 32) | (uint32_t)k));
+        const uint32_t cd = walk_code(codes, t);
+        k -= (cd != 1u); e -= (cd != 2u);
+    }
+    const __m128i rev = _mm_set_epi8(0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+    for (; t + 16 <= n; t += 16) {
+        const int32_t idx = t >> 4, sh = (t & 15) * 2;
+        const uint32_t w = sh ? (codes[idx] >> sh) | (codes[idx + 1] << (32 - sh)) : codes[idx];
+        const uint32_t b0 = _pext_u32(w, 0x55555555u), b1 = _pext_u32(w, 0xAAAAAAAAu);
+        const uint32_t dkb = ~(b0 & ~b1) & 0xFFFFu, deb = ~(b1 & ~b0) & 0xFFFFu;          /* bit s: step s moves k / e */
+        const __m128i pk = walk_prefix16(dkb, rev), pe = walk_prefix16(deb, rev);
+        const __m256i kv = _mm256_set1_epi32(k), ev = _mm256_set1_epi32(e);
+        __m256i* o = reinterpret_cast<__m256i*>(out + (n - t - 16));                       /* 32-byte aligned by the peel above */
+        for (int h = 0; h < 2; ++h) {                                                      /* steps 15..8, then 7..0 */
+            const __m256i k8 = _mm256_sub_epi32(kv, _mm256_cvtepu8_epi32(h ? _mm_srli_si128(pk, 8) : pk));
+            const __m256i e8 = _mm256_sub_epi32(ev, _mm256_cvtepu8_epi32(h ? _mm_srli_si128(pe, 8) : pe));
+            const __m256i lo = _mm256_unpacklo_epi32(k8, e8), hi = _mm256_unpackhi_epi32(k8, e8);   /* {ref_pos, read_pos} */
+            _mm256_stream_si256(o + 2 * h, _mm256_permute2x128_si256(lo, hi, 0x20));
+            _mm256_stream_si256(o + 2 * h + 1, _mm256_permute2x128_si256(lo, hi, 0x31));
+        }
+        k -= __builtin_popcount(dkb); e -= __builtin_popcount(deb);
+    }
+    for (; t < n; ++t) {
+        _mm_stream_si64(reinterpret_cast<long long*>(out + (n - 1 - t)), (long long)(((uint64_t)(uint32_t)e << 32) | (uint32_t)k));
+        const uint32_t cd = walk_code(codes, t);
+        k -= (cd != 1u); e -= (cd != 2u);
+    }
+    _mm_sfence();
+}
+
 static void expand_codes(const uint32_t* codes, int32_t n, int32_t k, int32_t e, abea_pair_t* out) {
+    static const bool simd = __builtin_cpu_supports("avx2") && __builtin_cpu_supports("bmi2") && !getenv("ABEA_HOST_SCALAR_EXPAND");
+    if (simd) { expand_codes_avx2(codes, n, k, e, out); return; }
     /* the caller's pair buffer is written once and not read back here: 8-byte non-temporal stores (the write-combining
      * buffers assemble full lines back to front) halve the DRAM traffic of a plain store's read-for-ownership */
     long long* o = reinterpret_cast<long long*>(out + n);
@@ -477,7 +532,52 @@ static void expand_codes_to_map(const uint32_t* codes, int32_t n, int32_t k, int
  * begin, the last non-empty one ending at the alignment's end event.  Two adds and a store per k-mer (the walk needs a tzcnt
  * chain with a serial dependency: 142 ms per 100 k reads against 110 ms for the pair lists; this: see DESIGN.md §6).  Returns false
  * at a count of 255 ("255 or more"): the caller rebuilds that read's map from the walk. */
+/* eight entries at a time (AVX2): inclusive prefix sums P of the eight counts in 32-bit lanes; with `top` the last event at or
+ * below the block's highest k-mer, entry j is {stop - c + 1, stop}, stop = top - total + P[j], or {-1, -1} when c = 0 */
+__attribute__((target("avx2")))
+static bool expand_counts_to_map_avx2(const uint8_t* count, int32_t K, int32_t end_event, abea_index_pair_t* map) {
+    long long* m64 = reinterpret_cast<long long*>(map);
+    int32_t cur = end_event, k = K - 1;
+    auto one = [&](int32_t kk) {                         /* scalar step: head (until the block stores are 32-byte aligned) and tail */
+        const int32_t c = count[kk];
+        if (c == 255) return false;
+        const int32_t start = c ? cur - c + 1 : -1, stop = c ? cur : -1;
+        _mm_stream_si64(m64 + kk, (long long)(((uint64_t)(uint32_t)stop << 32) | (uint32_t)start));
+        cur -= c;
+        return true;
+    };
+    for (; k >= 0 && (reinterpret_cast<uintptr_t>(map + k + 1) & 31u); --k) if (!one(k)) return false;
+    const __m256i ones = _mm256_set1_epi32(1), neg = _mm256_set1_epi32(-1), zero = _mm256_setzero_si256();
+    const __m256i lane3 = _mm256_set1_epi32(3), lane7 = _mm256_set1_epi32(7);
+    __m256i curv = _mm256_set1_epi32(cur);               /* the running event stays in a vector: the loop-carried chain is one
+                                                          * permute and one subtract per eight entries */
+    for (; k >= 7; k -= 8) {
+        const __m128i c8 = _mm_loadl_epi64(reinterpret_cast<const __m128i*>(count + k - 7));
+        if (_mm_movemask_epi8(_mm_cmpeq_epi8(c8, _mm_set1_epi8((char)255))) & 0xFF) return false;
+        const __m256i v = _mm256_cvtepu8_epi32(c8);
+        __m256i p = _mm256_add_epi32(v, _mm256_slli_si256(v, 4));          /* prefix sums inside each 128-bit half ... */
+        p = _mm256_add_epi32(p, _mm256_slli_si256(p, 8));
+        const __m256i low_total = _mm256_permutevar8x32_epi32(p, lane3);
+        p = _mm256_add_epi32(p, _mm256_blend_epi32(zero, low_total, 0xF0));   /* ... the upper half continues the lower one */
+        curv = _mm256_sub_epi32(curv, _mm256_permutevar8x32_epi32(p, lane7)); /* the event below the block, in every lane */
+        const __m256i stop = _mm256_add_epi32(curv, p);
+        const __m256i start = _mm256_add_epi32(_mm256_sub_epi32(stop, v), ones);
+        const __m256i none = _mm256_cmpeq_epi32(v, zero);
+        const __m256i st = _mm256_blendv_epi8(start, neg, none), sp = _mm256_blendv_epi8(stop, neg, none);
+        const __m256i lo = _mm256_unpacklo_epi32(st, sp), hi = _mm256_unpackhi_epi32(st, sp);       /* {start, stop} */
+        __m256i* o = reinterpret_cast<__m256i*>(map + k - 7);                /* 32-byte aligned by the head loop */
+        _mm256_stream_si256(o, _mm256_permute2x128_si256(lo, hi, 0x20));
+        _mm256_stream_si256(o + 1, _mm256_permute2x128_si256(lo, hi, 0x31));
+    }
+    cur = _mm256_extract_epi32(curv, 0);
+    for (; k >= 0; --k) if (!one(k)) return false;
+    _mm_sfence();
+    return true;
+}
+
 static bool expand_counts_to_map(const uint8_t* count, int32_t K, int32_t end_event, abea_index_pair_t* map) {
+    static const bool simd = __builtin_cpu_supports("avx2") && !getenv("ABEA_HOST_SCALAR_EXPAND");
+    if (simd) return expand_counts_to_map_avx2(count, K, end_event, map);
     long long* m64 = reinterpret_cast<long long*>(map);
     int32_t cur = end_event;
     for (int32_t k = K - 1; k >= 0; --k) {

@@ -591,3 +591,54 @@ def test_the_walk_code_rules_of_phase_3_are_postalign(orc, r9):
         assert (start == want["start"]).all() and (stop == want["stop"]).all(), i
         n_ok += 1
     assert n_ok >= 24
+
+
+def test_walk_code_expansion_every_length_and_alignment():
+    """abea_expand_walk_codes (AVX2 + BMI2 blocks of 16 steps between a scalar head that aligns the block stores to 32 bytes and
+    a scalar tail; plain loop on a CPU without them or with ABEA_HOST_SCALAR_EXPAND set): every list length from 1 step, every
+    placement of the output buffer, against a step-by-step reference; nothing is written outside the list."""
+    import ctypes
+    from f5c_amd import abea
+    lib = abea.load_library()
+    lib.abea_expand_walk_codes.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]
+    r = np.random.default_rng(5)
+    for n in list(range(1, 100)) + [255, 256, 257, 1023, 1024, 4097]:
+        steps = r.choice([0, 0, 0, 1, 1, 2], size=n).astype(np.uint32)
+        words = np.zeros((n + 15) // 16 + 1, dtype=np.uint32)
+        for j in range(16):
+            sl = steps[j::16]
+            words[:len(sl)] |= sl << (2 * j)
+        dk, de = (steps != 1).astype(np.int64), (steps != 2).astype(np.int64)
+        k0, e0 = 70000 + n, 90000 + n
+        want = np.stack([k0 - np.concatenate([[0], np.cumsum(dk)[:-1]]), e0 - np.concatenate([[0], np.cumsum(de)[:-1]])], axis=1)[::-1]
+        for off in range(4):
+            buf = np.full((n + off + 6, 2), -7, dtype=np.int32)
+            out = buf[off:off + n]
+            assert lib.abea_expand_walk_codes(words.ctypes.data, n, k0, e0, out.ctypes.data) == 0
+            assert (out == want).all(), (n, off)
+            assert (buf[:off] == -7).all() and (buf[off + n:] == -7).all(), (n, off)
+
+
+def test_kmer_count_expansion_every_length_and_alignment():
+    """abea_expand_kmer_counts_to_map (AVX2 blocks of eight entries between scalar head and tail; plain loop otherwise): every
+    table length, every placement of the output, counts up to 254, the escape value anywhere -> refused; nothing written outside."""
+    import ctypes
+    from f5c_amd import abea
+    lib = abea.load_library()
+    lib.abea_expand_kmer_counts_to_map.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]
+    r = np.random.default_rng(9)
+    for K in list(range(1, 70)) + [255, 256, 1000, 4099]:
+        for off in range(4):
+            c = np.where(r.random(K) < 0.1, 0, r.integers(1, 12, K)).astype(np.uint8)
+            if K > 20:
+                c[K // 3] = 254
+            end = int(c.sum()) + 1000
+            stop = end - (np.cumsum(c[::-1].astype(np.int64))[::-1] - c)
+            want = np.stack([np.where(c > 0, stop - c + 1, -1), np.where(c > 0, stop, -1)], axis=1)
+            buf = np.full((K + off + 6, 2), -7, dtype=np.int32)
+            out = buf[off:off + K]
+            assert lib.abea_expand_kmer_counts_to_map(c.ctypes.data, K, end, out.ctypes.data) == 0
+            assert (out == want).all(), (K, off)
+            assert (buf[:off] == -7).all() and (buf[off + K:] == -7).all(), (K, off)
+            c[r.integers(0, K)] = 255
+            assert lib.abea_expand_kmer_counts_to_map(c.ctypes.data, K, end, out.ctypes.data) != 0
