@@ -18,7 +18,7 @@ EXPORTS = ["abea_init", "abea_init_multi", "abea_device_count", "abea_free", "ab
            "abea_device_info", "abea_selftest", "abea_rsq_format", "abea_lpt_split", "abea_hmm_score_batch_host", "abea_expand_walk_codes", "abea_expand_walk_codes_to_map",
            "abea_host_plan_chunks", "abea_host_plan_threads", "abea_set_inflight", "abea_align_batch_host_submit",
            "abea_align_batch_host_wait", "abea_events_batch_host", "abea_process_batch_host", "abea_rsq_format_batch",
-           "abea_hmm_score_batch_device", "abea_expand_kmer_counts_to_map"]
+           "abea_hmm_score_batch_device", "abea_expand_kmer_counts_to_map", "abea_flatten_event_means"]
 SHIM_EXPORTS = ["abea_f5c_init", "abea_f5c_align", "abea_f5c_align_scale", "abea_f5c_free", "abea_f5c_align_submit",
                 "abea_f5c_align_wait", "abea_f5c_event_db", "abea_f5c_process"]      # include/abea_f5c_shim.h
 
@@ -102,7 +102,7 @@ class Stats(C.Structure):
                 ("bytes_moved", C.c_uint64),
                 ("flatten_ms", C.c_double), ("unflatten_ms", C.c_double), ("wait_ms", C.c_double),
                 ("h2d_bytes", C.c_uint64), ("d2h_bytes", C.c_uint64), ("n_devices", C.c_int32),
-                ("host_threads", C.c_int32)]
+                ("host_threads", C.c_int32), ("plan_ms", C.c_double), ("setup_ms", C.c_double)]
 
     def asdict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -202,7 +202,7 @@ extern "C" int abea_selftest(abea_ctx* c) {
 }
 
 /* ------------------------------------------------------------------ batch planning */
-void plan_desc(abea_read_desc& d, const plan_read& r, const abea_scalings_t& sc, sub_layout& lay, abea_stats& st) {
+void plan_desc_layout(abea_read_desc& d, const plan_read& r, const abea_scalings_t& sc, sub_layout& lay, abea_stats& st) {
     memset(&d, 0, sizeof d);
     d.out_idx = r.idx;
     d.read_len = r.L; d.n_events = r.E; d.n_kmers = r.K;
@@ -213,14 +213,6 @@ void plan_desc(abea_read_desc& d, const plan_read& r, const abea_scalings_t& sc,
     d.evm_off = (int64_t)lay.n_evm;     lay.n_evm += align_up((size_t)r.E + 64, 4);
     d.code_off = (int64_t)lay.n_code;   lay.n_code += align_up((size_t)(r.E + r.K) / 16 + 2, 4);
     d.trace_off = (int64_t)lay.n_trace; lay.n_trace += (size_t)d.n_groups * 64;
-    /* align.c:207-216, doubles, glibc */
-    volatile double eps = 1e-10, trim_p = 0.01;
-    double events_per_kmer = (double)(size_t)r.E / (size_t)r.K;
-    double p_stay = 1 - (1 / (events_per_kmer + 1));
-    d.lp_skip = log(eps);
-    d.lp_stay = log(p_stay);
-    d.lp_step = log(1.0 - exp(d.lp_skip) - exp(d.lp_stay));
-    d.lp_trim = log(trim_p);
     st.sum_events += r.E; st.sum_bands += r.n_bands;
     /* SURVEY §8d algorithmic bytes; P is added after the run from n_pairs */
     const uint64_t Bn = (uint64_t)r.n_bands;
@@ -230,6 +222,18 @@ void plan_desc(abea_read_desc& d, const plan_read& r, const abea_scalings_t& sc,
      * post (trace blocks on the path ~ 32 B/band worst case, codes, 16K+4E again, 8P out) */
     st.bytes_moved += 24ull * r.E + r.L + 12ull * r.K + 2 * (16ull * r.K + 4ull * r.E) + 64ull * Bn +
                       16ull * r.K + 4ull * r.E;
+}
+
+void plan_desc_consts(abea_read_desc& d) {
+    if (d.n_groups == 0) return;
+    /* align.c:207-216, doubles, glibc */
+    volatile double eps = 1e-10, trim_p = 0.01;
+    double events_per_kmer = (double)(size_t)d.n_events / (size_t)d.n_kmers;
+    double p_stay = 1 - (1 / (events_per_kmer + 1));
+    d.lp_skip = log(eps);
+    d.lp_stay = log(p_stay);
+    d.lp_step = log(1.0 - exp(d.lp_skip) - exp(d.lp_stay));
+    d.lp_trim = log(trim_p);
 }
 
 int ensure_pinned(void** p, size_t* cap, size_t need) {
@@ -360,8 +364,43 @@ extern "C" int abea_detect_events_device(abea_ctx* c, const abea_signal_batch* B
     return abea_detect_events_locked(c, B);
 }
 
+/* scratch of ONE pass of abea_detect_events_on over these reads (the arithmetic of its wave carving: 64 reads per wave in
+ * descending sample count, every array interleaved over the wave's lanes and as long as its longest read) */
+size_t abea_detect_scratch_bytes(const int32_t* n_samples, const int32_t* event_cap, const int32_t* n_kmers, int32_t n) {
+    if (n <= 0) return 0;
+    std::vector<int32_t> order((size_t)n);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return n_samples[a] > n_samples[b]; });
+    const size_t N = (size_t)n, n_waves = (N + 63) / 64;
+    const size_t EV_SEG = 512, EV_FIXCAP = 48, SEG_BYTES = 64 * (EV_SEG * 2 + EV_FIXCAP * 4 + 12 * 4 + 2 * 8 + 4 * 4);
+    size_t bytes = N * (4 + 8 + 4 + 12 + 8 + 4 + 8 + 4 + 4 + 4) + n_waves * 56 + 8192 + 4096 + 8192;
+    for (size_t w = 0; w < n_waves; ++w) {
+        const int32_t len = n_samples[order[w * 64]] + 1;
+        int32_t cap = 1, wk = 1;
+        for (size_t q = w * 64; q < std::min(N, (w + 1) * 64); ++q) {
+            cap = std::max(cap, event_cap[order[q]]);
+            if (n_kmers) wk = std::max(wk, n_kmers[order[q]]);
+        }
+        const size_t nseg = std::max<size_t>(1, ((size_t)std::max(len - 1, 0) + EV_SEG - 1) / EV_SEG);
+        bytes += (size_t)std::max(len, 1) * 64 * 24 + (size_t)cap * 64 * 8 + (size_t)wk * 64 * 4 + nseg * SEG_BYTES;
+    }
+    return bytes + (1u << 20);
+}
+
 /* the entry's body; the caller holds the context (abea_process.cpp chains it behind a host-side flatten) */
 int abea_detect_events_locked(abea_ctx* c, const abea_signal_batch* B) {
+    abea_ev_exec X;
+    X.stream = c->stream; X.scratch = c->arena; X.scratch_bytes = c->arena_bytes;
+    X.h_pinned = (void**)&c->h_desc; X.h_cap = &c->h_desc_cap; X.async = false; X.e0 = c->ev[0]; X.e1 = c->ev[1];
+    return abea_detect_events_on(c, B, X);
+}
+
+/* The detector's kernels for one signal batch on X.stream with scratch [X.scratch, +X.scratch_bytes) and the pinned index
+ * staging *X.h_pinned.  Synchronous form (X.async == false): sub-batches of waves as the scratch allows, a stream
+ * synchronisation after each, kernel time into c->stats.event_ms.  Asynchronous form (the chunk pipeline of
+ * abea_process.cpp): everything must fit the scratch at once (ABEA_ENOMEM otherwise), nothing is waited for, and the
+ * pinned staging must stay untouched until the stream has consumed it. */
+int abea_detect_events_on(abea_ctx* c, const abea_signal_batch* B, const abea_ev_exec& X) {
     const int32_t n = B->n_reads;
     if (n < 0) return abea_fail(ABEA_EINVAL, "n_reads < 0");
     if (n == 0) return ABEA_OK;
@@ -378,14 +417,14 @@ int abea_detect_events_locked(abea_ctx* c, const abea_signal_batch* B) {
     std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return B->n_samples[a] > B->n_samples[b]; });
     const size_t N = (size_t)n;
     const int n_waves_all = (n + 63) / 64;
-    c->stats.event_ms = 0;
+    if (!X.async) c->stats.event_ms = 0;
     int w0 = 0;
     while (w0 < n_waves_all) {
         /* ---- carve waves whose interleaved scratch fits the arena: per sample S,Q fp64 + two float t-statistics
          *      (24 B), per event slot a peak position + a mean (8 B) ---- */
         const size_t idx_bytes = N * (4 + 8 + 4 + 12 + 8 + 4 + 8 + 4 + 4 + 4) + (size_t)n_waves_all * 56 + 8192;
-        if (idx_bytes + (1u << 20) > c->arena_bytes) return abea_fail(ABEA_ENOMEM, "arena too small for %d index records", n);
-        const size_t budget = c->arena_bytes - idx_bytes - 4096;
+        if (idx_bytes + (1u << 20) > X.scratch_bytes) return abea_fail(ABEA_ENOMEM, "arena too small for %d index records", n);
+        const size_t budget = X.scratch_bytes - idx_bytes - 4096;
         std::vector<int64_t> wave_base, peak_base, kmer_base, seg_base; std::vector<int32_t> wave_len, wave_cap, wave_k, wave_nseg;
         size_t entries = 0, pentries = 0, kentries = 0, segs = 0;
         const size_t EV_SEG = 512, EV_FIXCAP = 48, SEG_BYTES = 64 * (EV_SEG * 2 + EV_FIXCAP * 4 + 12 * 4 + 2 * 8 + 4 * 4);   /* abea_kernels.hip */
@@ -407,12 +446,12 @@ int abea_detect_events_locked(abea_ctx* c, const abea_signal_batch* B) {
             entries += need; pentries += pneed; kentries += kneed; ++w1;
         }
         if (w1 == w0) return abea_fail(ABEA_ENOMEM, "a read of %d samples does not fit the %zu-byte arena",
-                                  B->n_samples[order[(size_t)w0 * 64]], c->arena_bytes);
+                                  B->n_samples[order[(size_t)w0 * 64]], X.scratch_bytes);
         const int nw = w1 - w0;
         const int r0 = w0 * 64, nr = std::min(n - r0, nw * 64);
-        int rc = ensure_pinned((void**)&c->h_desc, &c->h_desc_cap, idx_bytes);
+        int rc = ensure_pinned(X.h_pinned, X.h_cap, idx_bytes);
         if (rc) return rc;
-        uint8_t* h = (uint8_t*)c->h_desc; uint8_t* d = c->arena;
+        uint8_t* h = (uint8_t*)*X.h_pinned; uint8_t* d = X.scratch;
         size_t o = 0;
         auto put = [&](const void* src, size_t sz) { size_t at = o; if (src) memcpy(h + o, src, sz); else memset(h + o, 0, sz);
                                                      o = align_up(o + sz, 16); return at; };
@@ -439,76 +478,79 @@ int abea_detect_events_locked(abea_ctx* c, const abea_signal_batch* B) {
         int32_t* dRec = dFix + segs * EV_FIXCAP * 64;
         double* dSegSum = (double*)(dRec + segs * 12 * 64);
         uint32_t* dSegExp = (uint32_t*)(dSegSum + segs * 2 * 64);
-        HIP_TRY(hipMemcpyAsync(d, h, o, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(hipEventRecord(c->ev[0], c->stream));
+        HIP_TRY(hipMemcpyAsync(d, h, o, hipMemcpyHostToDevice, X.stream));
+        if (X.e0) HIP_TRY(hipEventRecord(X.e0, X.stream));
         /* pass 1: prefix sums by segments where that is provably exact, sequentially otherwise */
         const int max_nseg = *std::max_element(wave_nseg.begin(), wave_nseg.end());
         const dim3 sgrid((unsigned)((max_nseg + 3) / 4), (unsigned)nw);
         const bool seq_only = getenv("ABEA_EV_SEQUENTIAL") != nullptr;
         if (!seq_only) {
-            hipLaunchKernelGGL(abea_ev_psum_kernel, sgrid, dim3(256), 0, c->stream,
+            hipLaunchKernelGGL(abea_ev_psum_kernel, sgrid, dim3(256), 0, X.stream,
                                nr, (const int32_t*)(d + o_order), B->signal, (const int64_t*)(d + o_sig),
                                (const int32_t*)(d + o_ns), (const float*)(d + o_sc), (const int64_t*)(d + o_sb),
                                (const int32_t*)(d + o_wn), dSegSum, dSegExp);
-            hipLaunchKernelGGL(abea_ev_pscan_kernel, dim3((unsigned)nw), dim3(64), 0, c->stream,
+            hipLaunchKernelGGL(abea_ev_pscan_kernel, dim3((unsigned)nw), dim3(64), 0, X.stream,
                                nr, (const int32_t*)(d + o_order), (const int32_t*)(d + o_ns), (const int64_t*)(d + o_sb),
                                dSegSum, dSegExp, (int32_t*)(d + o_need_s));
-            hipLaunchKernelGGL(abea_ev_pwrite_kernel, sgrid, dim3(256), 0, c->stream,
+            hipLaunchKernelGGL(abea_ev_pwrite_kernel, sgrid, dim3(256), 0, X.stream,
                                nr, (const int32_t*)(d + o_order), B->signal, (const int64_t*)(d + o_sig),
                                (const int32_t*)(d + o_ns), (const float*)(d + o_sc), (const int64_t*)(d + o_wb),
                                (const int64_t*)(d + o_sb), (const int32_t*)(d + o_wn), dSegSum,
                                (const int32_t*)(d + o_need_s), dS, dQ);
         }
-        hipLaunchKernelGGL(abea_ev_sums_kernel, dim3((unsigned)nw), dim3(64), 0, c->stream,
+        hipLaunchKernelGGL(abea_ev_sums_kernel, dim3((unsigned)nw), dim3(64), 0, X.stream,
                            nr, (const int32_t*)(d + o_order), B->signal, (const int64_t*)(d + o_sig),
                            (const int32_t*)(d + o_ns), (const float*)(d + o_sc), (const int64_t*)(d + o_wb), dS, dQ,
                            seq_only ? (const int32_t*)nullptr : (const int32_t*)(d + o_need_s));
         const unsigned tiles = (unsigned)std::min<int64_t>(1024, (wave_len[0] + 3) / 4);   /* grid-stride: any tile count covers the wave */
-        hipLaunchKernelGGL(abea_ev_tstat_kernel, dim3(tiles, (unsigned)nw), dim3(256), 0, c->stream,
+        hipLaunchKernelGGL(abea_ev_tstat_kernel, dim3(tiles, (unsigned)nw), dim3(256), 0, X.stream,
                            nr, (const int32_t*)(d + o_order), (const int32_t*)(d + o_ns), (const int64_t*)(d + o_wb),
                            (const int32_t*)(d + o_wl), dS, dQ, dT1, dT2, rna);
         /* pass 3: the automaton over (read, segment) pairs, then the sequential one for reads whose segments never met */
-        hipLaunchKernelGGL(abea_ev_spec_kernel, sgrid, dim3(256), 0, c->stream,
+        hipLaunchKernelGGL(abea_ev_spec_kernel, sgrid, dim3(256), 0, X.stream,
                            nr, (const int32_t*)(d + o_order), (const int32_t*)(d + o_ns), (const int64_t*)(d + o_wb),
                            dT1, dT2, (const int64_t*)(d + o_sb), (const int32_t*)(d + o_wn), dSpec, dRec, rna);
         if (max_nseg > 1)
-            hipLaunchKernelGGL(abea_ev_fix_kernel, dim3((unsigned)((max_nseg - 1 + 3) / 4), (unsigned)nw), dim3(256), 0, c->stream,
+            hipLaunchKernelGGL(abea_ev_fix_kernel, dim3((unsigned)((max_nseg - 1 + 3) / 4), (unsigned)nw), dim3(256), 0, X.stream,
                                nr, (const int32_t*)(d + o_order), (const int32_t*)(d + o_ns), (const int64_t*)(d + o_wb),
                                dT1, dT2, (const int64_t*)(d + o_sb), (const int32_t*)(d + o_wn), dFix, dRec,
                                (int32_t*)(d + o_need), rna);
-        hipLaunchKernelGGL(abea_ev_scan_kernel, dim3((unsigned)nw), dim3(64), 0, c->stream,
+        hipLaunchKernelGGL(abea_ev_scan_kernel, dim3((unsigned)nw), dim3(64), 0, X.stream,
                            nr, (const int32_t*)(d + o_order), (const int32_t*)(d + o_ns), (const int64_t*)(d + o_sb), dRec,
                            B->n_events);
-        hipLaunchKernelGGL(abea_ev_gather_kernel, sgrid, dim3(256), 0, c->stream,
+        hipLaunchKernelGGL(abea_ev_gather_kernel, sgrid, dim3(256), 0, X.stream,
                            nr, (const int32_t*)(d + o_order), (const int32_t*)(d + o_ns), (const int64_t*)(d + o_sb),
                            (const int32_t*)(d + o_wn), dSpec, dFix, dRec, (const int64_t*)(d + o_pb),
                            (const int32_t*)(d + o_ec), dPk);
-        hipLaunchKernelGGL(abea_ev_detect_kernel, dim3((unsigned)nw), dim3(64), 0, c->stream,
+        hipLaunchKernelGGL(abea_ev_detect_kernel, dim3((unsigned)nw), dim3(64), 0, X.stream,
                            nr, (const int32_t*)(d + o_order), (const int32_t*)(d + o_ns), (const int64_t*)(d + o_wb),
                            dT1, dT2, (const int64_t*)(d + o_pb), (const int32_t*)(d + o_ec), dPk, B->n_events,
                            seq_only ? (const int32_t*)nullptr : (const int32_t*)(d + o_need), rna);
         const unsigned etiles = (unsigned)std::min<int64_t>(256, (wave_cap[0] + 3) / 4);
-        hipLaunchKernelGGL(abea_ev_create_kernel, dim3(etiles, (unsigned)nw), dim3(256), 0, c->stream,
+        hipLaunchKernelGGL(abea_ev_create_kernel, dim3(etiles, (unsigned)nw), dim3(256), 0, X.stream,
                            nr, (const int32_t*)(d + o_order), (const int32_t*)(d + o_ns), (const int64_t*)(d + o_wb),
                            dS, dQ, (const int64_t*)(d + o_pb), (const int32_t*)(d + o_wc), dPk, B->n_events,
                            (const int32_t*)(d + o_ec), B->events, (const int64_t*)(d + o_ep), dMean, rna);
         if (B->scalings) {
             const unsigned ktiles = (unsigned)std::min<int64_t>(256, (*std::max_element(wave_k.begin(), wave_k.end()) + 3) / 4);
-            hipLaunchKernelGGL(abea_ev_kmer_kernel, dim3(ktiles, (unsigned)nw), dim3(256), 0, c->stream,
+            hipLaunchKernelGGL(abea_ev_kmer_kernel, dim3(ktiles, (unsigned)nw), dim3(256), 0, X.stream,
                                nr, (const int32_t*)(d + o_order), B->reads, (const int64_t*)(d + o_rp),
                                (const int32_t*)(d + o_rl), c->d_model, (int)c->k, (const int64_t*)(d + o_kb),
                                (const int32_t*)(d + o_wk), dKm);
-            hipLaunchKernelGGL(abea_ev_scalings_kernel, dim3((unsigned)nw), dim3(64), 0, c->stream,
+            hipLaunchKernelGGL(abea_ev_scalings_kernel, dim3((unsigned)nw), dim3(64), 0, X.stream,
                                nr, (const int32_t*)(d + o_order), (const int64_t*)(d + o_pb), dMean, B->n_events,
                                (const int32_t*)(d + o_ec), (const int32_t*)(d + o_rl), (const int64_t*)(d + o_kb), dKm,
                                (int)c->k, B->scalings);
         }
-        HIP_TRY(hipEventRecord(c->ev[1], c->stream));
+        if (X.e1) HIP_TRY(hipEventRecord(X.e1, X.stream));
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (X.async) {
+            if (w1 < n_waves_all) return abea_fail(ABEA_ENOMEM, "internal: the detector's scratch for %d reads does not fit %zu bytes at once", n, X.scratch_bytes);
+            return ABEA_OK;
+        }
+        HIP_TRY(hipStreamSynchronize(X.stream));
         float ms = 0;
-        HIP_TRY(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
-        c->stats.event_ms += ms;
+        if (X.e0 && X.e1) { HIP_TRY(hipEventElapsedTime(&ms, X.e0, X.e1)); c->stats.event_ms += ms; }
         w0 = w1;
     }
     return ABEA_OK;

@@ -48,6 +48,8 @@ typedef struct {
     int32_t* nalign;                    /* [out_idx] n_event_alignment */
     uint8_t* kcnt;                      /* optional: events of every k-mer's map entry (stop - start + 1, 0 = {-1,-1}, 255 = more),
                                            at kcnt[desc.kmer_off + k]: the form in which the host entry takes the map over PCIe */
+    double* var_f64;                    /* optional [out_idx]: recalibrate_model's var in double when the read was recalibrated, -1 otherwise:
+                                           the host entries set scalings_t.log_var = (float)log(var) from it with glibc (align.c:760) */
     int32_t kmer_size, min_rescale;
 } abea_fused_scaling;
 

@@ -264,7 +264,7 @@ struct abea_host_slot {
     std::vector<int32_t> rd;                            /* caller index of descriptor j */
     bool scaling = false, device_pairs = false, staged = false;
     size_t o_np = 0, o_diag = 0, o_codes = 0, o_poff = 0, o_cursor = 0, o_pairs = 0;      /* offsets in `dn` */
-    size_t o_sc = 0, o_epb = 0, o_flag = 0, o_nal = 0, o_cnt = 0;
+    size_t o_sc = 0, o_epb = 0, o_flag = 0, o_nal = 0, o_cnt = 0, o_var = 0;
     abea_pair_t* d_pairs = nullptr;                     /* device-pairs mode: compacted lists to copy at stage A */
     size_t pair_cap = 0;
 };
@@ -618,6 +618,8 @@ struct host_opts {
     int n_slots;
     bool device_pairs;
     bool sdma_d2h;             /* experiment: return the result block with hipMemcpyAsync instead of the copy-out kernel */
+    int flatten_prefetch;      /* bytes the flatten loop prefetches ahead of its loads (0 = none) */
+    int flatten_hint;          /* 0 = prefetchnta, 1 = prefetcht0, 2 = prefetcht2 */
 };
 
 static host_opts read_opts() {
@@ -629,6 +631,9 @@ static host_opts read_opts() {
     if (const char* e = getenv("ABEA_HOST_SLOTS")) o.n_slots = std::min(ABEA_MAX_SLOTS, std::max(1, atoi(e)));
     if (const char* e = getenv("ABEA_HOST_PAIRS")) o.device_pairs = strcmp(e, "device") == 0;
     o.sdma_d2h = getenv("ABEA_HOST_SDMA_D2H") != nullptr;
+    o.flatten_prefetch = 1536; o.flatten_hint = 0;
+    if (const char* e = getenv("ABEA_HOST_FLATTEN_PREFETCH")) o.flatten_prefetch = std::max(0, std::min(1 << 16, atoi(e)));
+    if (const char* e = getenv("ABEA_HOST_FLATTEN_HINT")) o.flatten_hint = std::max(0, std::min(2, atoi(e)));
     o.chunk_reads_max = std::max(o.chunk_reads_max, o.chunk_reads_min);
     return o;
 }
@@ -641,7 +646,7 @@ static size_t chunk_io_bytes(const plan_read& r, bool pairs_on_device, bool scal
     size_t b = align_up((size_t)r.L + 1, 16) + 4 + sizeof(abea_read_diag) + 8;
     if (pairs_on_device) b += ((size_t)r.E + (size_t)r.L) * sizeof(abea_pair_t);
     /* map (device scratch) + per-read scalars */
-    if (scaling) b += (size_t)r.K * (sizeof(abea_index_pair_t) + 1) + sizeof(abea_scalings_t) + 8 + 4 + 4 + 4;   /* + one count byte per k-mer */
+    if (scaling) b += (size_t)r.K * (sizeof(abea_index_pair_t) + 1) + sizeof(abea_scalings_t) + 8 + 8 + 4 + 4 + 4;   /* + one count byte per k-mer */
     return b + 64;
 }
 
@@ -676,13 +681,30 @@ static std::vector<chunk_span> carve_chunks(const std::vector<plan_read>& reads,
     return out;
 }
 
-/* longest first, ties in caller order: sort packed (band count, inverted position) keys, no indirection */
+/* longest first (band count), ties in caller order.  `order` arrives in ascending caller order; a stable LSD radix sort on the
+ * complemented band count (four 7-bit digits cover ABEA_MAX_BANDS = 2^27) keeps it for equal keys.  0.6 ms for 100 k reads
+ * where std::sort of packed keys took 7 ms of the caller's thread before the first chunk could be cut (round 5). */
 static void order_longest_first(const std::vector<plan_read>& reads, std::vector<int32_t>& order) {
-    std::vector<uint64_t> key(order.size());
-    for (size_t t = 0; t < order.size(); ++t)
-        key[t] = ((uint64_t)reads[(size_t)order[t]].n_bands << 32) | (uint32_t)(0xFFFFFFFFu - (uint32_t)order[t]);
-    std::sort(key.begin(), key.end(), std::greater<uint64_t>());
-    for (size_t t = 0; t < order.size(); ++t) order[t] = (int32_t)(0xFFFFFFFFu - (uint32_t)key[t]);
+    const size_t n = order.size();
+    if (n < 2) return;
+    std::vector<uint32_t> key(n), key2(n);
+    std::vector<int32_t> ord2(n);
+    for (size_t t = 0; t < n; ++t)
+        key[t] = (uint32_t)(ABEA_MAX_BANDS - std::min<int64_t>(ABEA_MAX_BANDS, std::max<int64_t>(0, reads[(size_t)order[t]].n_bands)));
+    uint32_t* k_in = key.data(); uint32_t* k_out = key2.data();
+    int32_t* o_in = order.data(); int32_t* o_out = ord2.data();
+    for (int pass = 0; pass < 4; ++pass) {                  /* 4 x 7 bits = 28 bits >= log2(2^27 + 1) */
+        const int sh = pass * 7;
+        size_t cnt[129] = {0};
+        for (size_t t = 0; t < n; ++t) ++cnt[((k_in[t] >> sh) & 127u) + 1];
+        for (int b = 0; b < 128; ++b) cnt[b + 1] += cnt[b];
+        for (size_t t = 0; t < n; ++t) {
+            const size_t at = cnt[(k_in[t] >> sh) & 127u]++;
+            k_out[at] = k_in[t]; o_out[at] = o_in[t];
+        }
+        std::swap(k_in, k_out); std::swap(o_in, o_out);
+    }
+    /* four passes: the result is back in `order` */
 }
 
 /* The chunk plan abea_align_batch_host would use for these reads on an arena of `arena_bytes` (pairs returned through
@@ -714,6 +736,47 @@ extern "C" int abea_host_plan_chunks(const int32_t* read_len, const int32_t* n_e
     return ABEA_OK;
 }
 
+/* ------------------------------------------------------------------ flatten: event_t.mean -> float array */
+/* 4 of event_t's 24 bytes are wanted, but every cache line of the table crosses the memory bus: the loop is bound by how many
+ * line fills one core keeps in flight (16 GB/s per thread measured in situ on the MI355X host against 23-32 GB/s for one thread
+ * alone; 14 threads is all a 16-CPU quota leaves).  Eight events (three lines) per iteration with a software prefetch per line
+ * `pf` bytes ahead of the loads; non-temporal 16-byte stores (the staging block is written once and read by the DMA engine only;
+ * dst is 16-byte aligned: evm_off is a multiple of 4 floats). */
+template <int HINT>
+static inline void flatten_means_t(const abea_event_t* evs, int32_t E, float* dst, int pf) {
+    const char* base = reinterpret_cast<const char*>(evs);
+    const char* const last = base + (size_t)E * sizeof(abea_event_t) - 1;
+    int32_t e = 0;
+    if (pf > 0) {
+        for (; e + 8 <= E; e += 8) {
+            const char* p = base + (size_t)e * sizeof(abea_event_t) + pf;           /* 192 B per iteration = three lines */
+            if (p + 191 <= last) {
+                __builtin_prefetch(p, 0, HINT); __builtin_prefetch(p + 64, 0, HINT); __builtin_prefetch(p + 128, 0, HINT);
+            }
+            _mm_stream_ps(dst + e, _mm_set_ps(evs[e + 3].mean, evs[e + 2].mean, evs[e + 1].mean, evs[e].mean));
+            _mm_stream_ps(dst + e + 4, _mm_set_ps(evs[e + 7].mean, evs[e + 6].mean, evs[e + 5].mean, evs[e + 4].mean));
+        }
+    }
+    for (; e + 4 <= E; e += 4)
+        _mm_stream_ps(dst + e, _mm_set_ps(evs[e + 3].mean, evs[e + 2].mean, evs[e + 1].mean, evs[e].mean));
+    for (; e < E; ++e) dst[e] = evs[e].mean;
+}
+static inline void flatten_means(const abea_event_t* evs, int32_t E, float* dst, int pf, int hint) {
+    /* __builtin_prefetch locality: 0 = prefetchnta, 3 = prefetcht0, 1 = prefetcht2 */
+    if (hint == 1) flatten_means_t<3>(evs, E, dst, pf);
+    else if (hint == 2) flatten_means_t<1>(evs, E, dst, pf);
+    else flatten_means_t<0>(evs, E, dst, pf);
+}
+
+/* host-only entry over the same loop (unit tests, tools/probe/flatten_ab.cpp): means[e] = events[e].mean */
+extern "C" int abea_flatten_event_means(const abea_event_t* events, int32_t n_events, float* means, int32_t prefetch_bytes, int32_t hint) {
+    if (n_events < 0 || (n_events && (!events || !means)) || (reinterpret_cast<uintptr_t>(means) & 15u))
+        return abea_fail(ABEA_EINVAL, "abea_flatten_event_means: bad argument (means must be 16-byte aligned)");
+    flatten_means(events, n_events, means, std::max(0, prefetch_bytes), hint);
+    _mm_sfence();
+    return ABEA_OK;
+}
+
 /* ------------------------------------------------------------------ the pipeline on one device */
 struct host_run_state {
     double t_origin = 0; bool trace = false;
@@ -723,6 +786,7 @@ struct host_run_state {
     abea_ctx* c;
     abea_host_lane* lane;
     const abea_host_batch* H;
+    hipEvent_t origin = nullptr;          /* ABEA_HOST_TRACE: GPU clock origin of the call (recorded on the idle context stream) */
     host_opts opt;
     bool want_pairs, scaling, device_pairs;
     abea_stats st;
@@ -768,6 +832,7 @@ static int slot_retire(host_run_state& S, abea_host_slot& sl) {
     const double* epb = (const double*)(sl.dn + sl.o_epb);
     const int32_t* flag = (const int32_t*)(sl.dn + sl.o_flag);
     const int32_t* nal = (const int32_t*)(sl.dn + sl.o_nal);
+    const double* var64 = (const double*)(sl.dn + sl.o_var);
     const uint8_t* kcnt = (const uint8_t*)(sl.dn + sl.o_cnt);
     t0 = abea_now_ms();
     const bool want_pairs = S.want_pairs, dev_pairs = sl.device_pairs, scaling = sl.scaling;
@@ -787,7 +852,11 @@ static int slot_retire(host_run_state& S, abea_host_slot& sl) {
                 if (np > 0 && H->base_to_event_map[i] &&
                     !expand_counts_to_map(kcnt + descs[j].kmer_off, descs[j].n_kmers, diag[j].best_event, H->base_to_event_map[i]))
                     expand_codes_to_map(codes + descs[j].code_off, np, descs[j].n_kmers - 1, diag[j].best_event, H->base_to_event_map[i]);
-                if (H->scalings_out) H->scalings_out[i] = sc[j];
+                if (H->scalings_out) {
+                    abea_scalings_t o = sc[j];
+                    if (var64[j] >= 0.0) o.log_var = (float)log(var64[j]);      /* align.c:758-760 (CACHED_LOG): double log, glibc's */
+                    H->scalings_out[i] = o;
+                }
                 if (H->events_per_base) H->events_per_base[i] = epb[j];
                 if (H->read_stat_flag) H->read_stat_flag[i] = flag[j];
                 if (H->n_event_alignment) H->n_event_alignment[i] = nal[j];
@@ -797,6 +866,12 @@ static int slot_retire(host_run_state& S, abea_host_slot& sl) {
     S.st.unflatten_ms += abea_now_ms() - t0;
     S.log("retired", sl.chunk_no);
     float ms = 0;
+    if (S.trace && S.origin) {            /* the chunk's kernels on the GPU's clock: start of align-pre, start and end of the alignment kernel */
+        float a = 0, b = 0, e = 0;
+        if (hipEventElapsedTime(&a, S.origin, sl.k0) == hipSuccess && hipEventElapsedTime(&b, S.origin, sl.k1) == hipSuccess &&
+            hipEventElapsedTime(&e, S.origin, sl.k2) == hipSuccess)
+            fprintf(stderr, "[abea host dev %d] gpu chunk %2d  pre %9.3f  align %9.3f .. %9.3f ms  reads %d\n", S.c->device, sl.chunk_no, a, b, e, sl.m);
+    }
     HIP_TRY(hipEventElapsedTime(&ms, sl.k0, sl.k1)); S.st.pre_ms += ms;
     HIP_TRY(hipEventElapsedTime(&ms, sl.k1, sl.k2)); S.st.fill_ms += ms;
     for (int32_t j = 0; j < sl.m; ++j) S.st.sum_pairs += npairs[j];
@@ -876,6 +951,10 @@ static int host_run(abea_ctx* c, const abea_host_batch* H, const int32_t* mine, 
         c->slots[(size_t)q]->busy = false;                       /* nothing survives a call (slot_guard) */
     }
     slot_guard guard{c, &lane};
+    if (S.trace && hipEventRecord(c->ev[0], c->stream) == hipSuccess && hipEventSynchronize(c->ev[0]) == hipSuccess) {
+        S.origin = c->ev[0];
+        S.t_origin = abea_now_ms();                              /* host and GPU clocks share (to ~20 us) this origin */
+    }
     uint8_t* const lane_arena = c->arena + lane.arena_off;
     auto slot_at = [&](int q) -> abea_host_slot& { return *c->slots[(size_t)(slot0 + q)]; };
 
@@ -922,6 +1001,7 @@ static int host_run(abea_ctx* c, const abea_host_batch* H, const int32_t* mine, 
     const int min_rescale = H->min_num_events_to_rescale > 0 ? H->min_num_events_to_rescale : 200;
 
     const std::vector<chunk_span> chunks = carve_chunks(S.reads, order, S.opt, slot_arena, pairs_on_device, scaling);
+    S.st.setup_ms = abea_now_ms() - t_start;
     int turn = 0;
     for (int chunk_no = 0; chunk_no < (int)chunks.size(); ++chunk_no) {
         const size_t pos = chunks[(size_t)chunk_no].begin, end = chunks[(size_t)chunk_no].end, ev = chunks[(size_t)chunk_no].events;
@@ -963,7 +1043,7 @@ static int host_run(abea_ctx* c, const abea_host_batch* H, const int32_t* mine, 
                 sl.rd[(size_t)j] = r.idx;
                 const int32_t caller = r.idx;
                 r.idx = j;                                 /* out_idx = position in the chunk */
-                plan_desc(descs[j], r, H->scalings[caller], lay, S.st);
+                plan_desc_layout(descs[j], r, H->scalings[caller], lay, S.st);   /* the log-probabilities: in the flatten loop */
                 descs[j].read_off = (int64_t)ro; ro += align_up((size_t)r.L + 1, 16);
                 descs[j].pair_off = (int64_t)po; po += (size_t)r.E + (size_t)r.L;
                 descs[j].kmer_off = (int64_t)ko;
@@ -981,6 +1061,7 @@ static int host_run(abea_ctx* c, const abea_host_batch* H, const int32_t* mine, 
         sl.o_epb = o;     if (scaling) o = align_up(o + (size_t)m * 8, 256);
         sl.o_flag = o;    if (scaling) o = align_up(o + (size_t)m * 4, 256);
         sl.o_nal = o;     if (scaling) o = align_up(o + (size_t)m * 4, 256);
+        sl.o_var = o;     if (scaling) o = align_up(o + (size_t)m * 8, 256);
         sl.o_cnt = o;     if (scaling) o = align_up(o + n_kmer, 256);   /* events per k-mer, one byte each: the map as it crosses PCIe */
         const size_t dn_copy = o;                         /* one D2H copy of [0, dn_copy) */
         sl.o_pairs = o;   if (S.device_pairs) o = align_up(o + n_pair * sizeof(abea_pair_t), 256);
@@ -1017,22 +1098,19 @@ static int host_run(abea_ctx* c, const abea_host_batch* H, const int32_t* mine, 
         char* h_reads = (char*)(sl.up + u_reads);
         float* h_evm = (float*)(sl.up + u_evm);
         S.log("flatten", chunk_no);
+        const int pf = S.opt.flatten_prefetch, pf_hint = S.opt.flatten_hint;
+        S.st.plan_ms += abea_now_ms() - t0;
+        t0 = abea_now_ms();
         lane.pool->run(m, 1, [&](int64_t lo, int64_t hi) {
             for (int64_t j = lo; j < hi; ++j) {
+                plan_desc_consts(descs[j]);                 /* align.c:207-216: four libm calls per read, off the caller's serial path */
                 const abea_read_desc& d = descs[j];
                 const int32_t i = sl.rd[(size_t)j];
                 const size_t L = (size_t)d.read_len;
                 memcpy(h_reads + d.read_off, H->read[i], L);
                 h_reads[d.read_off + (int64_t)L] = '\0';
-                /* event means: 4 of event_t's 24 bytes; non-temporal stores (the staging block is written once and
-                 * read by the DMA engine only; dst is 16-byte aligned: evm_off is a multiple of 4 floats) */
-                const abea_event_t* evs = H->events[i];
-                float* dst = h_evm + d.evm_off;
-                const int32_t E = d.n_events;
-                int32_t e = 0;
-                for (; e + 4 <= E; e += 4)
-                    _mm_stream_ps(dst + e, _mm_set_ps(evs[e + 3].mean, evs[e + 2].mean, evs[e + 1].mean, evs[e].mean));
-                for (; e < E; ++e) dst[e] = evs[e].mean;
+                /* event means: 4 of event_t's 24 bytes (align.c:131 reads nothing else) */
+                flatten_means(H->events[i], d.n_events, h_evm + d.evm_off, pf, pf_hint);
             }
             _mm_sfence();
         });
@@ -1067,6 +1145,7 @@ static int host_run(abea_ctx* c, const abea_host_batch* H, const int32_t* mine, 
             fs.sc_io = (abea_scalings_t*)(d_dn + sl.o_sc); fs.epb = (double*)(d_dn + sl.o_epb);
             fs.flag_io = (int32_t*)(d_dn + sl.o_flag); fs.nalign = (int32_t*)(d_dn + sl.o_nal);
             fs.kcnt = (uint8_t*)(d_dn + sl.o_cnt);
+            fs.var_f64 = (double*)(d_dn + sl.o_var);
             fs.kmer_size = (int32_t)c->k; fs.min_rescale = min_rescale;
         }
         hipLaunchKernelGGL(abea_align_kernel, dim3((unsigned)m), dim3(64), 0, sl.stream,
@@ -1131,6 +1210,7 @@ static void stats_add(abea_stats& a, const abea_stats& b) {
     a.pre_ms = std::max(a.pre_ms, b.pre_ms); a.fill_ms = std::max(a.fill_ms, b.fill_ms); a.trace_ms = std::max(a.trace_ms, b.trace_ms);
     a.host_ms = std::max(a.host_ms, b.host_ms); a.flatten_ms = std::max(a.flatten_ms, b.flatten_ms);
     a.unflatten_ms = std::max(a.unflatten_ms, b.unflatten_ms); a.wait_ms = std::max(a.wait_ms, b.wait_ms);
+    a.plan_ms = std::max(a.plan_ms, b.plan_ms); a.setup_ms = std::max(a.setup_ms, b.setup_ms);
     a.n_reads_gpu += b.n_reads_gpu; a.n_reads_skipped += b.n_reads_skipped; a.n_sub_batches += b.n_sub_batches;
     a.sum_events += b.sum_events; a.sum_bands += b.sum_bands; a.sum_pairs += b.sum_pairs; a.fill_launches += b.fill_launches;
     a.arena_bytes += b.arena_bytes; a.bytes_ref += b.bytes_ref; a.bytes_min += b.bytes_min; a.bytes_moved += b.bytes_moved;

@@ -38,7 +38,7 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 /* ------------------------------------------------------------------ context */
 struct abea_host_pool;      /* abea_host.cpp: persistent host worker threads */
 struct abea_host_async;     /* abea_host.cpp: lanes (slot set + arena share + pool) and the batches in flight */
-static const int ABEA_MAX_SLOTS = 8;        /* stream slots per device context */
+static const int ABEA_MAX_SLOTS = 16;       /* stream slots per device context (8 are used unless ABEA_HOST_SLOTS asks for more) */
 struct abea_host_slot;      /* abea_host.cpp: one chunk in flight (stream, pinned staging, arena share) */
 struct abea_hmm_state;      /* abea_hmm.cpp: log-sum table, CpG model copy, staging of the profile-HMM entry (row N4) */
 
@@ -81,6 +81,16 @@ int abea_host_batches_in_flight(abea_ctx* c);   /* abea_host.cpp: submitted and 
     if (abea_host_batches_in_flight(c)) return abea_fail(ABEA_EBUSY, name ": submitted host batches are still in flight")
 /* bodies of public entries for callers that already hold the context (abea_process.cpp chains them) */
 int abea_detect_events_locked(abea_ctx* c, const abea_signal_batch* B);            /* abea_capi.cpp */
+/* where and how the detector's kernels of one signal batch run (abea_capi.cpp: abea_detect_events_on) */
+struct abea_ev_exec {
+    hipStream_t stream; uint8_t* scratch; size_t scratch_bytes;
+    void** h_pinned; size_t* h_cap;        /* pinned staging of the index records (grown on demand) */
+    bool async;                            /* true: one pass, no synchronisation (ABEA_ENOMEM when the scratch is too small) */
+    hipEvent_t e0, e1;                     /* optional: recorded before / after the kernels */
+};
+int abea_detect_events_on(abea_ctx* c, const abea_signal_batch* B, const abea_ev_exec& X);
+/* scratch bytes abea_detect_events_on needs for reads of these lengths in ONE pass (upper bound; the same arithmetic) */
+size_t abea_detect_scratch_bytes(const int32_t* n_samples, const int32_t* event_cap, const int32_t* n_kmers, int32_t n);
 int abea_host_batch_locked(abea_ctx* c, const abea_host_batch* H);                 /* abea_host.cpp */
 int abea_device_numa_node(int device);      /* abea_host.cpp: sysfs numa_node of a HIP device's PCI function */
 
@@ -117,8 +127,16 @@ static inline size_t scratch_bytes(const plan_read& r) {
 /* element counts of one launch's scratch arrays */
 struct sub_layout { size_t n_kpar = 0, n_evm = 0, n_code = 0, n_trace = 0; };
 
-/* Descriptor of one read and its place in the launch's scratch; the caller sets read_off/event_off/pair_off/kmer_off. */
-void plan_desc(abea_read_desc& d, const plan_read& r, const abea_scalings_t& sc, sub_layout& lay, abea_stats& st);
+/* Descriptor of one read and its place in the launch's scratch; the caller sets read_off/event_off/pair_off/kmer_off.
+ * plan_desc = plan_desc_layout (offsets and accounting: integer work, serial because every read's offsets follow the
+ * previous read's) + plan_desc_consts (the per-read log-probabilities of align.c:207-216: four glibc log/exp calls, the
+ * expensive part, independent per read — the host entry computes them inside its parallel flatten loop). */
+void plan_desc_layout(abea_read_desc& d, const plan_read& r, const abea_scalings_t& sc, sub_layout& lay, abea_stats& st);
+void plan_desc_consts(abea_read_desc& d);
+static inline void plan_desc(abea_read_desc& d, const plan_read& r, const abea_scalings_t& sc, sub_layout& lay, abea_stats& st) {
+    plan_desc_layout(d, r, sc, lay, st);
+    plan_desc_consts(d);
+}
 
 int ensure_pinned(void** p, size_t* cap, size_t need);
 

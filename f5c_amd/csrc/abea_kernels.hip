@@ -168,6 +168,7 @@ static __device__ __forceinline__ abea_index_pair_t load_map_l2(const abea_index
 static __device__ void abea_fused_not_aligned(const abea_fused_scaling& fs, int out_idx, int lane) {
     if (lane == 0) {                                     /* f5c.c:786-794: could not align */
         fs.flag_io[out_idx] |= ABEA_FAILED_ALIGNMENT; fs.epb[out_idx] = 0.0; fs.nalign[out_idx] = 0;
+        if (fs.var_f64) fs.var_f64[out_idx] = -1.0;
     }
 }
 
@@ -263,8 +264,9 @@ static __device__ void abea_scaling_single_wave(const abea_read_desc* d, const a
         const bool calibrated = n_M >= fs.min_rescale;
         int flag = 0;
         float fvar = fs.sc_io[out_idx].var;
+        double var = -1.0;
         if (calibrated) {
-            double var = acc / n_M;                       /* align.c:752-753 */
+            var = acc / n_M;                              /* align.c:752-753 */
             var = sqrt(var);
             abea_scalings_t o = fs.sc_io[out_idx];
             o.shift = (float)shift; o.scale = (float)scale; o.var = (float)var;
@@ -276,6 +278,7 @@ static __device__ void abea_scaling_single_wave(const abea_read_desc* d, const a
         fs.flag_io[out_idx] |= flag;
         fs.epb[out_idx] = events_per_base;
         fs.nalign[out_idx] = n_align;
+        if (fs.var_f64) fs.var_f64[out_idx] = var;      /* align.c:760: log_var = log(var) in double, glibc's: done by the host */
     }
 }
 

@@ -108,8 +108,9 @@ typedef struct {
      *      tile the path's events in k order), and 36 B of scalars per read.  All NULL = alignment only. ---- */
     abea_index_pair_t* const* base_to_event_map;   /* db->base_to_event_map[i]: caller-allocated, read_len-k+1 entries;
                                                       written only for reads with n_pairs > 0 (the reference leaves NULL otherwise) */
-    abea_scalings_t* scalings_out;         /* [n_reads] db->scalings[i] after recalibration (input copied when not recalibrated;
-                                              log_var untouched) ; may alias `scalings` */
+    abea_scalings_t* scalings_out;         /* [n_reads] db->scalings[i] after recalibration: shift, scale, var and log_var = (float)log(var)
+                                              (double var, glibc log: align.c:758-760, CACHED_LOG) of a recalibrated read; the input
+                                              copied unchanged otherwise ; may alias `scalings` */
     double*  events_per_base;              /* [n_reads] db->events_per_base[i] */
     int32_t* read_stat_flag;               /* [n_reads] in/out: ABEA_FAILED_* bits OR-ed in (src/f5c.h:66-68) */
     int32_t* n_event_alignment;            /* [n_reads] db->n_event_alignment[i] */
@@ -333,6 +334,8 @@ typedef struct {
     double wait_ms;                       /* time the calling thread spent waiting for the GPU */
     uint64_t h2d_bytes, d2h_bytes;        /* PCIe traffic of the call */
     int32_t n_devices, host_threads;
+    double plan_ms, setup_ms;             /* caller-thread time that is neither loop nor wait: per-chunk layout (plan) and the
+                                             guards + ordering + chunk carving before the first chunk (setup) */
 } abea_stats;
 int abea_get_stats(abea_ctx* ctx, abea_stats* out);
 /* Multi-device context: the share of the last host batch that ran on device_ids[device]; abea_get_stats() gives the
@@ -355,6 +358,10 @@ int abea_expand_walk_codes_to_map(const uint32_t* codes, int32_t n_steps, int32_
  * ending at end_event, so the counts determine the map.  A count of 255 means "255 or more" and is refused here (the host entry
  * rebuilds such a read's map from the walk).  Host-only. */
 int abea_expand_kmer_counts_to_map(const uint8_t* count, int32_t n_kmers, int32_t end_event, abea_index_pair_t* map);
+/* The flatten loop of the host entry on its own (host-only): means[e] = events[e].mean for e < n_events — 4 of event_t's 24
+ * bytes, the only field align() reads (src/align.c:131).  means must be 16-byte aligned (non-temporal stores);
+ * prefetch_bytes = distance of the software prefetch ahead of the loads (0 = none), hint 0 / 1 / 2 = nta / t0 / t2. */
+int abea_flatten_event_means(const abea_event_t* events, int32_t n_events, float* means, int32_t prefetch_bytes, int32_t hint);
 /* The chunk plan abea_align_batch_host() uses for a batch on an arena of arena_bytes (host-only; pairs returned, no
  * fused scaling): chunk_of[i] = launch-order number of the chunk read i goes into, -1 for reads skipped by the
  * align_single guards (src/f5c.c:813-814).  Reads go longest first; a chunk holds >= 2048 reads and >= 48 M events (the

@@ -104,8 +104,8 @@ int main(int argc, char** argv) {
     fclose(f);
     f = open_out(out, ".state", "w");
     for (int32_t i = 0; i < n; ++i)
-        fprintf(f, "%d\t%d\t%d\t%a\t%a\t%a\t%a\t%d\n", i, flag[i], nal[i], epb[i], (double)sc[i].shift, (double)sc[i].scale,
-                (double)sc[i].var, n_pairs[i]);
+        fprintf(f, "%d\t%d\t%d\t%a\t%a\t%a\t%a\t%d\t%a\n", i, flag[i], nal[i], epb[i], (double)sc[i].shift, (double)sc[i].scale,
+                (double)sc[i].var, n_pairs[i], (double)sc[i].log_var);
     fclose(f);
     f = open_out(out, ".pairs", "w");                        /* f5c.c:989-1006 */
     for (int32_t i = 0; i < n; ++i) {

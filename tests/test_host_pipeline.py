@@ -276,7 +276,11 @@ def test_fused_scaling_single_through_the_host_entry(ctx, orc, r9, monkeypatch, 
                 assert sc["scalings"]["shift"][i] == r["scalings"]["shift"]
                 assert sc["scalings"]["scale"][i] == r["scalings"]["scale"]
                 assert sc["scalings"]["var"][i] == r["scalings"]["var"]
+                # align.c:758-760 (CACHED_LOG): log_var = (float)log(double var) — round-4 advisor finding: it stayed log(1) = 0
+                assert sc["scalings"]["log_var"][i] == r["scalings"]["log_var"] != 0
                 n_cal += 1
+            else:
+                assert sc["scalings"]["log_var"][i] == batch["scalings"]["log_var"][i]
         else:
             assert (m == -1).all()                            # untouched: the reference leaves NULL there
             assert sc["scalings"]["scale"][i] == batch["scalings"]["scale"][i]
@@ -547,6 +551,7 @@ def test_fused_map_with_kmers_of_255_and_more_events(ctx, orc, r9):
         assert (m[:, 0] == r["base_to_event_map"]["start"]).all() and (m[:, 1] == r["base_to_event_map"]["stop"]).all(), i
         assert sc["read_stat_flag"][i] == r["flag"] and sc["events_per_base"][i] == r["events_per_base"]
         assert sc["scalings"]["shift"][i] == r["scalings"]["shift"] and sc["scalings"]["var"][i] == r["scalings"]["var"]
+        assert sc["scalings"]["log_var"][i] == r["scalings"]["log_var"]
         bm = r["base_to_event_map"]
         most.append(int(np.where(bm["start"] >= 0, bm["stop"] - bm["start"] + 1, 0).max()))
     assert max(most) >= 500 and sum(c >= 255 for c in most) >= 2 and sum(200 < c < 255 for c in most) >= 1, most

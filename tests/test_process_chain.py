@@ -113,6 +113,7 @@ def test_cpp_process_chain_on_real_reads(tmp_path, orc, r9):
         assert float.fromhex(st[3]) == rec["events_per_base"]
         assert (np.float32(float.fromhex(st[4])), np.float32(float.fromhex(st[5])), np.float32(float.fromhex(st[6]))) == \
                (sc["shift"], sc["scale"], sc["var"])
+        assert np.float32(float.fromhex(st[8])) == sc["log_var"]           # align.c:758-760: what the HMM stage reads (hmm.c:101)
         m = rec["base_to_event_map"]
         assert b2e[i] == "".join("%d,%d " % (a, b) for a, b in zip(m["start"], m["stop"]))
         gn = r["ada_printed"].split()[1]

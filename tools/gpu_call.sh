@@ -1,0 +1,49 @@
+#!/bin/bash
+# Round-5 GPU calls, one parameterised script (replaces the per-call tools/r04_call_*.sh one-offs):
+#   gpurun --timeout T -- 'bash tools/gpu_call.sh <stage> [tag]'
+# Every step runs under its own `timeout -k 10` (TERM to the process group, KILL 10 s later: a hung kernel or profiler
+# must not hold the box).  Output: gpurun_out/<tag>/ ; what is to be judged is copied into profiles/r05/ afterwards.
+cd /tmp && export TMPDIR=/tmp
+cd $GRAFT_REPO_ROOT
+STAGE=${1:-sweep}; TAG=${2:-r05_$STAGE}
+O=gpurun_out/$TAG; mkdir -p $O
+step() {   # name, timeout, command ...
+  local name=$1 to=$2; shift 2
+  local t0=$(date +%s)
+  timeout -k 10 $to "$@" > $O/$name.log 2>&1
+  echo "$name rc=$? $(( $(date +%s) - t0 )) s" >> $O/steps.txt
+}
+case $STAGE in
+  sweep)      # host-entry settings on ONE generated batch + the flatten loop alone + the changed host code against the oracle
+    step t_host 400 python -m pytest tests/test_host_pipeline.py -m gpu -x -q -k "not torchrun and not two_ranks"
+    tail -3 $O/t_host.log
+    step sweep 700 python tools/host_sweep.py --out $O ${SWEEP_ARGS:-}
+    grep -v "^first-touch\|^interleave" $O/sweep.log | tail -40
+    ;;
+  hwq)        # the same sweep under GPU_MAX_HW_QUEUES = 8 / 16 / 24 (read by the HIP runtime at initialisation: one process each)
+    step t_changed 400 python -m pytest tests/test_host_pipeline.py tests/test_process_chain.py tests/test_rna_events.py -m gpu -x -q -k "not torchrun and not two_ranks"
+    tail -3 $O/t_changed.log
+    for q in ${HWQS:-8 16 24}; do
+      GPU_MAX_HW_QUEUES=$q step sweep_q$q 400 python tools/host_sweep.py --out $O/q$q --no-flatten-probe --steps 3 --only ${ONLY:-base,slots16,chunk24M_slots16,chunk96M,chunk96M_slots16,rmin512,rmin512_slots16,fused_base,fused_slots16,fused_rmin512_slots16,base_again}
+      grep '"name"' $O/sweep_q$q.log | python3 -c "
+import sys, json
+for ln in sys.stdin:
+    r = json.loads(ln); print('q$q %-24s %7.1f ms  flat %6.1f unfl %5.1f wait %6.1f plan %4.1f  fill_sum %7.1f' % (r['name'], r['ms_per_step'], r['flatten_ms'], r['unflatten_ms'], r['wait_ms'], r['plan_ms'], r['fill_ms']))"
+    done
+    ;;
+  tests)      # the whole GPU suite + the bench line of the build that ships
+    step gpu_tests 900 python -m pytest tests -m gpu -x -q --durations=10
+    tail -16 $O/gpu_tests.log
+    timeout -k 10 420 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?" >> $O/steps.txt
+    tail -c 3000 $O/bench.json
+    ;;
+  quick)      # the GPU suite without the full-size configs
+    step gpu_tests 600 python -m pytest tests -m gpu -x -q --durations=10 --deselect tests/test_full_size.py ${PYTEST_ARGS:-}
+    tail -16 $O/gpu_tests.log
+    ;;
+  cmd)        # an ad-hoc command line (quoted by the caller) under a timeout
+    step cmd ${CMD_TIMEOUT:-600} bash -c "$CMD"
+    tail -40 $O/cmd.log
+    ;;
+esac
+cat $O/steps.txt
