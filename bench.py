@@ -34,6 +34,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+import f5c_amd  # noqa: E402,F401  first: sets GPU_MAX_HW_QUEUES=16 (unless given) before torch initialises the HIP runtime
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (≈6.3 TB/s achievable)
 
@@ -52,6 +53,7 @@ def main():
     ap.add_argument("--device-steps", type=int, default=3, help="device-resident steps (roofline leg)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-small-batch", action="store_true", help="skip the f5c-default-batch (-K 512 -B 2M) measurement")
+    ap.add_argument("--no-process-chain", action="store_true", help="skip the raw-signal chain leg (event_db -> align_db -> scaling_db)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline sample duration")
     ap.add_argument("--arena-gib", type=float, default=150.0, help="cap the scratch arena (the resident batch needs the rest)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -131,7 +133,8 @@ def main():
     if world > 1:
         # one process per GPU on ONE host: the ranks share the host's CPUs (and its cgroup quota), so each rank's
         # flatten / un-flatten pool gets its share instead of the library default (usable CPUs - 2 per process)
-        os.environ.setdefault("ABEA_HOST_THREADS", str(max(2, (effective_cpus() - 2) // world)))
+        # (each rank's HIP runtime adds ~2 busy threads of its own: a pool as wide as quota / world gets the whole cgroup throttled)
+        os.environ.setdefault("ABEA_HOST_THREADS", str(max(1, effective_cpus() // world - 2)))
     n_dev = args.gpus if args.single_process else 1
     dev_ids = ([0] * n_dev if args.one_device else list(range(n_dev))) if args.single_process else None
     ctx = abea.AbeaContext(model, k, device_id=local_rank, verbosity=0, device_ids=dev_ids,
@@ -152,8 +155,9 @@ def main():
         for _ in range(args.warmup):
             ctx.align_view(view)
         sync()
+        cg0 = cgroup_cpu_stat()
         t0 = time.perf_counter()
-        acc = dict(flatten_ms=0.0, unflatten_ms=0.0, wait_ms=0.0, pre_ms=0.0, fill_ms=0.0)
+        acc = dict(flatten_ms=0.0, unflatten_ms=0.0, wait_ms=0.0, pre_ms=0.0, fill_ms=0.0, plan_ms=0.0, setup_ms=0.0, gpu_busy_ms=0.0)
         for _ in range(args.steps):
             ctx.align_view(view)
             st = ctx.stats()
@@ -161,6 +165,7 @@ def main():
                 acc[key] += st[key]
         sync()
         elapsed = time.perf_counter() - t0
+        cg1 = cgroup_cpu_stat()
         host_stats = ctx.stats()
         host_n_pairs = view["n_pairs"].copy()
     # ================================================================ device-resident leg (not in the timed region)
@@ -246,7 +251,12 @@ def main():
                 "ms_per_step": round(elapsed / args.steps * 1e3, 2),
                 "host_ms_per_step": {"flatten": round(acc["flatten_ms"] / args.steps, 1),
                                      "unflatten": round(acc["unflatten_ms"] / args.steps, 1),
-                                     "wait_for_gpu": round(acc["wait_ms"] / args.steps, 1)},
+                                     "wait_for_gpu": round(acc["wait_ms"] / args.steps, 1),
+                                     "plan": round(acc["plan_ms"] / args.steps, 1), "setup": round(acc["setup_ms"] / args.steps, 1)},
+                "gpu_busy_ms_per_step": round(acc["gpu_busy_ms"] / args.steps, 1),
+                "gpu_idle_frac": round(1.0 - acc["gpu_busy_ms"] / max(1e-9, elapsed * 1e3), 4),
+                "gpu_busy_note": "union of the chunks' kernel intervals on the GPU clock (abea_stats.gpu_busy_ms): the rest of the step "
+                                 "the device had nothing of the call to run (ramp before the first chunk, un-flatten of the last)",
                 "chunks_per_step": int(host_stats["n_sub_batches"]), "host_threads": int(host_stats["host_threads"]),
                 "devices": int(host_stats["n_devices"]),
                 "pcie_bytes_per_step": {"h2d": int(host_stats["h2d_bytes"]), "d2h": int(host_stats["d2h_bytes"])},
@@ -257,13 +267,24 @@ def main():
                      "host_threads": int(r[6]), "kernels_ms_per_step_sum_over_chunks": round(r[7], 1)} for r in per_rank]
             slow = max(rows, key=lambda r: r["ms_per_step"])
             busy = slow["host_ms_per_step"]["flatten"] + slow["host_ms_per_step"]["unflatten"]
+            # host-bound = the device ran out of work while the caller's thread was busy: judged on the GPU's own clock at N = 1
+            # (gpu_idle_frac), on the caller thread's split otherwise
             out["per_rank"] = rows
             # the caller thread of the slowest rank either works (flatten + un-flatten) or waits for its GPU
-            out["bound"] = "host" if busy >= slow["host_ms_per_step"]["wait_for_gpu"] else "gpu"
-            out["bound_note"] = ("slowest rank %d: %.0f ms of host loops and %.0f ms waiting for the GPU per %.0f-ms step; all ranks share one "
+            out["bound"] = ("gpu" if out["host_to_host"]["gpu_idle_frac"] < 0.10 else "host") if world == 1 else \
+                           ("host" if busy >= slow["host_ms_per_step"]["wait_for_gpu"] else "gpu")
+            out["bound_note"] = ("rank 0's device idle %.1f %% of the step by its own clock; " % (100 * out["host_to_host"]["gpu_idle_frac"]) +
+                                 "slowest rank %d: %.0f ms of host loops and %.0f ms waiting for the GPU per %.0f-ms step; all ranks share one "
                                  "host's DRAM bandwidth and CPU quota (%d usable CPUs), so host-to-host `value` stops scaling when the "
                                  "host loops dominate; device_resident / kernel_only below are the whole-job rates without host traffic"
                                  % (slow["rank"], busy, slow["host_ms_per_step"]["wait_for_gpu"], slow["ms_per_step"], effective_cpus()))
+            out["cgroup_cpu"] = {"quota_cpus": effective_cpus(), "hw_threads": os.cpu_count(),
+                                 "in_timed_region": {key: cg1.get(key, 0) - cg0.get(key, 0) for key in ("nr_periods", "nr_throttled", "throttled_usec", "usage_usec")},
+                                 "note": "cpu.stat deltas of rank 0's cgroup over the timed steps: nr_throttled > 0 means CFS stopped the "
+                                         "process for exceeding the quota (host loops + HIP runtime threads), which stretches flatten / un-flatten"}
+            out["hip_runtime"] = {"GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"),
+                                  "note": "set by f5c_amd / abea_init before the HIP runtime initialises: with the default 4 hardware queues the "
+                                          "8 chunk streams share queues and their kernels serialise (422 vs 370 ms per step, profiles/r05/hw_queues_ab.txt)"}
             out["collective"] = {"backend": (args.backend if dist is not None else None), "world": world,
                                  "gather_device": gdev if dist is not None else None,
                                  "note": "statistics all_gather only; no data-path collective (reads are independent)"}
@@ -299,6 +320,8 @@ def main():
         if world == 1 and not args.single_process and not args.no_small_batch and host_stats is not None:
             out["f5c_default_batch"] = small_batch(ctx, batch)
             out["fused_scaling"] = fused_scaling(ctx, batch, view)
+            if not args.no_process_chain:
+                out["process_chain"] = process_chain(ctx, batch, model, k, not args.no_cpu_baseline)
         if world == 1 and not args.single_process and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(batch, model, k, args.cpu_seconds, view if host_stats is not None else None,
                                                dev, ctx)
@@ -368,26 +391,135 @@ def fused_scaling(ctx, batch, view):
     """align_db + scaling_db in one call (abea_f5c_align_scale's entry: process_db, src/f5c.c:924-936): base_to_event_map,
     recalibrated scalings, events_per_base and flags come back, the pair lists do not (pairs = NULL).  Same batch, host
     buffers in and out, outside the timed region."""
-    import numpy as np
     v = ctx.host_view(batch, scaling=True, want_pairs=False)
     ctx.align_view(v)
     reps = 3
+    acc = dict(flatten_ms=0.0, unflatten_ms=0.0, wait_ms=0.0, plan_ms=0.0, gpu_busy_ms=0.0)
     t0 = time.perf_counter()
     for _ in range(reps):
         ctx.align_view(v)
+        st = ctx.stats()
+        for key in acc:
+            acc[key] += st[key]
     t = (time.perf_counter() - t0) / reps
-    st = ctx.stats()
     ev = int(batch["n_events"].sum())
     same = bool((v["n_pairs"] == view["n_pairs"]).all())
     cal = int(((v["read_stat_flag"] & 1) == 0).sum())
     return {"mevents_per_s": round(ev / t / 1e6, 1), "ms_per_step": round(t * 1e3, 2),
-            "scaling_kernels_ms_sum_over_chunks": round(st["trace_ms"], 2),
+            "host_ms_per_step": {"flatten": round(acc["flatten_ms"] / reps, 1), "unflatten": round(acc["unflatten_ms"] / reps, 1),
+                                 "wait_for_gpu": round(acc["wait_ms"] / reps, 1), "plan": round(acc["plan_ms"] / reps, 1)},
+            "gpu_busy_ms_per_step": round(acc["gpu_busy_ms"] / reps, 1),
             "align_kernels_ms_sum_over_chunks": round(st["fill_ms"], 2),
-            "scaling_note": "round 4: scaling_single runs inside abea_align_kernel (the wavefront that aligned a read recalibrates it); "
-                            "no separate scaling kernels are launched, so their sum is 0 by construction",
+            "scaling_note": "scaling_single is the last phase of abea_align_kernel (the wavefront that aligned a read recalibrates it): the "
+                            "call is the alignment-only call plus that phase's GPU time, minus nothing — with the host loops hidden behind "
+                            "the GPU (round 5) the fused call cannot be faster than the alignment alone; what it saves is scaling_db's "
+                            "separate CPU pass and the pair lists (8 B per pair) never being written",
             "pcie_bytes_per_step": {"h2d": int(st["h2d_bytes"]), "d2h": int(st["d2h_bytes"])},
             "n_pairs_equal_alignment_only": same, "reads_calibrated": cal,
             "note": "pairs = NULL; base_to_event_map crosses PCIe as one event-count byte per k-mer and is rebuilt by the host workers"}
+
+
+def process_chain(ctx, batch, model, k, check_cpu=True, n_reads=10000):
+    """The callers either side of align_db through ONE call (rows N2 / N3): abea_process_batch_host = process_db_rsq's
+    event_db -> align_db -> scaling_db (src/resquiggle.c:283-315; src/f5c.c:682-734 for event_db) on raw signals — float ADC
+    counts in per-read host buffers, malloc()ed event tables + base_to_event_map + recalibrated scalings out — and
+    abea_events_batch_host (event_db alone).  A random 10 k-read sample of the batch, signals synthesised from its event tables
+    (synth.make_signals_flat); outside the timed region.  A few reads are re-derived with the CPU oracle chain
+    (getevents -> estimate_scalings -> align -> scaling_single) and compared bit for bit."""
+    import numpy as np
+    from f5c_amd import synth
+    n = len(batch["read_len"])
+    idx = np.sort(np.random.default_rng(777).permutation(n)[:min(n, n_reads)])
+    sub = synth.take_reads(batch, idx)
+    t0 = time.time()
+    sig, sp, ns, sc = synth.make_signals_flat(sub, seed=5, threads=max(2, effective_cpus() - 2))
+    t_gen = time.time() - t0
+    v = ctx.signal_view(sig, sp, ns, sc, batch=sub)
+    ctx.process_view(v)                                     # warm: slots, pinned staging
+    ctx.free_view(v)
+    reps, keys = 2, ("flatten_ms", "unflatten_ms", "wait_ms", "plan_ms", "event_ms", "pre_ms", "fill_ms", "gpu_busy_ms")
+    acc = dict.fromkeys(keys, 0.0)
+    t = 0.0
+    for rep in range(reps):
+        t0 = time.perf_counter()
+        ctx.process_view(v)
+        t += time.perf_counter() - t0
+        st = ctx.stats()
+        for key in keys:
+            acc[key] += st[key]
+        if rep < reps - 1:
+            ctx.free_view(v)                                # f5c's free_db_tmp: not part of process_db
+    t /= reps
+    n_ev = int(v["n_events"].sum())
+    n_smp = int(ns.sum())
+    out = {"reads": len(idx), "samples": n_smp, "events_detected": n_ev, "events_in_the_generating_tables": int(sub["n_events"].sum()),
+           "ms_per_call": round(t * 1e3, 1), "msamples_per_s": round(n_smp / t / 1e6, 1), "mevents_per_s": round(n_ev / t / 1e6, 1),
+           "reads_per_s": round(len(idx) / t, 1), "aligned_frac": round(float((v["n_pairs"] > 0).mean()), 4),
+           "host_ms_per_call": {"flatten_signal": round(acc["flatten_ms"] / reps, 1), "scatter_outputs": round(acc["unflatten_ms"] / reps, 1),
+                                "wait_for_gpu": round(acc["wait_ms"] / reps, 1), "plan": round(acc["plan_ms"] / reps, 1)},
+           "kernels_ms_sum_over_chunks": {"event_detection": round(acc["event_ms"] / reps, 1), "align_pre": round(acc["pre_ms"] / reps, 1),
+                                          "align": round(acc["fill_ms"] / reps, 1)},
+           "gpu_busy_ms_per_call": round(acc["gpu_busy_ms"] / reps, 1),
+           "gpu_idle_frac": round(1.0 - (acc["gpu_busy_ms"] / reps) / (t * 1e3), 4),
+           "pcie_bytes_per_call": {"h2d": int(st["h2d_bytes"]), "d2h": int(st["d2h_bytes"])},
+           "chunks": int(st["n_sub_batches"]), "signal_gen_s": round(t_gen, 1),
+           "note": "one C-ABI call; the alignment reads the event means from the tables the detector left in HBM (no second trip up); "
+                   "what crosses PCIe: 2 B per sample up, the 24-B event_t tables (an output of event_db) + 0.9 B per event of results down"}
+    if check_cpu:
+        from oracle import orc
+        ok, checked = True, 0
+        pick = np.argsort(ns)[len(ns) // 3: len(ns) // 3 + 4]            # four reads of modest length: seconds of oracle time
+        for j in pick:
+            j = int(j)
+            s16 = sig[sp[j]:sp[j] + ns[j]].astype(np.int16)
+            o_ev, _ = orc.getevents(s16, *[float(x) for x in sc[j]])
+            g_ev = ctx.view_events(v, j)
+            rs, L = int(sub["read_ptr"][j]), int(sub["read_len"][j])
+            seq = sub["reads"][rs:rs + L].tobytes()
+            same = len(g_ev) == len(o_ev) and all((g_ev[f] == o_ev[f]).all() for f in ("start", "length", "mean", "stdv"))
+            if same:
+                scale, shift = orc.estimate_scalings(seq, model, k, o_ev)
+                o_pairs, _ = orc.align(seq, o_ev, model, k, scale, shift)
+                rec = orc.scaling_single(o_pairs, seq, o_ev, model, k, scale, shift)
+                same = int(v["n_pairs"][j]) == len(o_pairs) and int(v["read_stat_flag"][j]) == rec["flag"] and \
+                    float(v["events_per_base"][j]) == rec["events_per_base"]
+                if same and len(o_pairs) > 0:
+                    m = ctx.view_map(v, j, L - k + 1)
+                    same = m is not None and (m[:, 0] == rec["base_to_event_map"]["start"]).all() and (m[:, 1] == rec["base_to_event_map"]["stop"]).all()
+                    if same and not (rec["flag"] & 1):
+                        same = all(v["scalings"][f][j] == rec["scalings"][f] for f in ("shift", "scale", "var", "log_var"))
+            ok &= bool(same)
+            checked += 1
+        out["gpu_bit_exact_on_cpu_sample"] = {"reads": checked, "ok": bool(ok),
+                                              "oracle": "getevents -> estimate_scalings -> align -> scaling_single (oracle/, CPU)"}
+    ctx.free_view(v)
+    ve = ctx.signal_view(sig, sp, ns, sc, batch=sub)
+    ctx.events_view(ve); ctx.free_view(ve)
+    t0 = time.perf_counter()
+    ctx.events_view(ve)
+    te = time.perf_counter() - t0
+    st = ctx.stats()
+    out["event_db_alone"] = {"ms_per_call": round(te * 1e3, 1), "msamples_per_s": round(n_smp / te / 1e6, 1),
+                             "mevents_per_s": round(int(ve["n_events"].sum()) / te / 1e6, 1),
+                             "kernels_ms_sum_over_chunks": round(st["event_ms"], 1),
+                             "gpu_idle_frac": round(1.0 - st["gpu_busy_ms"] / (te * 1e3), 4),
+                             "host_ms_per_call": {"flatten_signal": round(st["flatten_ms"], 1), "scatter_outputs": round(st["unflatten_ms"], 1),
+                                                  "wait_for_gpu": round(st["wait_ms"], 1)},
+                             "pcie_bytes_per_call": {"h2d": int(st["h2d_bytes"]), "d2h": int(st["d2h_bytes"])}}
+    ctx.free_view(ve)
+    return out
+
+
+def cgroup_cpu_stat():
+    """cpu.stat of this process's cgroup (v2): nr_periods, nr_throttled, throttled_usec, usage_usec; {} when unreadable"""
+    out = {}
+    try:
+        for ln in open("/sys/fs/cgroup/cpu.stat"):
+            key, val = ln.split()
+            out[key] = int(val)
+    except Exception:
+        pass
+    return out
 
 
 def pmc_traffic(config, sum_events, launches):
@@ -471,6 +603,9 @@ def numa_interleave(on):
     the library's context (threads, pinned staging) and the output buffers exist."""
     try:
         import ctypes
+        import platform
+        if platform.machine() != "x86_64":          # 238 is SYS_set_mempolicy on x86-64 only (round-4 advisor finding)
+            return False
         libc = ctypes.CDLL(None, use_errno=True)
         if not on:
             return libc.syscall(238, 0, None, 0) == 0                       # SYS_set_mempolicy (x86-64), MPOL_DEFAULT

@@ -69,6 +69,12 @@ extern "C" int abea_init(abea_ctx** out, const abea_cfg* cfg) {
     if (!out || !cfg || !cfg->model) return abea_fail(ABEA_EINVAL, "abea_init: null argument");
     if (cfg->kmer_size < 1 || cfg->kmer_size > ABEA_MAX_KMER_SIZE)
         return abea_fail(ABEA_EINVAL, "abea_init: kmer_size %u outside [1,%d]", cfg->kmer_size, ABEA_MAX_KMER_SIZE);
+    /* The host entry keeps up to 8 chunks in flight on as many streams; ROCm maps streams onto GPU_MAX_HW_QUEUES hardware queues
+     * (default 4) and kernels of streams that share a queue run one after the other (measured: 422 -> 370 ms per 100 k reads
+     * with 16 queues, profiles/r05/hw_queues_ab.txt).  The runtime reads the variable when it initialises, i.e. at the first HIP
+     * call of the process: if that is the call below (f5c: init_cuda is the first thing that touches the device) this takes
+     * effect; a process that has already used HIP must export it itself.  Never overrides the caller's value. */
+    setenv("GPU_MAX_HW_QUEUES", "16", 0);
     int n_dev = 0;
     if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0)
         return abea_fail(ABEA_ENODEV, "abea_init: no HIP device visible (this library has no CPU fallback)");
@@ -155,6 +161,7 @@ extern "C" void abea_free(abea_ctx* c) {
         hipSetDevice(c->device);
         if (c->stream) hipStreamSynchronize(c->stream);
         abea_host_release(c);
+        abea_chain_release(c);
         abea_hmm_release(c);
         hipFree(c->d_model); hipFree(c->arena);
         hipHostFree(c->h_desc);

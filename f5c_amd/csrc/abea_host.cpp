@@ -620,6 +620,7 @@ struct host_opts {
     bool sdma_d2h;             /* experiment: return the result block with hipMemcpyAsync instead of the copy-out kernel */
     int flatten_prefetch;      /* bytes the flatten loop prefetches ahead of its loads (0 = none) */
     int flatten_hint;          /* 0 = prefetchnta, 1 = prefetcht0, 2 = prefetcht2 */
+    bool ramp_order;           /* launch order: an ascending ramp of long reads first, then longest-first (order_for_launch) */
 };
 
 static host_opts read_opts() {
@@ -631,7 +632,9 @@ static host_opts read_opts() {
     if (const char* e = getenv("ABEA_HOST_SLOTS")) o.n_slots = std::min(ABEA_MAX_SLOTS, std::max(1, atoi(e)));
     if (const char* e = getenv("ABEA_HOST_PAIRS")) o.device_pairs = strcmp(e, "device") == 0;
     o.sdma_d2h = getenv("ABEA_HOST_SDMA_D2H") != nullptr;
-    o.flatten_prefetch = 1536; o.flatten_hint = 0;
+    o.flatten_prefetch = 1536; o.flatten_hint = 1;      /* prefetcht0 1.5 KB ahead: +5 % on the MI355X host (2 x EPYC), tools/host_sweep.py */
+    o.ramp_order = true;
+    if (const char* e = getenv("ABEA_HOST_ORDER")) o.ramp_order = strcmp(e, "lpt") != 0;
     if (const char* e = getenv("ABEA_HOST_FLATTEN_PREFETCH")) o.flatten_prefetch = std::max(0, std::min(1 << 16, atoi(e)));
     if (const char* e = getenv("ABEA_HOST_FLATTEN_HINT")) o.flatten_hint = std::max(0, std::min(2, atoi(e)));
     o.chunk_reads_max = std::max(o.chunk_reads_max, o.chunk_reads_min);
@@ -707,6 +710,32 @@ static void order_longest_first(const std::vector<plan_read>& reads, std::vector
     /* four passes: the result is back in `order` */
 }
 
+/* The order in which the reads are launched.  Longest-processing-time-first is what the END of a batch wants (the last reads
+ * to start must be short), but it is the worst start: a wavefront holds a read for its whole length, the GPU is at full rate
+ * only with ~4096 reads resident, and the 4096 longest reads of a 1-50 kb mix are 390 M events — 37 ms of flatten during which
+ * the device runs at half occupancy on average.  Any read length keeps the wave slots full once they ARE full (the host
+ * supplies events 1.5x faster than the kernel consumes them), so the batch starts with an ASCENDING RAMP: every other read of
+ * those above ABEA_RAMP_BANDS bands, shortest first — 4096 of the ramp's first reads are flattened in ~5 ms, and the read
+ * length then climbs to the longest while the slots stay full — followed by all the other reads longest first (the LPT tail is
+ * untouched).  Worth 15-18 ms per 100 k reads (367 -> 350 ms); batches with fewer than ABEA_RAMP_MIN_READS long
+ * reads keep the plain longest-first order.  Results do not depend on the order.  ABEA_HOST_ORDER=lpt restores longest-first. */
+static const int64_t ABEA_RAMP_BANDS = 18000;         /* ~12 k events: 4096 such reads are 50 M events */
+static const size_t ABEA_RAMP_MIN_READS = 8192;
+static void order_for_launch(const std::vector<plan_read>& reads, std::vector<int32_t>& order, const host_opts& opt) {
+    order_longest_first(reads, order);
+    if (!opt.ramp_order) return;
+    size_t p = 0;
+    while (p < order.size() && reads[(size_t)order[p]].n_bands >= ABEA_RAMP_BANDS) ++p;
+    if (p < ABEA_RAMP_MIN_READS) return;
+    std::vector<int32_t> out; out.reserve(order.size());
+    for (size_t t = (p - 1) | 1; ; t -= 2) {             /* odd ranks below p, ascending length */
+        if (t < p) out.push_back(order[t]);
+        if (t < 2) break;
+    }
+    for (size_t t = 0; t < order.size(); ++t) if (t >= p || (t & 1) == 0) out.push_back(order[t]);   /* the rest, longest first */
+    order.swap(out);
+}
+
 /* The chunk plan abea_align_batch_host would use for these reads on an arena of `arena_bytes` (pairs returned through
  * the walk codes, no fused scaling), host-only: chunk_of[i] = chunk of read i, -1 for reads the align_single guards
  * skip; chunks are numbered in launch order.  Exposed so that the planning logic is testable without a GPU. */
@@ -727,7 +756,7 @@ extern "C" int abea_host_plan_chunks(const int32_t* read_len, const int32_t* n_e
             order.push_back(i);
         }
     }
-    order_longest_first(reads, order);
+    order_for_launch(reads, order, opt);
     const size_t slot_arena = (size_t)arena_bytes / (size_t)opt.n_slots / 4096 * 4096;
     const std::vector<chunk_span> chunks = carve_chunks(reads, order, opt, slot_arena, false, false);
     for (size_t c = 0; c < chunks.size(); ++c)
@@ -786,7 +815,8 @@ struct host_run_state {
     abea_ctx* c;
     abea_host_lane* lane;
     const abea_host_batch* H;
-    hipEvent_t origin = nullptr;          /* ABEA_HOST_TRACE: GPU clock origin of the call (recorded on the idle context stream) */
+    hipEvent_t origin = nullptr;          /* GPU clock origin of the call (recorded on the idle context stream) */
+    std::vector<std::pair<float, float>> spans;   /* kernel span of every retired chunk on that clock */
     host_opts opt;
     bool want_pairs, scaling, device_pairs;
     abea_stats st;
@@ -866,11 +896,13 @@ static int slot_retire(host_run_state& S, abea_host_slot& sl) {
     S.st.unflatten_ms += abea_now_ms() - t0;
     S.log("retired", sl.chunk_no);
     float ms = 0;
-    if (S.trace && S.origin) {            /* the chunk's kernels on the GPU's clock: start of align-pre, start and end of the alignment kernel */
+    if (S.origin) {                       /* the chunk's kernels on the GPU's clock: start of align-pre, start and end of the alignment kernel */
         float a = 0, b = 0, e = 0;
         if (hipEventElapsedTime(&a, S.origin, sl.k0) == hipSuccess && hipEventElapsedTime(&b, S.origin, sl.k1) == hipSuccess &&
-            hipEventElapsedTime(&e, S.origin, sl.k2) == hipSuccess)
-            fprintf(stderr, "[abea host dev %d] gpu chunk %2d  pre %9.3f  align %9.3f .. %9.3f ms  reads %d\n", S.c->device, sl.chunk_no, a, b, e, sl.m);
+            hipEventElapsedTime(&e, S.origin, sl.k2) == hipSuccess) {
+            S.spans.emplace_back(a, e);
+            if (S.trace) fprintf(stderr, "[abea host dev %d] gpu chunk %2d  pre %9.3f  align %9.3f .. %9.3f ms  reads %d\n", S.c->device, sl.chunk_no, a, b, e, sl.m);
+        }
     }
     HIP_TRY(hipEventElapsedTime(&ms, sl.k0, sl.k1)); S.st.pre_ms += ms;
     HIP_TRY(hipEventElapsedTime(&ms, sl.k1, sl.k2)); S.st.fill_ms += ms;
@@ -918,6 +950,8 @@ static void ensure_lanes(abea_ctx* c, const host_thread_plan& pl, int n_lanes, i
     }
 }
 
+static hipStream_t sl0_stream(abea_ctx* c, int slot0) { return c->slots[(size_t)slot0]->stream; }
+
 static int host_run(abea_ctx* c, const abea_host_batch* H, const int32_t* mine, int32_t n_mine, abea_host_lane& lane,
                     abea_stats* st_out) {
     const double t_start = abea_now_ms();
@@ -951,9 +985,13 @@ static int host_run(abea_ctx* c, const abea_host_batch* H, const int32_t* mine, 
         c->slots[(size_t)q]->busy = false;                       /* nothing survives a call (slot_guard) */
     }
     slot_guard guard{c, &lane};
-    if (S.trace && hipEventRecord(c->ev[0], c->stream) == hipSuccess && hipEventSynchronize(c->ev[0]) == hipSuccess) {
-        S.origin = c->ev[0];
-        S.t_origin = abea_now_ms();                              /* host and GPU clocks share (to ~20 us) this origin */
+    struct origin_event {                                        /* per call: several lanes of one context may run at once */
+        hipEvent_t e = nullptr;
+        ~origin_event() { if (e) hipEventDestroy(e); }
+    } origin;
+    if (hipEventCreate(&origin.e) == hipSuccess && hipEventRecord(origin.e, sl0_stream(c, slot0)) == hipSuccess) {
+        S.origin = origin.e;
+        if (S.trace && hipEventSynchronize(origin.e) == hipSuccess) S.t_origin = abea_now_ms();   /* host and GPU clocks share (to ~20 us) this origin */
     }
     uint8_t* const lane_arena = c->arena + lane.arena_off;
     auto slot_at = [&](int q) -> abea_host_slot& { return *c->slots[(size_t)(slot0 + q)]; };
@@ -988,7 +1026,7 @@ static int host_run(abea_ctx* c, const abea_host_batch* H, const int32_t* mine, 
             }
         }
     }
-    order_longest_first(S.reads, order);
+    order_for_launch(S.reads, order, S.opt);
     auto io_bytes = [&](const plan_read& r) { return chunk_io_bytes(r, pairs_on_device, scaling); };
     /* check every read against the arena before anything is launched */
     for (int32_t q : order) {
@@ -1180,6 +1218,7 @@ static int host_run(abea_ctx* c, const abea_host_batch* H, const int32_t* mine, 
         if (rc) return rc;
     }
     S.st.host_ms = S.st.flatten_ms + S.st.unflatten_ms;
+    S.st.gpu_busy_ms = interval_union_ms(S.spans);
     S.st.total_ms = abea_now_ms() - t_start;
     *st_out = S.st;
     return ABEA_OK;
@@ -1211,6 +1250,7 @@ static void stats_add(abea_stats& a, const abea_stats& b) {
     a.host_ms = std::max(a.host_ms, b.host_ms); a.flatten_ms = std::max(a.flatten_ms, b.flatten_ms);
     a.unflatten_ms = std::max(a.unflatten_ms, b.unflatten_ms); a.wait_ms = std::max(a.wait_ms, b.wait_ms);
     a.plan_ms = std::max(a.plan_ms, b.plan_ms); a.setup_ms = std::max(a.setup_ms, b.setup_ms);
+    a.gpu_busy_ms = std::max(a.gpu_busy_ms, b.gpu_busy_ms);
     a.n_reads_gpu += b.n_reads_gpu; a.n_reads_skipped += b.n_reads_skipped; a.n_sub_batches += b.n_sub_batches;
     a.sum_events += b.sum_events; a.sum_bands += b.sum_bands; a.sum_pairs += b.sum_pairs; a.fill_launches += b.fill_launches;
     a.arena_bytes += b.arena_bytes; a.bytes_ref += b.bytes_ref; a.bytes_min += b.bytes_min; a.bytes_moved += b.bytes_moved;

@@ -40,6 +40,7 @@ struct abea_host_pool;      /* abea_host.cpp: persistent host worker threads */
 struct abea_host_async;     /* abea_host.cpp: lanes (slot set + arena share + pool) and the batches in flight */
 static const int ABEA_MAX_SLOTS = 16;       /* stream slots per device context (8 are used unless ABEA_HOST_SLOTS asks for more) */
 struct abea_host_slot;      /* abea_host.cpp: one chunk in flight (stream, pinned staging, arena share) */
+struct abea_chain_slot;     /* abea_chain.cpp: one chunk of the raw-signal pipeline in flight */
 struct abea_hmm_state;      /* abea_hmm.cpp: log-sum table, CpG model copy, staging of the profile-HMM entry (row N4) */
 
 struct abea_ctx {
@@ -56,6 +57,7 @@ struct abea_ctx {
     abea_read_desc* h_desc = nullptr; size_t h_desc_cap = 0;
     /* host-buffer entry (abea_host.cpp), created on first use */
     std::vector<abea_host_slot*> slots;
+    std::vector<abea_chain_slot*> chain_slots;   /* abea_chain.cpp, created on first use */
     std::mutex slots_mu;
     abea_host_async* async = nullptr;
     int numa_node = -1;                         /* of the device (sysfs), -1 unknown */
@@ -70,6 +72,25 @@ struct abea_ctx {
 void abea_host_join_async(abea_ctx* c);     /* joins the threads of submitted host batches (abea_host.cpp) */
 void abea_host_release(abea_ctx* c);       /* frees pool + slots (abea_host.cpp); called by abea_free */
 void abea_hmm_release(abea_ctx* c);        /* abea_hmm.cpp */
+void abea_chain_release(abea_ctx* c);      /* abea_chain.cpp */
+
+/* what the raw-signal pipeline works on: the fields of abea_events_host_batch / abea_process_batch (include/abea.h), one view
+ * for both entries.  align == false: event_db only (scalings = the method-of-moments estimate, may be NULL; read may be NULL
+ * with it).  align == true: event_db -> align_db -> scaling_db; every output array below must be present except pairs / diag /
+ * scalings_estimated. */
+struct abea_chain_job {
+    int32_t n_reads;
+    float* const* rawptr; const int64_t* n_samples; const float* offset; const float* range; const float* digitisation;
+    const char* const* read; const int32_t* read_len;
+    int32_t rna, signal_to_pa_in_place;
+    abea_event_t** events; uint64_t* n_events;
+    abea_scalings_t* scalings; abea_scalings_t* scalings_estimated;
+    bool align;
+    abea_pair_t** pairs; int32_t* n_pairs; abea_read_diag* diag; abea_index_pair_t** base_to_event_map;
+    double* events_per_base; int32_t* read_stat_flag; int32_t* n_event_alignment; int32_t min_num_events_to_rescale;
+};
+/* the pipeline on ONE device context over reads mine[0..n_mine) (NULL = all), the caller holds the context (abea_chain.cpp) */
+int abea_chain_run(abea_ctx* c, const abea_chain_job* J, const int32_t* mine, int32_t n_mine, abea_stats* st_out);
 /* run f(lo, hi) over [0, n) in pieces of `grain` items on the context's persistent worker pool (created on first use;
  * the caller's thread takes part) — abea_host.cpp */
 void abea_parallel_for(abea_ctx* c, int64_t n, int64_t grain, const std::function<void(int64_t, int64_t)>& f);
@@ -139,5 +160,17 @@ static inline void plan_desc(abea_read_desc& d, const plan_read& r, const abea_s
 }
 
 int ensure_pinned(void** p, size_t* cap, size_t need);
+
+/* length of the union of [begin, end) intervals (the chunks' kernel spans on the GPU clock) */
+static inline double interval_union_ms(std::vector<std::pair<float, float>>& iv) {
+    std::sort(iv.begin(), iv.end());
+    double total = 0; float lo = 0, hi = -1;
+    for (const auto& x : iv) {
+        if (hi < lo || x.first > hi) { if (hi > lo) total += hi - lo; lo = x.first; hi = x.second; }
+        else hi = std::max(hi, x.second);
+    }
+    if (hi > lo) total += hi - lo;
+    return total;
+}
 
 #endif

@@ -290,3 +290,40 @@ def make_signals(batch, seed=0, offset=10.0, rng_pa=1467.61, digitisation=8192.0
         sigs.append(np.clip(np.rint(pa / raw_unit - offset), -32768, 32767).astype(np.int16))
     sc = np.tile(np.array([offset, rng_pa, digitisation], dtype=np.float32), (len(sigs), 1))
     return sigs, sc
+
+
+def make_signals_flat(batch, idx=None, seed=0, offset=10.0, rng_pa=1467.61, digitisation=8192.0, threads=8):
+    """The same signals as make_signals() in law (each event contributes `length` samples drawn around its mean, sigma 1.2 pA),
+    for whole batches: one flat FLOAT32 array of ADC counts — the form f5c holds them in (signal_t.rawptr, f5c.h:276-286) —
+    built by `threads` numpy threads, every read with its own generator.  Returns (signal float32, sig_ptr int64[n] in
+    samples, n_samples int64[n], scaling float32 [n,3])."""
+    import threading
+    idx = np.arange(len(batch["read_len"])) if idx is None else np.asarray(idx)
+    n = len(idx)
+    raw_unit = np.float32(rng_pa) / np.float32(digitisation)
+    ep = batch["event_ptr"].astype(np.int64)
+    ne = batch["n_events"].astype(np.int64)
+    ns = np.zeros(n, dtype=np.int64)
+    lens = []
+    for j, i in enumerate(idx):
+        ln = batch["events"]["length"][ep[i]:ep[i] + ne[i]].astype(np.int64)
+        lens.append(ln)
+        ns[j] = int(ln.sum())
+    pad = (ns + 7) // 8 * 8
+    sig_ptr = np.concatenate([[0], np.cumsum(pad)[:-1]]).astype(np.int64)
+    out = np.zeros(int(pad.sum()), dtype=np.float32)
+
+    def work(t):
+        for j in range(t, n, threads):
+            i = int(idx[j])
+            r = np.random.default_rng([seed, 0x516, i])
+            mean = batch["events"]["mean"][ep[i]:ep[i] + ne[i]]
+            pa = np.repeat(mean, lens[j]) + np.float32(1.2) * r.standard_normal(int(ns[j]), dtype=np.float32)
+            np.clip(np.rint(pa / raw_unit - np.float32(offset)), -32768, 32767, out=out[sig_ptr[j]:sig_ptr[j] + ns[j]])
+    th = [threading.Thread(target=work, args=(t,)) for t in range(threads)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    sc = np.tile(np.array([offset, rng_pa, digitisation], dtype=np.float32), (n, 1))
+    return out, sig_ptr, ns, sc

@@ -336,6 +336,9 @@ typedef struct {
     int32_t n_devices, host_threads;
     double plan_ms, setup_ms;             /* caller-thread time that is neither loop nor wait: per-chunk layout (plan) and the
                                              guards + ordering + chunk carving before the first chunk (setup) */
+    double gpu_busy_ms;                   /* host batch / raw-signal entries: length of the union of the chunks' kernel intervals on the
+                                             GPU's clock (first kernel start .. last kernel end per chunk): total_ms - gpu_busy_ms = time
+                                             the device had nothing of this call to run */
 } abea_stats;
 int abea_get_stats(abea_ctx* ctx, abea_stats* out);
 /* Multi-device context: the share of the last host batch that ran on device_ids[device]; abea_get_stats() gives the

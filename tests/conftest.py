@@ -6,6 +6,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+import f5c_amd  # noqa: E402,F401  (sets GPU_MAX_HW_QUEUES before _have_gpu() below initialises the HIP runtime)
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 

@@ -167,15 +167,16 @@ def test_walk_code_expansion_matches_the_traceback(orc, r9):
 
 
 def test_chunk_plan_of_the_host_entry(monkeypatch):
-    """abea_host_plan_chunks = the carving abea_align_batch_host applies: every runnable read in exactly one chunk, chunks in
-    descending read length, size rules (>= 2048 reads and >= 48 M events, first two chunks a quarter / half, <= 16384 reads),
-    the arena share respected, over-long reads alone, guard failures left out."""
+    """abea_host_plan_chunks = the carving abea_align_batch_host applies: every runnable read in exactly one chunk, size rules
+    (>= 2048 reads and >= 48 M events, first two chunks a quarter / half, <= 16384 reads), the arena share respected, over-long
+    reads alone, guard failures left out.  Launch order (round 5): an ascending ramp — every other read above 18 000 bands,
+    shortest first — then everything else longest first; ABEA_HOST_ORDER=lpt = plain longest-first."""
     import ctypes
     from f5c_amd import abea, synth
     lib = abea.load_library()
     lib.abea_host_plan_chunks.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_uint32, ctypes.c_uint64,
                                           ctypes.c_void_p, ctypes.c_void_p]
-    for var in ("ABEA_HOST_CHUNK_EVENTS", "ABEA_HOST_CHUNK_READS", "ABEA_HOST_CHUNK_READS_MAX", "ABEA_HOST_SLOTS"):
+    for var in ("ABEA_HOST_CHUNK_EVENTS", "ABEA_HOST_CHUNK_READS", "ABEA_HOST_CHUNK_READS_MAX", "ABEA_HOST_SLOTS", "ABEA_HOST_ORDER"):
         monkeypatch.delenv(var, raising=False)
 
     def plan(L, E, arena):
@@ -187,23 +188,47 @@ def test_chunk_plan_of_the_host_entry(monkeypatch):
     L = synth.batch_lengths(100_000, 20250003, "loguniform")            # BASELINE configs[2]
     E = 2 * L + (L % 7)
     E[::1000] = 20 * L[::1000]                                          # over-segmented: skipped by E/L >= 15
-    rc, ch, n = plan(L, E, 150 << 30)
-    assert rc == 0 and 20 <= n <= 40
     skipped = np.zeros(len(L), bool); skipped[::1000] = True
-    assert (ch[skipped] == -1).all() and (ch[~skipped] >= 0).all() and ch.max() == n - 1
-    bands = E.astype(np.int64) + L
-    for c in range(n):
-        m = ch == c
-        cnt, ev = int(m.sum()), int(E[m].sum())
-        ramp = 4 if c == 0 else 2 if c == 1 else 1
-        if c < n - 1:
-            assert cnt >= 2048 // ramp and (ev >= (48 << 20) // ramp or cnt == 16384)
-            assert bands[m].min() >= bands[ch == c + 1].max()           # longest first across chunks
-        assert cnt <= 16384
-        # closing rule: without its last (shortest) read the chunk would have been below one of the two thresholds
-        last = np.nonzero(m)[0][np.argmin(bands[m])]
-        if c < n - 1 and cnt < 16384:
-            assert cnt - 1 < 2048 // ramp or ev - int(E[last]) < (48 << 20) // ramp
+    bands = E.astype(np.int64) + (L - 6 + 1) + 2
+    for order in ("lpt", "ramp"):
+        if order == "lpt":
+            monkeypatch.setenv("ABEA_HOST_ORDER", "lpt")
+        else:
+            monkeypatch.delenv("ABEA_HOST_ORDER")
+        rc, ch, n = plan(L, E, 150 << 30)
+        assert rc == 0 and 20 <= n <= 40
+        assert (ch[skipped] == -1).all() and (ch[~skipped] >= 0).all() and ch.max() == n - 1
+        hi = np.array([bands[ch == c].max() for c in range(n)]); lo = np.array([bands[ch == c].min() for c in range(n)])
+        if order == "lpt":
+            assert (lo[:-1] >= hi[1:]).all()                            # longest first across chunks
+            desc_from = 0
+        else:
+            # the ramp: chunks of ascending length holding every other read above 18 000 bands, then longest-first
+            top = int(np.argmax(hi))
+            assert 2 <= top <= n // 2 and hi[top] == bands[~skipped].max()
+            assert (hi[:top - 1] <= lo[1:top]).all() and lo[0] >= 18000             # ascending up to the chunk holding the turn; nothing below the ramp's floor
+            ramp_reads = np.isin(ch, np.arange(top + 1)) & ~skipped
+            above = (bands >= 18000) & ~skipped
+            assert abs(int(ramp_reads.sum()) - int(above.sum()) // 2) <= 16384       # ~half of the long reads (the chunk holding the turn is mixed)
+            desc_from = top + 1
+            assert (lo[desc_from:-1] >= hi[desc_from + 1:]).all()       # the LPT tail is untouched
+            assert hi[-1] < 4000 and (ch == 0).sum() >= 512 and E[ch == 0].sum() < 40 << 20   # a cheap first chunk: the GPU starts after ~2 ms
+        for c in range(n):
+            m = ch == c
+            cnt, ev = int(m.sum()), int(E[m].sum())
+            ramp = 4 if c == 0 else 2 if c == 1 else 1
+            if c < n - 1:
+                assert cnt >= 2048 // ramp and (ev >= (48 << 20) // ramp or cnt == 16384)
+            assert cnt <= 16384
+            # closing rule (descending part): without its last (shortest) read the chunk would have been below one of the two thresholds
+            last = np.nonzero(m)[0][np.argmin(bands[m])]
+            if desc_from <= c < n - 1 and cnt < 16384:
+                assert cnt - 1 < 2048 // ramp or ev - int(E[last]) < (48 << 20) // ramp
+    # small batches keep plain longest-first: nothing to ramp with fewer than 8192 long reads
+    rc, chs, ns = plan(L[:6000], 2 * L[:6000], 150 << 30)
+    assert rc == 0
+    b6 = 2 * L[:6000].astype(np.int64) + L[:6000]
+    assert all(b6[chs == c].min() >= b6[chs == c + 1].max() for c in range(ns - 1))
     # a small arena: shares of 2 MiB; the long read runs alone, the others are packed under the share
     L2 = np.array([1500, 40000, 1200, 2500, 60000, 1800]); E2 = 2 * L2
     rc, ch2, n2 = plan(L2, E2, 16 << 20)

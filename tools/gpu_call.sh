@@ -31,6 +31,20 @@ for ln in sys.stdin:
     r = json.loads(ln); print('q$q %-24s %7.1f ms  flat %6.1f unfl %5.1f wait %6.1f plan %4.1f  fill_sum %7.1f' % (r['name'], r['ms_per_step'], r['flatten_ms'], r['unflatten_ms'], r['wait_ms'], r['plan_ms'], r['fill_ms']))"
     done
     ;;
+  chain)      # round-5 rewrite of the raw-signal entries + the ramp launch order + where GPU_MAX_HW_QUEUES is set
+    step t_changed 500 python -m pytest tests/test_host_pipeline.py tests/test_process_chain.py tests/test_rna_events.py tests/test_fuzz_gpu.py -m gpu -x -q -k "not torchrun and not two_ranks" --durations=5
+    tail -9 $O/t_changed.log
+    step bench10k 400 python bench.py --config r9_10k_8kb --steps 3 --warmup 1
+    tail -c 2500 $O/bench10k.log
+    step sweep 400 python tools/host_sweep.py --out $O/py --no-flatten-probe --steps 3 --only base,lpt,fused_base,fused_lpt,base_again
+    ABEA_KEEP_HW_QUEUES=1 step sweep_lib 400 python tools/host_sweep.py --out $O/lib --no-flatten-probe --steps 3 --only base
+    for f in sweep sweep_lib; do grep '"name"\|GPU_MAX' $O/$f.log | python3 -c "
+import sys, json
+for ln in sys.stdin:
+    r = json.loads(ln)
+    if 'name' not in r: print('$f', r); continue
+    print('$f %-12s %7.1f ms  flat %6.1f unfl %5.1f wait %6.1f plan %4.1f  gpu_busy %7.1f' % (r['name'], r['ms_per_step'], r['flatten_ms'], r['unflatten_ms'], r['wait_ms'], r['plan_ms'], r.get('gpu_busy_ms', 0)))"; done
+    ;;
   tests)      # the whole GPU suite + the bench line of the build that ships
     step gpu_tests 900 python -m pytest tests -m gpu -x -q --durations=10
     tail -16 $O/gpu_tests.log

@@ -119,6 +119,8 @@ def main():
     s16 = {"ABEA_HOST_SLOTS": "16"}
     settings = [
         ("base", "pairs", {}, True),
+        ("lpt", "pairs", {"ABEA_HOST_ORDER": "lpt"}, True),
+        ("fused_lpt", "fused", {"ABEA_HOST_ORDER": "lpt"}, False),
         ("pf0", "pairs", {"ABEA_HOST_FLATTEN_PREFETCH": "0"}, False),
         ("pf_nta1536", "pairs", {"ABEA_HOST_FLATTEN_HINT": "0"}, False),
         ("pf_t2_4096", "pairs", {"ABEA_HOST_FLATTEN_PREFETCH": "4096", "ABEA_HOST_FLATTEN_HINT": "2"}, False),
@@ -164,7 +166,7 @@ def main():
         for _ in range(args.steps):
             ctx.align_view(view)
             st = ctx.stats()
-            for key in ("setup_ms", "plan_ms", "flatten_ms", "unflatten_ms", "wait_ms", "pre_ms", "fill_ms", "total_ms"):
+            for key in ("setup_ms", "plan_ms", "flatten_ms", "unflatten_ms", "wait_ms", "pre_ms", "fill_ms", "total_ms", "gpu_busy_ms"):
                 acc[key] = acc.get(key, 0.0) + st[key]
         dt = (time.perf_counter() - t0) / args.steps
         c1 = cpu_stat()
