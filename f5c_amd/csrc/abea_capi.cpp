@@ -544,7 +544,7 @@ int abea_detect_events_on(abea_ctx* c, const abea_signal_batch* B, const abea_ev
                                nr, (const int32_t*)(d + o_order), B->reads, (const int64_t*)(d + o_rp),
                                (const int32_t*)(d + o_rl), c->d_model, (int)c->k, (const int64_t*)(d + o_kb),
                                (const int32_t*)(d + o_wk), dKm);
-            hipLaunchKernelGGL(abea_ev_scalings_kernel, dim3((unsigned)nw), dim3(64), 0, X.stream,
+            hipLaunchKernelGGL(abea_ev_scalings_kernel, dim3((unsigned)nw), dim3(512), 0, X.stream,
                                nr, (const int32_t*)(d + o_order), (const int64_t*)(d + o_pb), dMean, B->n_events,
                                (const int32_t*)(d + o_ec), (const int32_t*)(d + o_rl), (const int64_t*)(d + o_kb), dKm,
                                (int)c->k, B->scalings);

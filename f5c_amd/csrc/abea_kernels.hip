@@ -19,7 +19,11 @@
 #include <hip/hip_runtime.h>
 #include <type_traits>
 #include "abea_device.h"
+#ifdef ABEA_MARKSTEIN            /* EXPERIMENT build only (tools/gpu_call.sh markstein): the quotient as three f32 instructions */
+#include "abea_fill_exp.inc"
+#else
 #include "abea_fill.inc"
+#endif
 #include "abea_walk.inc"
 
 #define NINF (-__builtin_inff())
@@ -111,7 +115,12 @@ void abea_pre_kernel(const abea_read_desc* __restrict__ descs,
         abea_kpar_t p;
         p.gpm  = __fadd_rn(__fmul_rn(scale, m.level_mean), shift);   /* align.c:137-138, mul then add, no FMA */
         p.ck   = __fsub_rn(-0.918938f, m.level_log_stdv);            /* align.c:111-113 */
+#ifdef ABEA_MARKSTEIN
+        { const float rr = (float)(1.0 / (double)m.level_stdv);      /* the quad's last two dwords: {stdv, RN32(1/stdv)} */
+          p.istd = __hiloint2double(__float_as_int(rr), __float_as_int(m.level_stdv)); }
+#else
         p.istd = 1.0 / (double)m.level_stdv;
+#endif
         kp[i] = p;
     }
     if (!events) return;                               /* host path: the means were uploaded straight into evm */
@@ -127,7 +136,13 @@ static __device__ __forceinline__ void abea_cell(float x, float gpm, float ck, d
                                                  double lp_step, double lp_stay, double lp_skip,
                                                  float& m, uint32_t& from) {
     float dx = __fsub_rn(x, gpm);
+#ifdef ABEA_MARKSTEIN
+    const float sv = __int_as_float(__double2loint(istd)), rr = __int_as_float(__double2hiint(istd));
+    const float q_ = __fmul_rn(dx, rr);
+    float a = __fmaf_rn(__fmaf_rn(-q_, sv, dx), rr, q_);
+#else
     float a  = (float)((double)dx * istd);                     /* == dx / stdv, correctly rounded */
+#endif
     /* align.c:113: ck + (-0.5f*a)*a.  Halving is exact, so RN((-0.5a)*a) = -0.5*RN(a*a) and one fma adds that product to ck
      * with the single rounding of the reference's add (identical unless a*a underflows and ck == 0: one subnormal ulp) */
     float lp = __fmaf_rn(-0.5f, __fmul_rn(a, a), ck);
@@ -331,15 +346,10 @@ void abea_align_kernel(const abea_read_desc* __restrict__ descs,
     /* pairs_all == nullptr: the pair lists are not materialised on the device (the host entry expands them from the
      * walk codes).  pair_cursor != nullptr: pair lists are packed back to back in completion order (atomic bump
      * allocation of n entries per read, offset reported in pair_off_out[]) instead of at desc.pair_off. */
-    /* 4 KiB of LDS per wavefront: phase 3's emission buffer (1024 floats in walk order).  Round 4: the fill loop no longer
-     * touches LDS — upcoming events and k-mers wait in the idle lanes 52..63 of the band registers (below) — so under
-     * ABEA_NO_ASM only, the C++ twin of the loop keeps its two rings here: [1024, 1536) events, [2048, 4096) k-mers. */
+    /* 4 KiB of LDS per wavefront: phase 3's emission buffer (1024 floats in walk order).  The fill loop does not touch LDS:
+     * upcoming events and k-mers wait in the idle lanes 52..63 of the band registers (below). */
     __shared__ __attribute__((aligned(4096))) uint4 smem[256];
     float* const lp_s = reinterpret_cast<float*>(smem);                      /* 1024 x 4 B */
-#ifdef ABEA_NO_ASM
-    abea_kpar_t* const k_ring = reinterpret_cast<abea_kpar_t*>(smem + 128);  /* 128 x 16 B */
-    float* const e_ring = reinterpret_cast<float*>(smem + 64);               /* 128 x 4 B  */
-#endif
 
     const abea_read_desc* d = descs + blockIdx.x;
     const int lane = threadIdx.x;
@@ -368,7 +378,7 @@ void abea_align_kernel(const abea_read_desc* __restrict__ descs,
     const int nb_pad = n_groups * ABEA_GROUP;
     const double lp_skip = d->lp_skip, lp_stay = d->lp_stay, lp_step = d->lp_step, lp_trim = d->lp_trim;
     const int o0 = 2 * lane, o1 = o0 + 1;              /* offsets owned by this lane */
-    [[maybe_unused]] const bool hi = lane >= 50;        /* FIFO lanes: scores pinned to -inf (C++ twin) */
+    [[maybe_unused]] const bool hi = lane >= 50;        /* FIFO lanes: scores pinned to -inf */
 
     /* ---- state after bands 0 and 1 (align.c:277-291) ---- */
     int ll_e = 50, ll_k = -51;                          /* lower-left of band 1 */
@@ -393,22 +403,6 @@ void abea_align_kernel(const abea_read_desc* __restrict__ descs,
         g0 = p0.gpm; c0 = p0.ck; i0 = p0.istd;
         g1 = p1.gpm; c1 = p1.ck; i1 = p1.istd;
     }
-#ifdef ABEA_NO_ASM
-    /* C++ twin only — LDS rings: entry i lives at slot i & 127 (chunk c = i >> 6 in half c & 1) */
-    int e_next = ll_e + 1;                              /* event entering at offset 0 on the next down move */
-    int k_next = ll_k + 128;                            /* k-mer entering at offset 127 on the next right move */
-    e_ring[lane] = evm[min(lane, E - 1)];
-    e_ring[64 + lane] = evm[min(64 + lane, E - 1)];
-    float e_pend = evm[min(128 + lane, E - 1)];         /* chunk 2, written when chunk 1 is entered */
-    k_ring[64 + lane] = kpar[min(64 + lane, K - 1)];    /* chunk 1 */
-    k_ring[lane] = kpar[min(128 + lane, K - 1)];        /* chunk 2 */
-    float kpg, kpc; double kpi;                         /* chunk 3, in flight */
-    { const abea_kpar_t t = kpar[min(192 + lane, K - 1)]; kpg = t.gpm; kpc = t.ck; kpi = t.istd; }
-    __syncthreads();
-    float nx = e_ring[e_next & 127];
-    float nkg, nkc; double nki;                         /* incoming k-mer (uniform) */
-    { const abea_kpar_t t = k_ring[k_next & 127]; nkg = t.gpm; nkc = t.ck; nki = t.istd; }
-#else
     /* Lanes 52..63 of the event registers hold the next 24 events (lane 63's cell 1 first; a down move rotates the wave);
      * their k-mer quads hold offsets 104..127 as they always did.  The pending registers are what the next refill, 24 moves
      * of a kind later, puts into those lanes. */
@@ -422,7 +416,6 @@ void abea_align_kernel(const abea_read_desc* __restrict__ descs,
         const abea_kpar_t tb = kpar[min(max(ll_k + 24 + 2 * lane + 1, 0), K - 1)];
         kag = ta.gpm; kac = ta.ck; kai = ta.istd; kbg = tb.gpm; kbc = tb.ck; kbi = tb.istd;
     }
-#endif
 
     /* trace accumulator: 4 bits per band shifted in from the right, COMPLEMENTED (see abea_fill.inc); bands 0,1:
      * only band 1 offset 50 = FROM_U */
@@ -431,127 +424,16 @@ void abea_align_kernel(const abea_read_desc* __restrict__ descs,
     uint32_t mvacc = 0, mvprev = 0;                     /* band-move bits of this group / the group below */
     int b = 2;
 
-#ifdef ABEA_NO_ASM   /* the C++ twin of the band loop: reference semantics of one band (LDS-ring feeds); the shipped path is the asm below */
-    auto step = [&](auto border_tag) {
-        constexpr bool BORDER = decltype(border_tag)::value;
-        /* ---- Suzuki-Kasahara move (align.c:304-322): right = ll < ur, alternate when both are -inf ---- */
-        const float s_ll = readlane_f(Pf0, 0);
-        bool right;
-        if (__float_as_uint(s_ll) != 0xff800000u) {
-            right = ((__ballot(s_ll < Pf1) >> 49) & 1ull) != 0;      /* lane 49 slot 1 = offset 99 */
-        } else {
-            const float s_ur = readlane_f(Pf1, 49);
-            right = (__float_as_uint(s_ur) == 0xff800000u) ? ((b & 1) != 0) : true;
-        }
-        double D0, D1, nU0, nU1, nL0, nL1;
-        if (right) {
-            ll_k += 1;
-            /* k-mer parameters slide one offset down; nk (k-mer ll_k+127) enters at lane 63 slot 1 */
-            const float tg = dpp_from_upper_f(nkg, g0);
-            const float tc = dpp_from_upper_f(nkc, c0);
-            const double ti = dpp_from_upper_d(nki, i0);
-            g0 = g1; c0 = c1; i0 = i1;
-            g1 = tg; c1 = tc; i1 = ti;
-            k_next += 1;
-            if ((k_next & 63) == 0) {                  /* entering chunk c: land chunk c+1, fetch chunk c+2 */
-                const int c = k_next >> 6;
-                abea_kpar_t t; t.gpm = kpg; t.ck = kpc; t.istd = kpi;
-                k_ring[((c + 1) & 1) * 64 + lane] = t;
-                t = kpar[min((c + 2) * 64 + lane, K - 1)];
-                kpg = t.gpm; kpc = t.ck; kpi = t.istd;
-                __syncthreads();
-            }
-            { const abea_kpar_t t = k_ring[k_next & 127]; nkg = t.gpm; nkc = t.ck; nki = t.istd; }
-            nL0 = P0; nL1 = P1;
-            nU0 = P1; nU1 = dpp_from_upper_d((double)NINF, P0);
-            D0 = U0; D1 = U1;
-            mvacc = (mvacc << 1) | 1u;
-        } else {
-            ll_e += 1;
-            const float tx = dpp_from_lower_f(nx, x1);  /* lane 0 keeps nx = event ll_e */
-            x1 = x0; x0 = tx;
-            e_next += 1;
-            if ((e_next & 63) == 0) {
-                const int c = e_next >> 6;
-                e_ring[((c + 1) & 1) * 64 + lane] = e_pend;
-                e_pend = evm[min((c + 2) * 64 + lane, E - 1)];
-                __syncthreads();
-            }
-            nx = e_ring[e_next & 127];
-            nU0 = P0; nU1 = P1;
-            nL1 = P0; nL0 = dpp_from_lower_d((double)NINF, P1);
-            D0 = L0; D1 = L1;
-            mvacc = mvacc << 1;
-        }
-
-        /* ---- cells (align.c:337-409) ---- */
-        float m0, m1; uint32_t f0, f1;
-        abea_cell(x0, g0, c0, i0, D0, nU0, nL0, lp_step, lp_stay, lp_skip, m0, f0);
-        abea_cell(x1, g1, c1, i1, D1, nU1, nL1, lp_step, lp_stay, lp_skip, m1, f1);
-        if constexpr (BORDER) {
-            const int min_off = max(max(-ll_k, ll_e - (E - 1)), 0);
-            const int max_off = min(min(K - ll_k, ll_e + 1), ABEA_W);
-            const bool v0 = (o0 >= min_off) && (o0 < max_off);
-            const bool v1 = (o1 >= min_off) && (o1 < max_off);
-            m0 = v0 ? m0 : NINF; f0 = v0 ? f0 : 0u;
-            m1 = v1 ? m1 : NINF; f1 = v1 ? f1 : 0u;
-            /* trim column, k-mer -1 (align.c:324-333) */
-            const int trim_o = -1 - ll_k;
-            if (trim_o >= 0 && trim_o < ABEA_W) {
-                const int te = ll_e - trim_o;
-                if (te >= 0 && te < E) {
-                    const float tv = (float)(lp_trim * (double)(te + 1));
-                    if (o0 == trim_o) { m0 = tv; f0 = 1u; }
-                    if (o1 == trim_o) { m1 = tv; f1 = 1u; }
-                }
-            }
-        } else {
-            m0 = hi ? NINF : m0; m1 = hi ? NINF : m1;   /* all 100 band cells are in range here */
-        }
-
-        /* ---- rotate rows ---- */
-        U0 = nU0; U1 = nU1; L0 = nL0; L1 = nL1;
-        Pf0 = m0; Pf1 = m1; P0 = (double)m0; P1 = (double)m1;
-
-        /* ---- trace: oldest band in the top nibble, 8 bands per dword, 4 dwords per store ---- */
-        acc = (acc << 4) | (~(f0 | (f1 << 2)) & 15u);
-        if ((b & 7) == 7) {
-            a0 = a1; a1 = a2; a2 = a3; a3 = ~acc;
-            if ((b & 31) == 31) {
-                const bool ml = lane == ABEA_MOVE_LANE;
-                trace[(size_t)(b >> 5) * 64 + lane] = make_uint4(ml ? mvacc : a0, ml ? mvprev : a1, a2, a3);
-                mvprev = mvacc;
-            }
-        }
-
-        if constexpr (BORDER) {
-            /* ---- online end-point scan (align.c:424-445): bands visit events in increasing order ---- */
-            const int oc = (K - 1) - ll_k;
-            if (oc >= 0 && oc < ABEA_W) {
-                const int e = ll_e - oc;
-                if (e >= 0 && e < E) {
-                    const float sc = (oc & 1) ? readlane_f(Pf1, oc >> 1) : readlane_f(Pf0, oc >> 1);
-                    const float s = (float)((double)sc + (double)(E - e) * lp_trim);
-                    if (s > best) { best = s; best_e = e; best_llk = ll_k; }
-                }
-            }
-        }
-        ++b;
-    };
-#endif
 
     while (b < nb_pad) {
         /* bands for which every one of the 100 cells is inside the matrix and neither the trim column
          * nor the last k-mer column can be in band, whatever the moves: one of ll_e / ll_k grows per band */
         int run = min(min(E - 2 - ll_e, K - 102 - ll_k), nb_pad - b);
-#ifdef ABEA_NO_ASM
-        if (ll_k >= 0 && ll_e >= 99 && run > 0) {
-            for (; run > 0; --run) step(std::false_type{});
-#else
         {
-            /* hand-scheduled loops (tools/gen_fill_asm.py).  Interior variant: same semantics as step(false) x run
-             * while every cell is provably in range.  Border variant (validity masks, trim column, online end-point
-             * scan = step(true)): the first ~100 bands until ll_k >= 0 and ll_e >= 99, and everything after the
+            /* hand-scheduled loops (tools/gen_fill_asm.py; executed instruction by instruction against the oracle on the CPU by
+             * tools/gfx950_emu.py, tests/test_asm_emulated.py).  Interior variant: `run` bands of align.c:300-410 while every
+             * cell is provably in range.  Border variant (validity masks align.c:337-346, trim column align.c:324-333, online
+             * end-point scan align.c:424-445): the first ~100 bands until ll_k >= 0 and ll_e >= 99, and everything after the
              * band has touched the bottom/right edge of the matrix (never interior again: ll_e, ll_k only grow) */
             uint32_t toff = (uint32_t)lane * 16u + (uint32_t)(b >> 5) * 1024u;
             uint32_t t0, t1, t2, t3, t4, cnt, per; uint64_t cm0a, cm0b, cm1a, cm1b, cv0, cv1;
@@ -597,13 +479,7 @@ void abea_align_kernel(const abea_read_desc* __restrict__ descs,
             ll_e = s_ll_e; ll_k = s_ll_k; b = s_b; run = 0;
             mvacc = s_mvacc; mvprev = s_mvprev;
             P0 = (double)Pf0; P1 = (double)Pf1;
-#endif
         }
-#ifdef ABEA_NO_ASM
-        else {
-            step(std::true_type{});
-        }
-#endif
     }
     }
     __syncthreads();            /* this wave's trace stores are complete before it reads them back */
@@ -623,56 +499,7 @@ void abea_align_kernel(const abea_read_desc* __restrict__ descs,
      * in 4 VGPRs (one uint4 per lane); the 128 bits of the lane pair the path is in are held in SGPRs,
      * so a step is pure SALU bit picking; v_readlane only when the path changes lane pair or group.
      * Each step emits a 2-bit code; 16 codes -> one dword, 64 dwords -> one coalesced store. */
-#ifdef ABEA_NO_ASM
-    int e = best_e, k = K - 1, llk = best_llk;
-    int n = 0, gap = 0, max_gap = 0, last_k = k;
-    uint32_t cwd = 0, cv = 0, walk_reloads = 0;
-    {
-        int b = e + k + 2;
-        uint4 cw = trace[(size_t)(b >> 5) * 64 + lane];
-        bool alive = true;
-        while (alive) {                                    /* one iteration per 32-band trace group */
-            const int g = b >> 5;
-            const uint4 nxg = trace[(size_t)max(g - 1, 0) * 64 + lane];    /* prefetch the group below */
-            const uint64_t mv64 = ((uint64_t)(uint32_t)readlane_i(cw.y, ABEA_MOVE_LANE) << 32) |
-                                  (uint32_t)readlane_i(cw.x, ABEA_MOVE_LANE);
-            int lp = -1;
-            uint64_t tlo = 0, thi = 0;
-            do {
-                const int off = k - llk;                   /* band offset of (e,k): ll_k + off = k */
-                if ((off >> 1) != lp) {                    /* path moved to another lane pair */
-                    lp = off >> 1;
-                    tlo = ((uint64_t)(uint32_t)readlane_i(cw.y, lp) << 32) | (uint32_t)readlane_i(cw.x, lp);
-                    thi = ((uint64_t)(uint32_t)readlane_i(cw.w, lp) << 32) | (uint32_t)readlane_i(cw.z, lp);
-                }
-                const int bi = b & 31;
-                const int bp = 4 * (bi ^ 7) + 2 * (off & 1);
-                const uint64_t t64 = (bp & 64) ? thi : tlo;
-                const uint32_t from = min((uint32_t)(t64 >> (bp & 63)) & 3u, 2u);   /* 3 = FROM_L and FROM_U tie */
-                const uint32_t two = (uint32_t)(mv64 >> (31 - bi)) & 3u;   /* bit0 = move(b), bit1 = move(b-1) */
-                cwd |= from << ((n & 15) << 1);
-                ++n;
-                if ((n & 15) == 0) {
-                    if (lane == (((n >> 4) - 1) & 63)) cv = cwd;
-                    cwd = 0;
-                    if ((n & 1023) == 0) codes[(size_t)((n >> 10) - 1) * 64 + lane] = cv;
-                }
-                last_k = k;
-                const uint32_t isL = from >> 1;
-                const uint32_t notD = (from | isL) & 1u;   /* 0 only for FROM_D */
-                const int dk = (int)((from & 1u) ^ 1u);    /* D,L step the k-mer */
-                const int de = (int)(isL ^ 1u);            /* D,U step the event */
-                k -= dk; e -= de; b -= dk + de;
-                llk -= (int)(two & 1u) + (int)((two >> 1) & (notD ^ 1u));
-                gap = isL ? gap + 1 : 0;
-                max_gap = max(max_gap, gap);
-                alive = (k | e) >= 0;
-            } while (alive && (b >> 5) == g);
-            cw = nxg;
-        }
-    }
-#else
-    /* hand-written scalar walk (tools/gen_fill_asm.py: gen_walk), same semantics as the loop above */
+    /* hand-written scalar walk (tools/gen_fill_asm.py: gen_walk) */
     int n, max_gap, last_k;
     uint32_t cwd, cv, walk_reloads;
     {
@@ -687,7 +514,6 @@ void abea_align_kernel(const abea_read_desc* __restrict__ descs,
             : ABEA_WALK_CLOBBERS);
         n = (int)(o_nfl * 16u + o_sh2 / 2u);
     }
-#endif
     if ((n & 15) != 0 && lane == ((n >> 4) & 63)) cv = cwd;
     if ((n & 1023) != 0 && lane <= (((n - 1) >> 4) & 63)) codes[(size_t)(n >> 10) * 64 + lane] = cv;
     __syncthreads();                                     /* this wave's code words -> all its lanes */
@@ -742,7 +568,13 @@ void abea_align_kernel(const abea_read_desc* __restrict__ descs,
                 if (pairs) pairs[n - 1 - (i0 + j)] = p;
                 const abea_kpar_t kp = kpar[kk];
                 const float dx = __fsub_rn(evm[ee], kp.gpm);
+#ifdef ABEA_MARKSTEIN
+                const float sv = __int_as_float(__double2loint(kp.istd)), rr = __int_as_float(__double2hiint(kp.istd));
+                const float q_ = __fmul_rn(dx, rr);
+                const float a = __fmaf_rn(__fmaf_rn(-q_, sv, dx), rr, q_);
+#else
                 const float a = (float)((double)dx * kp.istd);
+#endif
                 lp = __fadd_rn(kp.ck, __fmul_rn(__fmul_rn(-0.5f, a), a));
                 const uint32_t cd = (w >> (2 * j)) & 3u;
                 if (map) {
@@ -1513,47 +1345,92 @@ void abea_ev_kmer_kernel(int n_reads, const int32_t* __restrict__ order, const c
     }
 }
 
-/* pass 5: estimate_scalings_using_mom (align.c:58-106), lane-per-read, sequential fp64 sums in the reference's order */
-extern "C" __global__ __launch_bounds__(64)
+/* pass 5: estimate_scalings_using_mom (align.c:58-106): lane-per-read, sequential fp64 sums in the reference's order.
+ * Four chains per read — Σ event mean, Σ level, Σ level², then Σ (mean − shift)² — whose terms arrive from HBM: rounds 1-4 let
+ * the one wavefront of 64 reads fetch its own terms (16 rows of 64 floats in flight, ~2 µs each: 9.7 of the detector's 22.7 ms
+ * per 2048 reads, profiles/r04/e_n2_kernel_stats.csv — a lone wave per 64 reads cannot keep enough loads in flight from its
+ * registers).  Round 5: the chains are fed from LDS, as phase 4 of the alignment kernel feeds recalibrate_model's.  A block is
+ * 8 wavefronts: wave 0 owns the 64 chains and reads its terms from LDS, waves 1..7 do nothing but stream the next tile of
+ * interleaved rows into the other half of a double buffer.  The order of every addition is untouched. */
+#define EV_SC_TILE 64                       /* rows per tile in pass A (two arrays); pass B uses 2 x EV_SC_TILE rows of one array */
+extern "C" __global__ __launch_bounds__(512)
 void abea_ev_scalings_kernel(int n_reads, const int32_t* __restrict__ order, const int64_t* __restrict__ peak_base,
                              const float* __restrict__ mean_all, const int32_t* __restrict__ n_events,
                              const int32_t* __restrict__ event_cap, const int32_t* __restrict__ read_len,
                              const int64_t* __restrict__ kmer_base, const float* __restrict__ kmean_all,
                              int kmer_size, abea_scalings_t* __restrict__ scalings) {
-    const int lane = threadIdx.x;
+    __shared__ float lds[4 * EV_SC_TILE * 64];                       /* 64 KiB: [2 buffers][2 arrays][TILE][64] or [2][2 x TILE][64] */
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int slot = blockIdx.x * 64 + lane;
-    if (slot >= n_reads) return;
-    const int r = order[slot];
-    const int n_ev = n_events[r];
-    const int ne = min(n_ev, event_cap[r]);
+    const bool live = slot < n_reads;
+    const int r = live ? order[slot] : 0;
+    const int n_ev = live ? n_events[r] : 0;
+    const int ne = live ? min(n_ev, event_cap[r]) : 0;
+    const int K = live ? read_len[r] - kmer_size + 1 : 0;
+    int ne_max = ne, k_max = K;                                       /* the same in all eight waves: they hold the same 64 reads */
+    for (int off = 32; off > 0; off >>= 1) { ne_max = max(ne_max, __shfl_xor(ne_max, off, 64)); k_max = max(k_max, __shfl_xor(k_max, off, 64)); }
     const float* __restrict__ mean = mean_all + peak_base[blockIdx.x] + lane;
-    /* the event-mean sum and the two k-mer sums are independent sequential chains: one loop carries all three */
-    const int K = read_len[r] - kmer_size + 1;
     const float* __restrict__ km = kmean_all + kmer_base[blockIdx.x] + lane;
+    /* ---- pass A: the event-mean sum and the two k-mer sums (three independent chains per lane) ---- */
     double ev_sum = 0.0, km_sum = 0.0, km_sq = 0.0;
-    const int n_it = max(ne, K);
-    for (int i0 = 0; i0 < n_it; i0 += 8) {
-        float m[8], l[8];
-        #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            m[j] = mean[(size_t)min(i0 + j, max(ne - 1, 0)) * 64];
-            l[j] = km[(size_t)min(i0 + j, max(K - 1, 0)) * 64];
-        }
-        #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            if (i0 + j < ne) ev_sum += m[j];
-            if (i0 + j < K) { const double x = l[j]; km_sum += x; km_sq += x * x; }
+    {
+        const int n_it = max(ne_max, k_max), tiles = (n_it + EV_SC_TILE - 1) / EV_SC_TILE;
+        auto fill = [&](int t) {                                      /* waves 1..7: rows of tile t, every 7th each */
+            float* bm = lds + (size_t)(t & 1) * 2 * EV_SC_TILE * 64;
+            float* bk = bm + EV_SC_TILE * 64;
+            for (int row = wv - 1; row < EV_SC_TILE; row += 7) {
+                const int i = t * EV_SC_TILE + row;
+                bm[row * 64 + lane] = i < ne_max ? mean[(size_t)i * 64] : 0.0f;    /* rows below the wave's longest table exist for every lane */
+                bk[row * 64 + lane] = i < k_max ? km[(size_t)i * 64] : 0.0f;
+            }
+        };
+        if (wv > 0 && tiles > 0) fill(0);
+        __syncthreads();
+        for (int t = 0; t < tiles; ++t) {
+            if (wv > 0) { if (t + 1 < tiles) fill(t + 1); }
+            else {
+                const float* bm = lds + (size_t)(t & 1) * 2 * EV_SC_TILE * 64;
+                const float* bk = bm + EV_SC_TILE * 64;
+                const int i0 = t * EV_SC_TILE;
+                #pragma unroll 8
+                for (int row = 0; row < EV_SC_TILE; ++row) {
+                    const float m = bm[row * 64 + lane], l = bk[row * 64 + lane];
+                    if (i0 + row < ne) ev_sum += m;
+                    if (i0 + row < K) { const double x = l; km_sum += x; km_sq += x * x; }
+                }
+            }
+            __syncthreads();
         }
     }
-    const double shift = ev_sum / n_ev - km_sum / K;
+    const double shift = ev_sum / n_ev - km_sum / K;                  /* waves 1..7 compute garbage here and never use it */
+    /* ---- pass B: Σ (mean − shift)² ---- */
     double ev_sq = 0.0;
-    for (int i0 = 0; i0 < ne; i0 += 8) {
-        float m[8];
-        #pragma unroll
-        for (int j = 0; j < 8; ++j) m[j] = mean[(size_t)min(i0 + j, ne - 1) * 64];
-        #pragma unroll
-        for (int j = 0; j < 8; ++j) if (i0 + j < ne) ev_sq += ((double)m[j] - shift) * ((double)m[j] - shift);
+    {
+        const int T2 = 2 * EV_SC_TILE, tiles = (ne_max + T2 - 1) / T2;
+        auto fill = [&](int t) {
+            float* bm = lds + (size_t)(t & 1) * T2 * 64;
+            for (int row = wv - 1; row < T2; row += 7) {
+                const int i = t * T2 + row;
+                bm[row * 64 + lane] = i < ne_max ? mean[(size_t)i * 64] : 0.0f;
+            }
+        };
+        if (wv > 0 && tiles > 0) fill(0);
+        __syncthreads();
+        for (int t = 0; t < tiles; ++t) {
+            if (wv > 0) { if (t + 1 < tiles) fill(t + 1); }
+            else {
+                const float* bm = lds + (size_t)(t & 1) * T2 * 64;
+                const int i0 = t * T2;
+                #pragma unroll 8
+                for (int row = 0; row < T2; ++row) {
+                    const double d = (double)bm[row * 64 + lane] - shift;
+                    if (i0 + row < ne) ev_sq += d * d;
+                }
+            }
+            __syncthreads();
+        }
     }
+    if (wv != 0 || !live) return;
     const double scale = (ev_sq / n_ev) / (km_sq / K);
     abea_scalings_t o; o.shift = (float)shift; o.scale = (float)scale; o.var = 1.0f; o.log_var = 0.0f;
     scalings[r] = o;

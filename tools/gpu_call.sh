@@ -45,6 +45,22 @@ for ln in sys.stdin:
     if 'name' not in r: print('$f', r); continue
     print('$f %-12s %7.1f ms  flat %6.1f unfl %5.1f wait %6.1f plan %4.1f  gpu_busy %7.1f' % (r['name'], r['ms_per_step'], r['flatten_ms'], r['unflatten_ms'], r['wait_ms'], r['plan_ms'], r.get('gpu_busy_ms', 0)))"; done
     ;;
+  exp)        # round-5 experiments: where GPU_MAX_HW_QUEUES takes effect for a C++ caller, the method-of-moments kernel, the Markstein quotient
+    step t_n2 500 python -m pytest tests/test_rna_events.py tests/test_process_chain.py tests/test_oracle_ecoli.py tests/test_fuzz_gpu.py -m gpu -x -q -k "not alignment_and_scaling" --durations=5
+    tail -8 $O/t_n2.log
+    step ab_markstein 300 python tools/ab_quick.py ship=f5c_amd/libabea_hip.so markstein=build/libabea_markstein.so ship2=f5c_amd/libabea_hip.so markstein2=build/libabea_markstein.so --config r9_10k_8kb --launches 6
+    grep "kernel ms" $O/ab_markstein.log
+    step n2prof 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/n2 -o n2 -- python tools/n2_profile.py 2048
+    grep "parameters" $O/n2prof.log; find $O/n2 -name "*kernel_stats.csv" | head -2
+    g++ -std=c++11 -O2 tests/shim_driver.cpp -o /tmp/shim_driver -Lf5c_amd -labea_hip -Wl,-rpath,$GRAFT_REPO_ROOT/f5c_amd
+    step dump 200 python tools/probe/dump_batch.py r9_10k_8kb /tmp/b10k.bin
+    for q in lib 4 16; do
+      if [ $q = lib ]; then unset GPU_MAX_HW_QUEUES; else export GPU_MAX_HW_QUEUES=$q; fi
+      SHIM_REPS=6 SHIM_NOPRINT=1 timeout -k 10 200 /tmp/shim_driver /tmp/b10k.bin /dev/null 2> $O/shim_q$q.log
+      echo "C++ caller, GPU_MAX_HW_QUEUES=$q: $(grep wall $O/shim_q$q.log | awk '{print $4}' | tr '\n' ' ')"
+    done | tee $O/hw_queues_cpp_caller.txt
+    unset GPU_MAX_HW_QUEUES
+    ;;
   tests)      # the whole GPU suite + the bench line of the build that ships
     step gpu_tests 900 python -m pytest tests -m gpu -x -q --durations=10
     tail -16 $O/gpu_tests.log
