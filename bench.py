@@ -522,15 +522,31 @@ def cgroup_cpu_stat():
     return out
 
 
+def kernel_code_sha():
+    """sha256 of the sources abea_align_kernel is built from — the same digest profiles/make_pmc_traffic.py stores next to the
+    counters it extracts: static counters are quoted only for the code they were measured on."""
+    import hashlib
+    h = hashlib.sha256()
+    for rel in ("f5c_amd/csrc/abea_fill.inc", "f5c_amd/csrc/abea_walk.inc", "f5c_amd/csrc/abea_kernels.hip"):
+        h.update(open(os.path.join(ROOT, rel), "rb").read())
+    return h.hexdigest()
+
+
+def pmc_entry(config):
+    """profiles/pmc_traffic.json[config] if its counters were taken on the kernel sources of this tree, else None"""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))[config]
+        return t if t.get("code_sha256") == kernel_code_sha() else None
+    except Exception:
+        return None
+
+
 def pmc_traffic(config, sum_events, launches):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of `bench.py --mode device`
     on the same workload (profiles/pmc_traffic.json: FETCH_SIZE and WRITE_SIZE both measured on this config, separate
     passes, FETCH doubled per MI355X_MICROARCH.md §HBM)."""
-    try:
-        t = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))[config]
-        return int(t["hbm_bytes_per_event"] * sum_events / max(1, launches))
-    except Exception:
-        return None
+    t = pmc_entry(config)                    # None (-> "traffic": null) when the kernel sources changed since the PMC passes
+    return int(t["hbm_bytes_per_event"] * sum_events / max(1, launches)) if t else None
 
 
 def valu_issue(config, sum_events, launch_ms, launches):
@@ -539,13 +555,17 @@ def valu_issue(config, sum_events, launch_ms, launches):
     `bench.py --mode device` on the same workload (profiles/pmc_traffic.json, built by profiles/make_pmc_traffic.py) — not an
     instruction count times a cost constant (round 2's model gave 1.025, an impossible fraction)."""
     try:
-        t = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))[config]
+        t = pmc_entry(config)
+        if t is None:
+            return {"unit": "valu-busy", "static": True, "stale": True, "code_sha256": kernel_code_sha(),
+                    "static_note": "profiles/pmc_traffic.json was taken on other kernel sources (code_sha256 differs): no counters quoted"}
         # the counter books one quad-cycle per VALU instruction of any class and the per-XCD GRBM clocks are averaged, so the
         # measured ratio is good to about 1 %: it reads 1.0015 on this workload ("saturated"); frac is capped at 1, raw kept
         prof_ms = t["kernel_ms_in_each_pass"].get("sqb")
-        return {"unit": "valu-busy", "static": True,
-                "static_note": "counter ratio of the committed PMC pass (profiles/pmc_traffic.json), NOT measured in this run; "
-                               "stale if kernel_ms_this_run is more than 3 % from kernel_ms_in_the_pmc_pass",
+        return {"unit": "valu-busy", "static": True, "code_sha256": t["code_sha256"],
+                "static_note": "counter ratio of the committed PMC pass (profiles/pmc_traffic.json), NOT measured in this run; tied to the "
+                               "kernel sources by code_sha256 (abea_fill.inc + abea_walk.inc + abea_kernels.hip, recomputed here), and "
+                               "stale as well if kernel_ms_this_run is more than 3 % from kernel_ms_in_the_pmc_pass",
                 "stale": bool(prof_ms is None or abs(launch_ms - prof_ms) > 0.03 * prof_ms),
                 "frac": round(min(1.0, t["valu_busy"]), 4), "raw_counter_ratio": round(t["valu_busy"], 4),
                 "formula": t["valu_busy_formula"],
@@ -568,10 +588,7 @@ def valu_roofline(config, sum_events, launch_ms, launches, n_right=0, n_down=0):
                     full rate: 2 cycles), times the right-move and down-move bands of this launch.  A true lower bound of the
                     kernel time (walk and expansion add to it)."""
     try:
-        try:
-            t = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))[config]
-        except Exception:
-            t = {}
+        t = pmc_entry(config) or {}
         clk = t.get("shader_clock_ghz", 2.4)                    # measured GRBM clock of the SQ pass; 2.4 GHz nominal without one
         out = {"measured_ms": round(launch_ms, 3), "shader_clock_ghz": round(clk, 3)}
         if "valu_wave_instr_per_event" in t:

@@ -19,11 +19,7 @@
 #include <hip/hip_runtime.h>
 #include <type_traits>
 #include "abea_device.h"
-#ifdef ABEA_MARKSTEIN            /* EXPERIMENT build only (tools/gpu_call.sh markstein): the quotient as three f32 instructions */
-#include "abea_fill_exp.inc"
-#else
 #include "abea_fill.inc"
-#endif
 #include "abea_walk.inc"
 
 #define NINF (-__builtin_inff())
@@ -115,12 +111,7 @@ void abea_pre_kernel(const abea_read_desc* __restrict__ descs,
         abea_kpar_t p;
         p.gpm  = __fadd_rn(__fmul_rn(scale, m.level_mean), shift);   /* align.c:137-138, mul then add, no FMA */
         p.ck   = __fsub_rn(-0.918938f, m.level_log_stdv);            /* align.c:111-113 */
-#ifdef ABEA_MARKSTEIN
-        { const float rr = (float)(1.0 / (double)m.level_stdv);      /* the quad's last two dwords: {stdv, RN32(1/stdv)} */
-          p.istd = __hiloint2double(__float_as_int(rr), __float_as_int(m.level_stdv)); }
-#else
         p.istd = 1.0 / (double)m.level_stdv;
-#endif
         kp[i] = p;
     }
     if (!events) return;                               /* host path: the means were uploaded straight into evm */
@@ -136,13 +127,7 @@ static __device__ __forceinline__ void abea_cell(float x, float gpm, float ck, d
                                                  double lp_step, double lp_stay, double lp_skip,
                                                  float& m, uint32_t& from) {
     float dx = __fsub_rn(x, gpm);
-#ifdef ABEA_MARKSTEIN
-    const float sv = __int_as_float(__double2loint(istd)), rr = __int_as_float(__double2hiint(istd));
-    const float q_ = __fmul_rn(dx, rr);
-    float a = __fmaf_rn(__fmaf_rn(-q_, sv, dx), rr, q_);
-#else
     float a  = (float)((double)dx * istd);                     /* == dx / stdv, correctly rounded */
-#endif
     /* align.c:113: ck + (-0.5f*a)*a.  Halving is exact, so RN((-0.5a)*a) = -0.5*RN(a*a) and one fma adds that product to ck
      * with the single rounding of the reference's add (identical unless a*a underflows and ck == 0: one subnormal ulp) */
     float lp = __fmaf_rn(-0.5f, __fmul_rn(a, a), ck);
@@ -568,13 +553,7 @@ void abea_align_kernel(const abea_read_desc* __restrict__ descs,
                 if (pairs) pairs[n - 1 - (i0 + j)] = p;
                 const abea_kpar_t kp = kpar[kk];
                 const float dx = __fsub_rn(evm[ee], kp.gpm);
-#ifdef ABEA_MARKSTEIN
-                const float sv = __int_as_float(__double2loint(kp.istd)), rr = __int_as_float(__double2hiint(kp.istd));
-                const float q_ = __fmul_rn(dx, rr);
-                const float a = __fmaf_rn(__fmaf_rn(-q_, sv, dx), rr, q_);
-#else
                 const float a = (float)((double)dx * kp.istd);
-#endif
                 lp = __fadd_rn(kp.ck, __fmul_rn(__fmul_rn(-0.5f, a), a));
                 const uint32_t cd = (w >> (2 * j)) & 3u;
                 if (map) {
@@ -1378,10 +1357,18 @@ void abea_ev_scalings_kernel(int n_reads, const int32_t* __restrict__ order, con
         auto fill = [&](int t) {                                      /* waves 1..7: rows of tile t, every 7th each */
             float* bm = lds + (size_t)(t & 1) * 2 * EV_SC_TILE * 64;
             float* bk = bm + EV_SC_TILE * 64;
-            for (int row = wv - 1; row < EV_SC_TILE; row += 7) {
-                const int i = t * EV_SC_TILE + row;
-                bm[row * 64 + lane] = i < ne_max ? mean[(size_t)i * 64] : 0.0f;    /* rows below the wave's longest table exist for every lane */
-                bk[row * 64 + lane] = i < k_max ? km[(size_t)i * 64] : 0.0f;
+            constexpr int PER = (EV_SC_TILE + 6) / 7;                 /* all of a loader's loads are issued before the first LDS write: */
+            float rm[PER], rk[PER];                                   /* 2 x PER rows in flight per wave, not one */
+            #pragma unroll
+            for (int j = 0; j < PER; ++j) {
+                const int row = wv - 1 + 7 * j, i = t * EV_SC_TILE + row;
+                rm[j] = (row < EV_SC_TILE && i < ne_max) ? mean[(size_t)i * 64] : 0.0f;   /* rows below the wave's longest table exist for every lane */
+                rk[j] = (row < EV_SC_TILE && i < k_max) ? km[(size_t)i * 64] : 0.0f;
+            }
+            #pragma unroll
+            for (int j = 0; j < PER; ++j) {
+                const int row = wv - 1 + 7 * j;
+                if (row < EV_SC_TILE) { bm[row * 64 + lane] = rm[j]; bk[row * 64 + lane] = rk[j]; }
             }
         };
         if (wv > 0 && tiles > 0) fill(0);
@@ -1409,9 +1396,17 @@ void abea_ev_scalings_kernel(int n_reads, const int32_t* __restrict__ order, con
         const int T2 = 2 * EV_SC_TILE, tiles = (ne_max + T2 - 1) / T2;
         auto fill = [&](int t) {
             float* bm = lds + (size_t)(t & 1) * T2 * 64;
-            for (int row = wv - 1; row < T2; row += 7) {
-                const int i = t * T2 + row;
-                bm[row * 64 + lane] = i < ne_max ? mean[(size_t)i * 64] : 0.0f;
+            constexpr int PER = (2 * EV_SC_TILE + 6) / 7;
+            float rm[PER];
+            #pragma unroll
+            for (int j = 0; j < PER; ++j) {
+                const int row = wv - 1 + 7 * j, i = t * T2 + row;
+                rm[j] = (row < T2 && i < ne_max) ? mean[(size_t)i * 64] : 0.0f;
+            }
+            #pragma unroll
+            for (int j = 0; j < PER; ++j) {
+                const int row = wv - 1 + 7 * j;
+                if (row < T2) bm[row * 64 + lane] = rm[j];
             }
         };
         if (wv > 0 && tiles > 0) fill(0);

@@ -7,7 +7,21 @@ config.  Corrections / definitions (MI355X_MICROARCH.md, HBM and rocprofv3 secti
   valu_busy   = SQ_ACTIVE_INST_VALU x 4 / (n_simd x GRBM_GUI_ACTIVE / n_xcd)     the gfx9 VALUBusy formula: SQ_ACTIVE_INST_* count
                 quad-cycles summed over waves, GRBM_GUI_ACTIVE counts cycles summed over the 8 XCDs
   wave-time split: SQ_ACTIVE_INST_ANY + SQ_WAIT_INST_ANY + SQ_WAIT_ANY = SQ_WAVE_CYCLES (issuing / issue-stalled / parked)"""
-import collections, csv, json, os, sys
+import collections, csv, hashlib, json, os, sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KERNEL_SOURCES = ("f5c_amd/csrc/abea_fill.inc", "f5c_amd/csrc/abea_walk.inc", "f5c_amd/csrc/abea_kernels.hip")
+
+
+def code_sha():
+    """sha256 over the sources abea_align_kernel is built from: the counters below describe THIS code (run this script on the
+    tree the passes were taken with); bench.py recomputes it and refuses the static numbers when it differs (round-4 verdict:
+    a time window is not a guard)."""
+    h = hashlib.sha256()
+    for rel in KERNEL_SOURCES:
+        h.update(open(os.path.join(ROOT, rel), "rb").read())
+    return h.hexdigest()
+
 
 EVENTS = {"10k": ("r9_10k_8kb", 158727291), "100k": ("r9_100k_mixed", 2514312019)}
 N_SIMD, N_XCD = 1024, 8
@@ -39,6 +53,7 @@ def main(prefix):
              "FETCH_SIZE_KB": c["FETCH_SIZE"], "WRITE_SIZE_KB": c["WRITE_SIZE"],
              "fetch_bytes_per_event_x2": c["FETCH_SIZE"] * 2048 / events, "write_bytes_per_event": c["WRITE_SIZE"] * 1024 / events,
              "hbm_bytes_per_launch": hbm, "hbm_bytes_per_event": hbm / events,
+             "code_sha256": code_sha(), "code_sha256_of": list(KERNEL_SOURCES),
              "kernel_ms_in_each_pass": kms, "passes": src,
              "sq_counters_per_launch": {k: v for k, v in sorted(c.items()) if k.startswith("SQ_") or k.startswith("GRBM")}}
         if "SQ_ACTIVE_INST_VALU" in c and "GRBM_GUI_ACTIVE" in c:

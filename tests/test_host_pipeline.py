@@ -672,3 +672,35 @@ def test_kmer_count_expansion_every_length_and_alignment():
             assert (buf[:off] == -7).all() and (buf[off + K:] == -7).all(), (K, off)
             c[r.integers(0, K)] = 255
             assert lib.abea_expand_kmer_counts_to_map(c.ctypes.data, K, end, out.ctypes.data) != 0
+
+
+def test_expansion_sweeps_through_the_scalar_fallback():
+    """The expansion path (AVX2 / plain loop) is latched once per process, so on an AVX2 host the in-process sweeps above only ever
+    run the vector code (round-4 advisor finding): re-run both in a child with ABEA_HOST_SCALAR_EXPAND=1."""
+    import sys
+    env = dict(os.environ, ABEA_HOST_SCALAR_EXPAND="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-p", "no:cacheprovider", os.path.abspath(__file__), "-k",
+                        "every_length_and_alignment or kmer_count_expansion_matches_postalign or walk_code_expansion_matches"],
+                       env=env, capture_output=True, text=True, cwd=ROOT)
+    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_flatten_loop_every_length_prefetch_and_hint():
+    """abea_flatten_event_means = the flatten loop of the host entry: means[e] = events[e].mean for every table length, with and
+    without the software prefetch (distances beyond the table included), every hint; nothing written past the table."""
+    import ctypes
+    from f5c_amd import abea
+    from f5c_amd.types import EVENT_DT
+    lib = abea.load_library()
+    lib.abea_flatten_event_means.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32]
+    r = np.random.default_rng(11)
+    for E in list(range(0, 40)) + [255, 256, 1000, 4099]:
+        ev = np.zeros(E, dtype=EVENT_DT)
+        ev["mean"] = r.normal(90, 12, E).astype(np.float32); ev["start"] = np.arange(E); ev["stdv"] = 1.5; ev["length"] = 9
+        out = np.zeros(E + 12, dtype=np.float32)                       # numpy data is 16-byte aligned
+        for pf in (0, 64, 1536, 65536):
+            for hint in (0, 1, 2):
+                out[:] = -1
+                assert lib.abea_flatten_event_means(ev.ctypes.data, E, out.ctypes.data, pf, hint) == 0
+                assert (out[:E] == ev["mean"]).all() and (out[E:] == -1).all(), (E, pf, hint)
+    assert lib.abea_flatten_event_means(ev.ctypes.data, 4, out.ctypes.data + 4, 0, 0) != 0   # misaligned destination: refused

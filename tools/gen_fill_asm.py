@@ -81,7 +81,6 @@ def emit(s):
     out.append(s)
 
 
-MARKSTEIN = os.environ.get("ABEA_GEN_MARKSTEIN") == "1"   # experiment: writes abea_fill_exp.inc (git-ignored), never abea_fill.inc
 CHECK_ONLY = "--check" in __import__("sys").argv     # compare with the committed .inc files instead of writing them
 stale = []
 
@@ -127,24 +126,11 @@ def cell_ops(j, D, U, L, quad):
     sd, su, sl = td, tu, lpd   # after the adds the pair's low dword holds the float result (cvt in place)
     cm1, cm2 = f"%[cm{j}a]", f"%[cm{j}b]"
     mf = MF0 + j
-    if MARKSTEIN:
-        # EXPERIMENT (round 5, profiles/r05/experiments/markstein_quotient.md): a = dx / stdv as the f32 Markstein sequence
-        # q = dx*r; e = fma(-q, stdv, dx); a = fma(e, r, q) with r = RN32(1/stdv) — three full-rate f32 instructions instead of
-        # cvt / v_mul_f64 / cvt.  The k-mer quad carries {gpm, ck, stdv, r} instead of {gpm, ck, istd(f64)}.
-        quot = [
-            f"v_sub_f32 {v(t32)}, {v(x)}, {v(g)}",
-            f"v_mul_f32 {v(tu)}, {v(t32)}, {v(i + 1)}",
-            f"v_fma_f32 {v(t32)}, -{v(tu)}, {v(i)}, {v(t32)}",
-            f"v_fma_f32 {v(t32)}, {v(t32)}, {v(i + 1)}, {v(tu)}",
-        ]
-    else:
-        quot = [
-            f"v_sub_f32 {v(t32)}, {v(x)}, {v(g)}",
-            f"v_cvt_f64_f32 {vp(lpd)}, {v(t32)}",
-            f"v_mul_f64 {vp(lpd)}, {vp(lpd)}, {vp(i)}",
-            f"v_cvt_f32_f64 {v(t32)}, {vp(lpd)}",
-        ]
-    ops = quot + [
+    ops = [
+        f"v_sub_f32 {v(t32)}, {v(x)}, {v(g)}",
+        f"v_cvt_f64_f32 {vp(lpd)}, {v(t32)}",
+        f"v_mul_f64 {vp(lpd)}, {vp(lpd)}, {vp(i)}",
+        f"v_cvt_f32_f64 {v(t32)}, {vp(lpd)}",
         # lp = ck + (-0.5f*a)*a (align.c:113) in two instructions: halving is exact, so RN((-0.5a)*a) = -0.5*RN(a*a), and the
         # fma adds that exact product to ck with the ONE rounding the reference's add performs.  (Differs from the three-
         # instruction form only when a*a underflows AND ck == 0: by one subnormal ulp, 1e-45, of a term that is added to
@@ -565,8 +551,7 @@ def main():
 {text.replace(chr(10), " " + chr(92) + chr(10))}
 #define ABEA_FILL_CLOBBERS {clob}, "vcc", "scc", "memory"
 """
-    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "f5c_amd", "csrc",
-                        "abea_fill_exp.inc" if MARKSTEIN else "abea_fill.inc")
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "f5c_amd", "csrc", "abea_fill.inc")
     _emit_file(path, inc, len(lines))
 
 
@@ -736,7 +721,6 @@ def _finish_walk(o):
 
 
 if __name__ == "__main__":
-    if not MARKSTEIN:
-        gen_walk()
+    gen_walk()
     if stale:
         raise SystemExit(f"generated files differ from tools/gen_fill_asm.py output: {stale}")

@@ -61,6 +61,14 @@ for ln in sys.stdin:
     done | tee $O/hw_queues_cpp_caller.txt
     unset GPU_MAX_HW_QUEUES
     ;;
+  exp2)       # the two-wave-per-read model of a band (tools/ubench/two_wave_band.hip) + the method-of-moments kernel again
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -w tools/ubench/two_wave_band.hip -o /tmp/two_wave_band && step two_wave 120 /tmp/two_wave_band
+    cat $O/two_wave.log
+    step t_n2 300 python -m pytest tests/test_rna_events.py tests/test_process_chain.py tests/test_oracle_ecoli.py -m gpu -x -q
+    tail -3 $O/t_n2.log
+    step n2prof 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/n2 -o n2 -- python tools/n2_profile.py 2048
+    grep "parameters" $O/n2prof.log; grep "scalings\|copyBuffer" $O/n2/n2_kernel_stats.csv | cut -d, -f1-6
+    ;;
   tests)      # the whole GPU suite + the bench line of the build that ships
     step gpu_tests 900 python -m pytest tests -m gpu -x -q --durations=10
     tail -16 $O/gpu_tests.log
