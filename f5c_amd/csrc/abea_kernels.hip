@@ -1381,9 +1381,11 @@ void abea_ev_scalings_kernel(int n_reads, const int32_t* __restrict__ order, con
                 const int i0 = t * EV_SC_TILE;
                 #pragma unroll 8
                 for (int row = 0; row < EV_SC_TILE; ++row) {
-                    const float m = bm[row * 64 + lane], l = bk[row * 64 + lane];
-                    if (i0 + row < ne) ev_sum += m;
-                    if (i0 + row < K) { const double x = l; km_sum += x; km_sq += x * x; }
+                    /* past a lane's own end the term is +0.0: x + (+0.0) == x bit for bit (the sums start at +0.0 and never
+                     * become -0.0), so the tile needs no per-lane branches */
+                    const double m = (i0 + row < ne) ? (double)bm[row * 64 + lane] : 0.0;
+                    const double x = (i0 + row < K) ? (double)bk[row * 64 + lane] : 0.0;
+                    ev_sum += m; km_sum += x; km_sq += x * x;
                 }
             }
             __syncthreads();
@@ -1419,7 +1421,7 @@ void abea_ev_scalings_kernel(int n_reads, const int32_t* __restrict__ order, con
                 #pragma unroll 8
                 for (int row = 0; row < T2; ++row) {
                     const double d = (double)bm[row * 64 + lane] - shift;
-                    if (i0 + row < ne) ev_sq += d * d;
+                    ev_sq += (i0 + row < ne) ? d * d : 0.0;
                 }
             }
             __syncthreads();

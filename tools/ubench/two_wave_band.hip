@@ -14,30 +14,64 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 
-#define CELL(x, g, ck, istd, D, U, L, lpd, td, tu, mf, fr)                                                       \
-    "v_sub_f32 " td ", " x ", " g "\n"                                                                          \
-    "v_cvt_f64_f32 " lpd ", " td "\n"                                                                           \
-    "v_mul_f64 " lpd ", " lpd ", " istd "\n"                                                                    \
-    "v_cvt_f32_f64 " td ", " lpd "\n"                                                                           \
-    "v_mul_f32 " tu ", " td ", " td "\n"                                                                        \
-    "v_fma_f32 " tu ", -0.5, " tu ", " ck "\n"                                                                  \
-    "v_cvt_f64_f32 " lpd ", " tu "\n"                                                                           \
-    "v_add_f64 " td ", " D ", %[lp]\n"                                                                          \
-    "v_add_f64 " tu ", " U ", %[lp]\n"                                                                          \
-    "v_add_f64 " td ", " td ", " lpd "\n"                                                                       \
-    "v_add_f64 " tu ", " tu ", " lpd "\n"                                                                       \
-    "v_add_f64 " lpd ", " L ", %[lp]\n"                                                                         \
-    "v_cvt_f32_f64 " td ", " td "\n"                                                                            \
-    "v_cvt_f32_f64 " tu ", " tu "\n"                                                                            \
-    "v_cvt_f32_f64 " lpd ", " lpd "\n"                                                                          \
-    "v_max3_f32 " mf ", " td ", " tu ", " lpd "\n"                                                              \
-    "v_sub_f32 " fr ", " tu ", " td "\n"                                                                        \
-    "v_sub_f32 " td ", " lpd ", " mf "\n"
-
+// GENERATED (see the git history of this file for the three-line generator): cell 0 alone, and cells 0 and 1 interleaved as
+// tools/gen_fill_asm.py interleaves them (an in-order wave issues the two independent chains alternately)
+#define C0 "v_sub_f32 v72, v78, v79\n" \
+    "v_cvt_f64_f32 v[70:71], v72\n" \
+    "v_mul_f64 v[70:71], v[70:71], v[82:83]\n" \
+    "v_cvt_f32_f64 v72, v[70:71]\n" \
+    "v_mul_f32 v74, v72, v72\n" \
+    "v_fma_f32 v74, -0.5, v74, v80\n" \
+    "v_cvt_f64_f32 v[70:71], v74\n" \
+    "v_add_f64 v[72:73], v[64:65], %[lp]\n" \
+    "v_add_f64 v[74:75], v[66:67], %[lp]\n" \
+    "v_add_f64 v[72:73], v[72:73], v[70:71]\n" \
+    "v_add_f64 v[74:75], v[74:75], v[70:71]\n" \
+    "v_add_f64 v[70:71], v[68:69], %[lp]\n" \
+    "v_cvt_f32_f64 v72, v[72:73]\n" \
+    "v_cvt_f32_f64 v74, v[74:75]\n" \
+    "v_cvt_f32_f64 v70, v[70:71]\n" \
+    "v_max3_f32 v76, v72, v74, v70\n" \
+    "v_sub_f32 v77, v74, v72\n" \
+    "v_sub_f32 v72, v70, v76\n"
+#define C01 "v_sub_f32 v72, v78, v79\n" \
+    "v_sub_f32 v96, v102, v103\n" \
+    "v_cvt_f64_f32 v[70:71], v72\n" \
+    "v_cvt_f64_f32 v[94:95], v96\n" \
+    "v_mul_f64 v[70:71], v[70:71], v[82:83]\n" \
+    "v_mul_f64 v[94:95], v[94:95], v[106:107]\n" \
+    "v_cvt_f32_f64 v72, v[70:71]\n" \
+    "v_cvt_f32_f64 v96, v[94:95]\n" \
+    "v_mul_f32 v74, v72, v72\n" \
+    "v_mul_f32 v98, v96, v96\n" \
+    "v_fma_f32 v74, -0.5, v74, v80\n" \
+    "v_fma_f32 v98, -0.5, v98, v104\n" \
+    "v_cvt_f64_f32 v[70:71], v74\n" \
+    "v_cvt_f64_f32 v[94:95], v98\n" \
+    "v_add_f64 v[72:73], v[64:65], %[lp]\n" \
+    "v_add_f64 v[96:97], v[88:89], %[lp]\n" \
+    "v_add_f64 v[74:75], v[66:67], %[lp]\n" \
+    "v_add_f64 v[98:99], v[90:91], %[lp]\n" \
+    "v_add_f64 v[72:73], v[72:73], v[70:71]\n" \
+    "v_add_f64 v[96:97], v[96:97], v[94:95]\n" \
+    "v_add_f64 v[74:75], v[74:75], v[70:71]\n" \
+    "v_add_f64 v[98:99], v[98:99], v[94:95]\n" \
+    "v_add_f64 v[70:71], v[68:69], %[lp]\n" \
+    "v_add_f64 v[94:95], v[92:93], %[lp]\n" \
+    "v_cvt_f32_f64 v72, v[72:73]\n" \
+    "v_cvt_f32_f64 v96, v[96:97]\n" \
+    "v_cvt_f32_f64 v74, v[74:75]\n" \
+    "v_cvt_f32_f64 v98, v[98:99]\n" \
+    "v_cvt_f32_f64 v70, v[70:71]\n" \
+    "v_cvt_f32_f64 v94, v[94:95]\n" \
+    "v_max3_f32 v76, v72, v74, v70\n" \
+    "v_max3_f32 v100, v96, v98, v94\n" \
+    "v_sub_f32 v77, v74, v72\n" \
+    "v_sub_f32 v101, v98, v96\n" \
+    "v_sub_f32 v72, v70, v76\n" \
+    "v_sub_f32 v96, v94, v100\n"
 // fixed registers: v[64:65] D0, v[66:67] U0, v[68:69] L0, v[70:71] lpd0, v[72:73] td0, v[74:75] tu0, v76 mf0, v77 fr0, v78 x0,
 //                  v79 g0, v80 ck0, v[82:83] istd0; cell 1: +24
-#define C0 CELL("v78", "v79", "v80", "v[82:83]", "v[64:65]", "v[66:67]", "v[68:69]", "v[70:71]", "v[72:73]", "v[74:75]", "v76", "v77")
-#define C1 CELL("v102", "v103", "v104", "v[106:107]", "v[88:89]", "v[90:91]", "v[92:93]", "v[94:95]", "v[96:97]", "v[98:99]", "v100", "v101")
 // this band's maxima -> exact f64 copies -> shifted by one lane: the next band's U / L (D = the previous U): the loop-carried chain
 #define CARRY0                                                                                                   \
     "v_cvt_f64_f32 v[64:65], v76\n"                                                                             \
@@ -71,7 +105,7 @@
 __global__ void __launch_bounds__(64) one_wave(float* out, int bands) {
     const double lp = -0.7;
     asm volatile(INIT ::: CLOB);
-    for (int b = 0; b < bands; ++b) asm volatile(C0 C1 CARRY0 CARRY1 BOOK :: [lp] "v"(lp) : CLOB);
+    for (int b = 0; b < bands; ++b) asm volatile(C01 CARRY0 CARRY1 BOOK :: [lp] "v"(lp) : CLOB);
     float r; asm volatile("v_mov_b32 %0, v76" : "=v"(r)); out[blockIdx.x * 64 + threadIdx.x] = r;
 }
 // two wavefronts, one cell per lane: the boundary score (offset 49 <-> 50) and the band-end scores cross through LDS
