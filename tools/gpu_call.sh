@@ -72,12 +72,52 @@ for ln in sys.stdin:
   tests)      # the whole GPU suite + the bench line of the build that ships
     step gpu_tests 900 python -m pytest tests -m gpu -x -q --durations=10
     tail -16 $O/gpu_tests.log
-    timeout -k 10 420 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?" >> $O/steps.txt
-    tail -c 3000 $O/bench.json
+    t0=$(date +%s); timeout -k 10 600 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$? $(( $(date +%s) - t0 )) s" >> $O/steps.txt
+    python tools/bench_summary.py $O/bench.json
+    ;;
+  bench)      # the bench line alone (the driver's command)
+    t0=$(date +%s); timeout -k 10 600 python bench.py ${BENCH_ARGS:-} > $O/bench.json 2> $O/bench.err; echo "bench rc=$? $(( $(date +%s) - t0 )) s" >> $O/steps.txt
+    tail -3 $O/bench.err; python tools/bench_summary.py $O/bench.json
     ;;
   quick)      # the GPU suite without the full-size configs
     step gpu_tests 600 python -m pytest tests -m gpu -x -q --durations=10 --deselect tests/test_full_size.py ${PYTEST_ARGS:-}
     tail -16 $O/gpu_tests.log
+    ;;
+  prof100a|prof100b|prof10)   # rocprofv3 passes of `bench.py --mode device` on the build that ships (what profiles/pmc_traffic.json is made from):
+              # prof100a = configs[2] kernel trace + FETCH + WRITE, prof100b = configs[2] SQ passes A / B, prof10 = all five on configs[1].
+              # PMC passes carry only --kernel-trace (gpurun refuses counters combined with the other trace domains).
+    SQA="SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE"
+    SQB="SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VALU SQ_BUSY_CU_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA SQ_WAVE_CYCLES"
+    pass() {   # name, timeout, rocprofv3 options ..., -- command
+      local name=$1 to=$2; shift 2
+      local t0=$(date +%s)
+      timeout -k 10 $to rocprofv3 --kernel-trace --output-format csv -d $O/$name -o $name "$@" > $O/$name.log 2>&1
+      echo "$name rc=$? $(( $(date +%s) - t0 )) s" >> $O/steps.txt
+    }
+    DEV100="python bench.py --mode device --device-steps 2 --no-cpu-baseline"
+    DEV10="python bench.py --mode device --config r9_10k_8kb --device-steps 3 --no-cpu-baseline --arena-gib 40"
+    if [ $STAGE = prof100a ]; then
+      pass kt100k 330 --stats -- $DEV100
+      pass pmc_fetch100k 330 --pmc FETCH_SIZE -- $DEV100
+      pass pmc_write100k 330 --pmc WRITE_SIZE -- $DEV100
+    elif [ $STAGE = prof100b ]; then
+      pass pmc_sqa100k 330 --pmc $SQA -- $DEV100
+      pass pmc_sqb100k 330 --pmc $SQB GRBM_GUI_ACTIVE -- $DEV100
+    else
+      pass kt10k 150 --stats -- $DEV10
+      pass pmc_sqa10k 150 --pmc $SQA -- $DEV10
+      pass pmc_sqb10k 150 --pmc $SQB GRBM_GUI_ACTIVE -- $DEV10
+      pass pmc_fetch10k 150 --pmc FETCH_SIZE -- $DEV10
+      pass pmc_write10k 150 --pmc WRITE_SIZE -- $DEV10
+    fi
+    find $O -name "*kernel_trace.csv" -size +20M -delete
+    find $O -name "*.csv" | head -40
+    ;;
+  phase4)     # A/B of the fused scaling_single phase (device-resident launches, one process) + the GPU suite without the full-size configs
+    step ab_phase4 400 python tools/ab_quick.py r04before=build/libabea_r05_before_phase4_prefetch.so r04after=f5c_amd/libabea_hip.so r04before2=build/libabea_r05_before_phase4_prefetch.so r04after2=f5c_amd/libabea_hip.so --config r9_10k_8kb --launches 4 --scaling-launches 5
+    grep "kernel ms" $O/ab_phase4.log
+    step gpu_tests 600 python -m pytest tests -m gpu -x -q --durations=6 --deselect tests/test_full_size.py
+    tail -12 $O/gpu_tests.log
     ;;
   cmd)        # an ad-hoc command line (quoted by the caller) under a timeout
     step cmd ${CMD_TIMEOUT:-600} bash -c "$CMD"
