@@ -59,7 +59,7 @@ class _HostBatch(C.Structure):
                 ("diag", C.c_void_p),
                 ("base_to_event_map", C.c_void_p), ("scalings_out", C.c_void_p), ("events_per_base", C.c_void_p),
                 ("read_stat_flag", C.c_void_p), ("n_event_alignment", C.c_void_p),
-                ("min_num_events_to_rescale", C.c_int32), ("reserved", C.c_int32)]
+                ("min_num_events_to_rescale", C.c_int32), ("flags", C.c_int32)]
 
 
 class _DevBatch(C.Structure):

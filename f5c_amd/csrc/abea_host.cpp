@@ -817,6 +817,7 @@ struct host_run_state {
     const abea_host_batch* H;
     hipEvent_t origin = nullptr;          /* GPU clock origin of the call (recorded on the idle context stream) */
     std::vector<std::pair<float, float>> spans;   /* kernel span of every retired chunk on that clock */
+    std::atomic<bool> oom{false};         /* ABEA_HB_MALLOC_MAPS: a map could not be allocated */
     host_opts opt;
     bool want_pairs, scaling, device_pairs;
     abea_stats st;
@@ -879,9 +880,15 @@ static int slot_retire(host_run_state& S, abea_host_slot& sl) {
             if (scaling) {
                 /* the map comes down as one byte per k-mer (0.5 B per event on the wire) and is rebuilt with two adds per entry;
                  * a read with a k-mer of 255+ events falls back to the walk (0.4 B per event, which comes down anyway) */
-                if (np > 0 && H->base_to_event_map[i] &&
-                    !expand_counts_to_map(kcnt + descs[j].kmer_off, descs[j].n_kmers, diag[j].best_event, H->base_to_event_map[i]))
-                    expand_codes_to_map(codes + descs[j].code_off, np, descs[j].n_kmers - 1, diag[j].best_event, H->base_to_event_map[i]);
+                abea_index_pair_t* map = H->base_to_event_map[i];
+                if (H->flags & ABEA_HB_MALLOC_MAPS) {      /* scaling_single mallocs the map of an aligned read (f5c.c:746), NULL otherwise (f5c.c:787) */
+                    map = np > 0 ? (abea_index_pair_t*)malloc(sizeof(abea_index_pair_t) * (size_t)descs[j].n_kmers) : nullptr;
+                    if (np > 0 && !map) S.oom.store(true);
+                    const_cast<abea_index_pair_t**>(H->base_to_event_map)[i] = map;
+                }
+                if (np > 0 && map &&
+                    !expand_counts_to_map(kcnt + descs[j].kmer_off, descs[j].n_kmers, diag[j].best_event, map))
+                    expand_codes_to_map(codes + descs[j].code_off, np, descs[j].n_kmers - 1, diag[j].best_event, map);
                 if (H->scalings_out) {
                     abea_scalings_t o = sc[j];
                     if (var64[j] >= 0.0) o.log_var = (float)log(var64[j]);      /* align.c:758-760 (CACHED_LOG): double log, glibc's */
@@ -894,6 +901,7 @@ static int slot_retire(host_run_state& S, abea_host_slot& sl) {
         }
     });
     S.st.unflatten_ms += abea_now_ms() - t0;
+    if (S.oom.load()) return abea_fail(ABEA_ENOMEM, "malloc of a base_to_event_map failed");
     S.log("retired", sl.chunk_no);
     float ms = 0;
     if (S.origin) {                       /* the chunk's kernels on the GPU's clock: start of align-pre, start and end of the alignment kernel */
@@ -1019,6 +1027,7 @@ static int host_run(abea_ctx* c, const abea_host_batch* H, const int32_t* mine, 
                 H->diag[i] = dg;
             }
             if (scaling) {                                        /* f5c.c:786-794: could not align */
+                if (H->flags & ABEA_HB_MALLOC_MAPS) const_cast<abea_index_pair_t**>(H->base_to_event_map)[i] = nullptr;
                 if (H->scalings_out) H->scalings_out[i] = H->scalings[i];
                 if (H->events_per_base) H->events_per_base[i] = 0.0;
                 if (H->read_stat_flag) H->read_stat_flag[i] |= ABEA_FAILED_ALIGNMENT;
@@ -1282,7 +1291,18 @@ struct affinity_scope {
 
 /* One host batch on lane `lane_no` (-1 = the full lane) of every device of the context: single device, or LPT split over
  * the children with one driver thread per device. */
+static int run_host_batch_inner(abea_ctx* c, const abea_host_batch* H, int lane_no, int n_lanes, abea_stats* st_out);
+
 static int run_host_batch(abea_ctx* c, const abea_host_batch* H, int lane_no, int n_lanes, abea_stats* st_out) {
+    const bool own_maps = H->base_to_event_map && (H->flags & ABEA_HB_MALLOC_MAPS);
+    abea_index_pair_t** maps = own_maps ? const_cast<abea_index_pair_t**>(H->base_to_event_map) : nullptr;
+    if (own_maps) for (int32_t i = 0; i < H->n_reads; ++i) maps[i] = nullptr;
+    const int rc = run_host_batch_inner(c, H, lane_no, n_lanes, st_out);
+    if (rc && own_maps) for (int32_t i = 0; i < H->n_reads; ++i) { free(maps[i]); maps[i] = nullptr; }   /* nothing half-built is handed back */
+    return rc;
+}
+
+static int run_host_batch_inner(abea_ctx* c, const abea_host_batch* H, int lane_no, int n_lanes, abea_stats* st_out) {
     const int32_t n = H->n_reads;
     const double t_start = abea_now_ms();
     const host_opts opt = read_opts();

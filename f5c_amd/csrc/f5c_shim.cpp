@@ -73,14 +73,10 @@ static void shim_fill(abea_f5c_core* core, abea_f5c_db* db, bool scale, const ch
     hb.n_pairs = db->n_event_align_pairs;
     hb.diag = nullptr;
     if (scale) {
-        /* scaling_single malloc()s base_to_event_map[i] for aligned reads (f5c.c:746); which reads align is known only
-         * afterwards, so every read that passes the guards gets one and the failed ones are released below */
-        for (int32_t i = 0; i < n; ++i) {
-            const int32_t nk = db->read_len[i] - (int32_t)core->kmer_size + 1;
-            const bool good = (!db->nsample || db->nsample[i] > 0) && nk > 0 && db->et[i].n > 0;
-            db->base_to_event_map[i] = good ? (abea_index_pair_t*)malloc(sizeof(abea_index_pair_t) * (size_t)nk) : nullptr;
-            if (good && !db->base_to_event_map[i]) { fprintf(stderr, "[%s::ERROR] malloc failed\n", who); exit(EXIT_FAILURE); }
-        }
+        /* scaling_single malloc()s base_to_event_map[i] for aligned reads (f5c.c:746) and leaves NULL otherwise (f5c.c:787): the
+         * library does the same from its un-flatten workers (ABEA_HB_MALLOC_MAPS; rounds 2-4 malloc()ed one per read here, on the
+         * caller's thread, and released the failed ones afterwards) */
+        hb.flags |= ABEA_HB_MALLOC_MAPS;
         hb.base_to_event_map = db->base_to_event_map;
         hb.scalings_out = db->scalings;              /* recalibrated in place, like recalibrate_model(&db->scalings[i]) */
         hb.events_per_base = db->events_per_base;
@@ -91,10 +87,7 @@ static void shim_fill(abea_f5c_core* core, abea_f5c_db* db, bool scale, const ch
 }
 
 static void shim_finish(abea_f5c_core* core, abea_f5c_db* db, bool scale, const char* who) {
-    const int32_t n = db->n_bam_rec;
-    if (scale)
-        for (int32_t i = 0; i < n; ++i)
-            if (db->n_event_align_pairs[i] <= 0 && db->base_to_event_map[i]) { free(db->base_to_event_map[i]); db->base_to_event_map[i] = nullptr; }
+    (void)db; (void)scale;
     abea_stats st;
     abea_get_stats((abea_ctx*)core->cuda, &st);
     /* the copies overlap the kernels and the host loops (h2d_ms / d2h_ms stay 0); flatten = the reference's

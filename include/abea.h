@@ -115,8 +115,12 @@ typedef struct {
     int32_t* read_stat_flag;               /* [n_reads] in/out: ABEA_FAILED_* bits OR-ed in (src/f5c.h:66-68) */
     int32_t* n_event_alignment;            /* [n_reads] db->n_event_alignment[i] */
     int32_t  min_num_events_to_rescale;    /* opt.min_num_events_to_rescale; 0 -> 200 */
-    int32_t  reserved;
+    int32_t  flags;                        /* ABEA_HB_* */
 } abea_host_batch;
+/* base_to_event_map[i] is an OUTPUT pointer: the library malloc()s the map of every read that aligned (read_len - k + 1 entries,
+ * where scaling_single -> postalign mallocs it, f5c.c:746) and stores NULL for the others (f5c.c:787); the caller free()s.  On
+ * failure everything allocated by the call is released and the entries are NULL. */
+#define ABEA_HB_MALLOC_MAPS 0x1
 
 /* Replaces align_cuda(core_t*, db_t*)  src/f5c.cu:647-1061 : flatten + H2D + kernels + D2H.
  * The batch is cut into chunks of reads, longest reads first; chunks rotate through a few stream slots so that the host
