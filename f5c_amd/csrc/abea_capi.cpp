@@ -209,17 +209,14 @@ extern "C" int abea_selftest(abea_ctx* c) {
 }
 
 /* ------------------------------------------------------------------ batch planning */
-void plan_desc_layout(abea_read_desc& d, const plan_read& r, const abea_scalings_t& sc, sub_layout& lay, abea_stats& st) {
-    memset(&d, 0, sizeof d);
-    d.out_idx = r.idx;
-    d.read_len = r.L; d.n_events = r.E; d.n_kmers = r.K;
-    if (!r.run) { d.n_groups = 0; return; }
-    d.n_groups = (int32_t)((r.n_bands + ABEA_GROUP - 1) / ABEA_GROUP);
-    d.scale = sc.scale; d.shift = sc.shift;
-    d.kpar_off = (int64_t)lay.n_kpar;   lay.n_kpar += (size_t)r.K;
-    d.evm_off = (int64_t)lay.n_evm;     lay.n_evm += align_up((size_t)r.E + 64, 4);
-    d.code_off = (int64_t)lay.n_code;   lay.n_code += align_up((size_t)(r.E + r.K) / 16 + 2, 4);
-    d.trace_off = (int64_t)lay.n_trace; lay.n_trace += (size_t)d.n_groups * 64;
+plan_offsets plan_advance(const plan_read& r, sub_layout& lay, abea_stats& st) {
+    plan_offsets o = {0, 0, 0, 0};
+    if (!r.run) return o;
+    const int64_t n_groups = (r.n_bands + ABEA_GROUP - 1) / ABEA_GROUP;
+    o.kpar_off = (int64_t)lay.n_kpar;   lay.n_kpar += (size_t)r.K;
+    o.evm_off = (int64_t)lay.n_evm;     lay.n_evm += align_up((size_t)r.E + 64, 4);
+    o.code_off = (int64_t)lay.n_code;   lay.n_code += align_up((size_t)(r.E + r.K) / 16 + 2, 4);
+    o.trace_off = (int64_t)lay.n_trace; lay.n_trace += (size_t)n_groups * 64;
     st.sum_events += r.E; st.sum_bands += r.n_bands;
     /* SURVEY §8d algorithmic bytes; P is added after the run from n_pairs */
     const uint64_t Bn = (uint64_t)r.n_bands;
@@ -229,6 +226,21 @@ void plan_desc_layout(abea_read_desc& d, const plan_read& r, const abea_scalings
      * post (trace blocks on the path ~ 32 B/band worst case, codes, 16K+4E again, 8P out) */
     st.bytes_moved += 24ull * r.E + r.L + 12ull * r.K + 2 * (16ull * r.K + 4ull * r.E) + 64ull * Bn +
                       16ull * r.K + 4ull * r.E;
+    return o;
+}
+
+void plan_desc_fill(abea_read_desc& d, const plan_read& r, const abea_scalings_t& sc, const plan_offsets& o) {
+    memset(&d, 0, sizeof d);
+    d.out_idx = r.idx;
+    d.read_len = r.L; d.n_events = r.E; d.n_kmers = r.K;
+    if (!r.run) { d.n_groups = 0; return; }
+    d.n_groups = (int32_t)((r.n_bands + ABEA_GROUP - 1) / ABEA_GROUP);
+    d.scale = sc.scale; d.shift = sc.shift;
+    d.kpar_off = o.kpar_off; d.evm_off = o.evm_off; d.code_off = o.code_off; d.trace_off = o.trace_off;
+}
+
+void plan_desc_layout(abea_read_desc& d, const plan_read& r, const abea_scalings_t& sc, sub_layout& lay, abea_stats& st) {
+    plan_desc_fill(d, r, sc, plan_advance(r, lay, st));
 }
 
 void plan_desc_consts(abea_read_desc& d) {

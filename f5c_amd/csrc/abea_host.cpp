@@ -262,6 +262,8 @@ struct abea_host_slot {
     /* ---- the chunk in flight ---- */
     int32_t m = 0, chunk_no = 0;
     std::vector<int32_t> rd;                            /* caller index of descriptor j */
+    struct read_offs { plan_offsets o; int64_t read_off, pair_off, kmer_off; int32_t src; };
+    std::vector<read_offs> offs;                        /* the serial part of a chunk's plan: where descriptor j's arrays start */
     bool scaling = false, device_pairs = false, staged = false;
     size_t o_np = 0, o_diag = 0, o_codes = 0, o_poff = 0, o_cursor = 0, o_pairs = 0;      /* offsets in `dn` */
     size_t o_sc = 0, o_epb = 0, o_flag = 0, o_nal = 0, o_cnt = 0, o_var = 0;
@@ -1083,18 +1085,21 @@ static int host_run(abea_ctx* c, const abea_host_batch* H, const int32_t* mine, 
         if ((rc = ensure_pinned((void**)&sl.up, &sl.up_cap, u_end))) return rc;
         abea_read_desc* descs = (abea_read_desc*)(sl.up + u_desc);
         sub_layout lay;
+        /* the serial part of the plan: every read's offsets into the chunk's arrays, into a small cache-resident table; the
+         * descriptors themselves (112 B each into the pinned staging block: two write misses per read) are written by the
+         * parallel flatten loop below */
+        sl.offs.resize((size_t)m);
         {
             size_t ro = 0, po = 0, ko = 0;
             for (int32_t j = 0; j < m; ++j) {
-                plan_read r = S.reads[(size_t)order[pos + (size_t)j]];
+                const plan_read& r = S.reads[(size_t)order[pos + (size_t)j]];
                 sl.rd[(size_t)j] = r.idx;
-                const int32_t caller = r.idx;
-                r.idx = j;                                 /* out_idx = position in the chunk */
-                plan_desc_layout(descs[j], r, H->scalings[caller], lay, S.st);   /* the log-probabilities: in the flatten loop */
-                descs[j].read_off = (int64_t)ro; ro += align_up((size_t)r.L + 1, 16);
-                descs[j].pair_off = (int64_t)po; po += (size_t)r.E + (size_t)r.L;
-                descs[j].kmer_off = (int64_t)ko;
-                ko += (size_t)r.K;
+                abea_host_slot::read_offs& f = sl.offs[(size_t)j];
+                f.o = plan_advance(r, lay, S.st);
+                f.src = order[pos + (size_t)j];
+                f.read_off = (int64_t)ro; ro += align_up((size_t)r.L + 1, 16);
+                f.pair_off = (int64_t)po; po += (size_t)r.E + (size_t)r.L;
+                f.kmer_off = (int64_t)ko; ko += (size_t)r.K;
             }
         }
         /* `dn` = [npairs][diag][codes | poff, cursor][scaling outputs] mirrors the arena block behind the scratch */
@@ -1150,9 +1155,18 @@ static int host_run(abea_ctx* c, const abea_host_batch* H, const int32_t* mine, 
         t0 = abea_now_ms();
         lane.pool->run(m, 1, [&](int64_t lo, int64_t hi) {
             for (int64_t j = lo; j < hi; ++j) {
-                plan_desc_consts(descs[j]);                 /* align.c:207-216: four libm calls per read, off the caller's serial path */
-                const abea_read_desc& d = descs[j];
                 const int32_t i = sl.rd[(size_t)j];
+                {
+                    const abea_host_slot::read_offs& f = sl.offs[(size_t)j];
+                    plan_read r = S.reads[(size_t)f.src];
+                    r.idx = (int32_t)j;                     /* out_idx = position in the chunk */
+                    abea_read_desc nd;
+                    plan_desc_fill(nd, r, H->scalings[i], f.o);
+                    nd.read_off = f.read_off; nd.pair_off = f.pair_off; nd.kmer_off = f.kmer_off;
+                    plan_desc_consts(nd);                   /* align.c:207-216: four libm calls per read, off the caller's serial path */
+                    descs[j] = nd;
+                }
+                const abea_read_desc& d = descs[j];
                 const size_t L = (size_t)d.read_len;
                 memcpy(h_reads + d.read_off, H->read[i], L);
                 h_reads[d.read_off + (int64_t)L] = '\0';

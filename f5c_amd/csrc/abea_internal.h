@@ -152,6 +152,12 @@ struct sub_layout { size_t n_kpar = 0, n_evm = 0, n_code = 0, n_trace = 0; };
  * plan_desc = plan_desc_layout (offsets and accounting: integer work, serial because every read's offsets follow the
  * previous read's) + plan_desc_consts (the per-read log-probabilities of align.c:207-216: four glibc log/exp calls, the
  * expensive part, independent per read — the host entry computes them inside its parallel flatten loop). */
+struct plan_offsets { int64_t kpar_off, evm_off, code_off, trace_off; };
+/* plan_desc_layout = plan_advance (the read's place in the scratch arrays + the accounting: the only part that must run in
+ * read order) + plan_desc_fill (the descriptor itself: the host entry writes it from its parallel flatten loop, so that the
+ * write misses into the pinned staging block are not taken on the caller's serial path) */
+plan_offsets plan_advance(const plan_read& r, sub_layout& lay, abea_stats& st);
+void plan_desc_fill(abea_read_desc& d, const plan_read& r, const abea_scalings_t& sc, const plan_offsets& o);
 void plan_desc_layout(abea_read_desc& d, const plan_read& r, const abea_scalings_t& sc, sub_layout& lay, abea_stats& st);
 void plan_desc_consts(abea_read_desc& d);
 static inline void plan_desc(abea_read_desc& d, const plan_read& r, const abea_scalings_t& sc, sub_layout& lay, abea_stats& st) {

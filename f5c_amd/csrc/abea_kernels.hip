@@ -189,42 +189,17 @@ static __device__ void abea_scaling_single_wave(const abea_read_desc* d, const a
     int n_M = 0, n_align = 0;
     double acc = 0.0;                                    /* lanes 0..4: A00, A01, A11, b0, b1 (pass 0); lane 0: var (pass 1) */
     double shift = 0, scale = 0;
-    /* A block of 64 k-mers needs two dependent trips to memory — its map entries and bases, then the model entry of each rank and
-     * the event mean at each map start — and a wavefront walks the blocks one after the other: rounds 4's loop paid both latencies
-     * per block and per pass (+6-9 % on the launch).  Round 5: the loads run ahead of the arithmetic: stage 1 (map entry, rank) of
-     * block b + 2 and stage 2 (model entry, event mean, for every lane with a map entry) of block b + 1 are issued before block b's
-     * ballots and chains, so a block costs its own work only.  Same values, same order of every addition. */
-    struct stage1 { abea_index_pair_t m; int rank; };
-    struct stage2 { abea_index_pair_t m; int rank; float level_mean, level_stdv, raw_event; };
-    auto load1 = [&](int k0) {
-        stage1 r; r.m.start = -1; r.m.stop = -1; r.rank = 0;
-        const int k = k0 + lane;
-        if (k < K) {
-            r.m = load_map_l2(map + k);
-            for (int j = 0; j < kmer_size; ++j) r.rank = (r.rank << 2) | (int)base_code(seq[k + j]);
-        }
-        return r;
-    };
-    auto load2 = [&](const stage1& a) {
-        stage2 r; r.m = a.m; r.rank = a.rank; r.level_mean = 0.f; r.level_stdv = 1.f; r.raw_event = 0.f;
-        if (a.m.start != -1) {
-            const abea_model_t mo = model[a.rank];
-            r.level_mean = mo.level_mean; r.level_stdv = mo.level_stdv; r.raw_event = evm[a.m.start];
-        }
-        return r;
-    };
     for (int pass = 0; pass < 2; ++pass) {
         int carry_rank = -1;
         if (pass == 1) acc = 0.0;
-        stage1 s1 = load1(0);
-        stage2 cur = load2(s1);
-        s1 = load1(64);
         for (int k0 = 0; k0 < K; k0 += 64) {
-            const stage2 nxt = load2(s1);                 /* block k0 + 64: in flight while block k0 is worked on */
-            s1 = load1(k0 + 128);                        /* block k0 + 128 */
             const int k = k0 + lane;
-            const abea_index_pair_t m = cur.m;
-            const int rank = cur.rank;
+            abea_index_pair_t m; m.start = -1; m.stop = -1;
+            int rank = 0;
+            if (k < K) {
+                m = load_map_l2(map + k);
+                for (int j = 0; j < kmer_size; ++j) rank = (rank << 2) | (int)base_code(seq[k + j]);
+            }
             const bool valid = m.start != -1;
             /* the map's entries tile the events of the path in k order (every event is new for exactly one k-mer), so the number
              * of events per k-mer IS the map: one byte per k-mer for the host entry instead of eight (255 = "255 or more": the
@@ -241,7 +216,8 @@ static __device__ void abea_scaling_single_wave(const abea_read_desc* d, const a
             const int cnt = __popcll(mm);
             const int pos = __popcll(mm & ((1ull << lane) - 1ull));   /* this 'M' state's place among the block's */
             if (isM) {
-                const double level_stdv = cur.level_stdv, level_mean = cur.level_mean, raw_event = cur.raw_event;
+                const abea_model_t mo = model[rank];
+                const double level_stdv = mo.level_stdv, level_mean = mo.level_mean, raw_event = evm[m.start];
                 if (pass == 0) {                          /* align.c:697-706 */
                     const double inv_var = 1. / (level_stdv * level_stdv);
                     const double mu = level_mean, e = raw_event;
@@ -272,7 +248,6 @@ static __device__ void abea_scaling_single_wave(const abea_read_desc* d, const a
                 for (; i < cnt; ++i) acc += lds[i * stride + col];
             }
             __syncthreads();
-            cur = nxt;
         }
         if (pass == 0) {
             if (n_M < fs.min_rescale) break;             /* align.c:688: not enough 'M' states, no recalibration */
