@@ -133,8 +133,10 @@ def main():
     if world > 1:
         # one process per GPU on ONE host: the ranks share the host's CPUs (and its cgroup quota), so each rank's
         # flatten / un-flatten pool gets its share instead of the library default (usable CPUs - 2 per process)
-        # (each rank's HIP runtime adds ~2 busy threads of its own: a pool as wide as quota / world gets the whole cgroup throttled)
-        os.environ.setdefault("ABEA_HOST_THREADS", str(max(1, effective_cpus() // world - 2)))
+        # (each rank's HIP runtime adds helper threads of its own, mostly blocked: the pools together stay at or under the quota —
+        # 20 busy threads on a 16-CPU quota cost 1.6 s of CFS throttling per 6 steps at N = 1, 16 cost 8 ms, tools/host_sweep.py —
+        # and the line carries the cgroup's throttling counters so that a flat curve can be read off it)
+        os.environ.setdefault("ABEA_HOST_THREADS", str(max(2, effective_cpus() // world - 1)))
     n_dev = args.gpus if args.single_process else 1
     dev_ids = ([0] * n_dev if args.one_device else list(range(n_dev))) if args.single_process else None
     ctx = abea.AbeaContext(model, k, device_id=local_rank, verbosity=0, device_ids=dev_ids,
@@ -336,7 +338,7 @@ def small_batch(ctx, batch):
     """What a drop-in does WITHOUT re-tuned flags: f5c's default batch is -K 512 reads / -B 2 Mbases (src/f5c.c:1178-1179).
     One such batch fills 512 of the GPU's 4096 wave slots and lasts as long as its longest read.  Measured one batch at a
     time (as process_db issues them) and with 2 / 4 consecutive default batches in flight through
-    abea_align_batch_host_submit/_wait (what a caller overlapping process_db calls gets)."""
+    abea_align_batch_host_submit/_wait (what a caller overlapping process_db calls gets); 8 = a lane per stream slot."""
     import numpy as np
     from f5c_amd import synth
     L = batch["read_len"].astype(np.int64)
@@ -365,7 +367,7 @@ def small_batch(ctx, batch):
         ref.append((v["n_pairs"].copy(), v["pairs"].copy()))
         v["pairs"].fill(0); v["n_pairs"].fill(-1)
     over = {}
-    for lanes in (2, 4):
+    for lanes in (2, 4, 8):
         ctx.set_inflight(lanes)
         for rep in range(2):                                       # first pass warms the lanes' slots and staging
             t0 = time.perf_counter()

@@ -144,7 +144,7 @@ int abea_align_batch_host(abea_ctx* ctx, const abea_host_batch* batch);
  * of the same context return ABEA_EBUSY.  Works on multi-device contexts (every device runs lane l of each batch).
  * abea_get_stats() reports the batch of the last successful wait.  A ticket is redeemed once: a second wait on it returns
  * ABEA_EBUSY while the first is still blocked and ABEA_EINVAL afterwards. */
-#define ABEA_MAX_INFLIGHT 4
+#define ABEA_MAX_INFLIGHT 8
 int abea_set_inflight(abea_ctx* ctx, int32_t n_lanes);      /* only while nothing is in flight; a lane gets 1/n of slots, arena, threads */
 int abea_align_batch_host_submit(abea_ctx* ctx, const abea_host_batch* batch, int32_t* ticket);
 int abea_align_batch_host_wait(abea_ctx* ctx, int32_t ticket);

@@ -1,0 +1,124 @@
+"""The raw-signal chunk pipeline (f5c_amd/csrc/abea_chain.cpp, round 5) behind abea_events_batch_host (event_db,
+src/f5c.c:682-734) and abea_process_batch_host (process_db_rsq: event_db -> align_db -> scaling_db, src/resquiggle.c:283-315),
+driven through the C ABI on synthetic raw signals and compared, read by read and bit for bit, with the oracle chain
+getevents -> estimate_scalings -> align -> scaling_single:
+  * many small chunks rotating through few slots (stage D of chunk c + 1 is issued before stage A of chunk c),
+  * tables that overflow their first-guess capacity (ABEA_CHAIN_CAP_DIV) and are redone after the pipeline has drained from the
+    int16 staging — with the float signal already rewritten to pA,
+  * a read without signal in the middle of the batch, event_db alone, the pA conversion in place.
+The real-read version of the same comparison (10 reads from a plain g++ caller) is tests/test_process_chain.py."""
+import numpy as np
+import pytest
+
+
+def _oracle_chain(orc, model, k, seq, s16, sc3):
+    o_ev, o_pa = orc.getevents(s16, *[float(x) for x in sc3])
+    scale, shift = orc.estimate_scalings(seq, model, k, o_ev)
+    o_pairs, _ = orc.align(seq, o_ev, model, k, scale, shift)
+    rec = orc.scaling_single(o_pairs, seq, o_ev, model, k, scale, shift)
+    return o_ev, o_pa, (scale, shift), o_pairs, rec
+
+
+def _batch_and_signals(r9, n, seed, law):
+    from f5c_amd import synth
+    k, model = r9
+    b = synth.make_batch(n, model, k, seed=seed, law=law, bad_frac=0.05, workers=4)
+    sig, sp, ns, sc = synth.make_signals_flat(b, seed=seed + 1, threads=4)
+    return b, sig, sp, ns, sc
+
+
+def _compare(ctx, orc, model, k, b, v, sig0, sp, ns, sc, reads, want_pairs):
+    n_aligned = 0
+    for j in reads:
+        rs, L = int(b["read_ptr"][j]), int(b["read_len"][j])
+        seq = b["reads"][rs:rs + L].tobytes()
+        if ns[j] == 0:                                                      # f5c.c:727-731, 826-828, 786-794
+            assert v["ev_pp"][j] == 0 and v["n_events"][j] == 0 and v["n_pairs"][j] == 0 and v["map_pp"][j] == 0
+            assert v["read_stat_flag"][j] & 2 and v["events_per_base"][j] == 0.0
+            continue
+        s16 = sig0[sp[j]:sp[j] + ns[j]].astype(np.int16)
+        o_ev, _, (scale, shift), o_pairs, rec = _oracle_chain(orc, model, k, seq, s16, sc[j])
+        g_ev = ctx.view_events(v, j)
+        assert len(g_ev) == len(o_ev), j
+        for f in ("start", "length", "mean", "stdv"):
+            assert (g_ev[f] == o_ev[f]).all(), (j, f)
+        est = v["scalings_estimated"][j]
+        assert est["scale"] == np.float32(scale) and est["shift"] == np.float32(shift), j
+        assert int(v["n_pairs"][j]) == len(o_pairs), j
+        assert int(v["read_stat_flag"][j]) == rec["flag"] and int(v["n_event_alignment"][j]) == rec["n_alignment"], j
+        assert float(v["events_per_base"][j]) == rec["events_per_base"], j
+        if want_pairs:
+            assert (ctx.view_pairs(v, j).view(np.int32).reshape(-1, 2) == o_pairs.view(np.int32).reshape(-1, 2)).all(), j
+        m = ctx.view_map(v, j, L - k + 1)
+        if len(o_pairs) > 0:
+            n_aligned += 1
+            assert m is not None and (m[:, 0] == rec["base_to_event_map"]["start"]).all() and (m[:, 1] == rec["base_to_event_map"]["stop"]).all(), j
+            if not (rec["flag"] & 1):                                        # recalibrated: shift, scale, var, log_var (align.c:755-760)
+                for f in ("shift", "scale", "var", "log_var"):
+                    assert v["scalings"][f][j] == rec["scalings"][f], (j, f)
+        else:
+            assert m is None                                                 # f5c.c:787
+    return n_aligned
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cap_div", [4, 48])
+def test_process_chain_many_chunks_and_overflowed_tables(ctx, orc, r9, monkeypatch, cap_div):
+    """120 synthetic reads + one without signal through abea_process_batch_host in ~10 chunks on 3 slots.  cap_div = 48 gives every
+    table a first-guess capacity of n/48 + 16 events: most overflow and take the redo path (int16 staging -> exact capacity ->
+    host entry) AFTER their float signal has been rewritten to pA; the outputs must not depend on it."""
+    k, model = r9
+    b, sig, sp, ns, sc = _batch_and_signals(r9, 120, 4242, 2500)
+    ns = ns.copy(); ns[57] = 0                                              # a read without signal (nsample == 0)
+    sig0 = sig.copy()
+    monkeypatch.setenv("ABEA_CHAIN_SLOTS", "3")
+    monkeypatch.setenv("ABEA_CHAIN_CHUNK_SAMPLES", str(600_000))
+    monkeypatch.setenv("ABEA_CHAIN_CHUNK_READS", "8")
+    monkeypatch.setenv("ABEA_CHAIN_CAP_DIV", str(cap_div))
+    v = ctx.signal_view(sig, sp, ns, sc, batch=b, want_pairs=True, to_pa=True)
+    ctx.process_view(v)
+    st = ctx.stats()
+    assert st["n_sub_batches"] >= 6 and st["gpu_busy_ms"] > 0
+    n_aligned = _compare(ctx, orc, model, k, b, v, sig0, sp, ns, sc, range(120), True)
+    assert n_aligned >= 100
+    # the signal is left in pA (f5c.c:693-696: the same two float operations), untouched for the read without signal
+    for j in (0, 31, 119):
+        _, o_pa = orc.getevents(sig0[sp[j]:sp[j] + ns[j]].astype(np.int16), *[float(x) for x in sc[j]])
+        assert (sig[sp[j]:sp[j] + ns[j]] == o_pa).all(), j
+    if cap_div == 48:                                                        # the synthetic signals give one event per ~5 samples: all overflow n/48
+        assert int((v["n_events"] > ns // 48 + 16).sum()) >= 100
+    ctx.free_view(v)
+
+
+@pytest.mark.gpu
+def test_event_db_alone_and_repeatability(ctx, orc, r9, monkeypatch):
+    """abea_events_batch_host through the same pipeline (no alignment stage): tables + method-of-moments scalings equal the
+    oracle's, with and without the sequences; a second call gives the same bytes; a fractional sample is refused."""
+    from f5c_amd import abea
+    k, model = r9
+    b, sig, sp, ns, sc = _batch_and_signals(r9, 60, 99, 1800)
+    monkeypatch.setenv("ABEA_CHAIN_SLOTS", "2")
+    monkeypatch.setenv("ABEA_CHAIN_CHUNK_SAMPLES", str(400_000))
+    monkeypatch.setenv("ABEA_CHAIN_CHUNK_READS", "4")
+    v = ctx.signal_view(sig, sp, ns, sc, batch=b)
+    ctx.events_view(v)
+    first = [ctx.view_events(v, j) for j in range(60)]
+    for j in range(0, 60, 7):
+        rs, L = int(b["read_ptr"][j]), int(b["read_len"][j])
+        o_ev, _ = orc.getevents(sig[sp[j]:sp[j] + ns[j]].astype(np.int16), *[float(x) for x in sc[j]])
+        assert len(first[j]) == len(o_ev) and all((first[j][f] == o_ev[f]).all() for f in ("start", "length", "mean", "stdv")), j
+        scale, shift = orc.estimate_scalings(b["reads"][rs:rs + L].tobytes(), model, k, o_ev)
+        assert v["scalings"]["scale"][j] == np.float32(scale) and v["scalings"]["shift"][j] == np.float32(shift), j
+    ctx.free_view(v)
+    ctx.events_view(v)
+    assert all((ctx.view_events(v, j).tobytes() == first[j].tobytes()) for j in range(60))
+    ctx.free_view(v)
+    v2 = ctx.signal_view(sig, sp, ns, sc)                                    # no sequences: tables only
+    ctx.events_view(v2)
+    assert all((ctx.view_events(v2, j).tobytes() == first[j].tobytes()) for j in range(0, 60, 5))
+    ctx.free_view(v2)
+    bad = sig.copy(); bad[sp[3] + 10] += 0.5                                 # not an ADC count
+    v3 = ctx.signal_view(bad, sp, ns, sc)
+    with pytest.raises(abea.AbeaError, match="int16 ADC count"):
+        ctx.events_view(v3)
+    assert (v3["ev_pp"] == 0).all()                                          # nothing half-built is handed back

@@ -71,7 +71,7 @@ def _check(view, batch, ora):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("lanes", [2, 4])
+@pytest.mark.parametrize("lanes", [2, 4, 8])
 def test_submitted_batches_overlap_and_match_the_oracle(orc, r9, lanes, monkeypatch):
     """`lanes` host batches in flight at once on one context: every output bit-equal to the oracle; tickets can be waited
     for in any order; a full house returns ABEA_EBUSY; the synchronous entries refuse to run meanwhile."""

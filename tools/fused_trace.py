@@ -28,6 +28,6 @@ for mode in ("pairs", "fused"):
         t0 = time.perf_counter(); ctx.align_view(v); t = time.perf_counter() - t0
         st = ctx.stats()
         print(f"{mode:6s} rep {rep}: {ev/t/1e6:8.1f} Mevents/s wall {t*1e3:7.1f} ms | flatten {st['flatten_ms']:6.1f} unflatten {st['unflatten_ms']:6.1f} wait {st['wait_ms']:6.1f} "
-              f"| kernels (sum over chunks) pre {st['pre_ms']:.1f} align {st['fill_ms']:.1f} scaling+recalib {st['trace_ms']:.1f} | {st['n_sub_batches']} chunks", flush=True)
+              f"| kernels (sum over chunks) pre {st['pre_ms']:.1f} align {st['fill_ms']:.1f} gpu busy {st['gpu_busy_ms']:.1f} | {st['n_sub_batches']} chunks", flush=True)
     del v
 ctx.close()

@@ -119,6 +119,13 @@ for ln in sys.stdin:
     step gpu_tests 600 python -m pytest tests -m gpu -x -q --durations=6 --deselect tests/test_full_size.py
     tail -12 $O/gpu_tests.log
     ;;
+  fusedtrace) # the fused align + scaling_single HOST call under rocprofv3: kernel timeline (8 chunks in flight) and one SQ pass
+    step ft_gen 200 python tools/fused_trace.py 20000 /tmp/ft
+    step fused_kt 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/fused_kt -o fused -- python tools/fused_trace.py 20000 /tmp/ft
+    grep "rep" $O/fused_kt.log
+    step fused_sq 200 rocprofv3 --kernel-trace --output-format csv -d $O/fused_sq -o fused --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE -- python tools/fused_trace.py 20000 /tmp/ft
+    find $O -name "*.csv" | head
+    ;;
   cmd)        # an ad-hoc command line (quoted by the caller) under a timeout
     step cmd ${CMD_TIMEOUT:-600} bash -c "$CMD"
     tail -40 $O/cmd.log
