@@ -19,7 +19,7 @@ consecutive ones with 2 / 4 in flight through abea_align_batch_host_submit/_wait
 call), `cpu_baseline` (the oracle port on the host cores, which also checks this run's GPU pairs bit for bit on its sample).
 `roofline.traffic`, `roofline.limiter` and the instruction counts of `roofline.valu_roofline` are STATIC: they come from the
 committed rocprofv3 PMC passes of the same workload on the build that ships (profiles/pmc_traffic.json, built by
-profiles/make_pmc_traffic.py from profiles/r04/e_*); the launch time they are set against is this run's.  `roofline.target_frac`
+profiles/make_pmc_traffic.py from profiles/r05/f_*, tied to the kernel sources by a sha256); the launch time they are set against is this run's.  `roofline.target_frac`
 / `target_met` say in the record that the north-star 40 % of the HBM roofline is not reached (the kernel is VALU-issue-bound).
 For N > 1 (and under torch.distributed.run at N = 1) `per_rank` lists every rank's host loops, threads and kernel time and
 `bound` says whether the slowest rank's caller thread worked or waited.

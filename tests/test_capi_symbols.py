@@ -61,3 +61,19 @@ def test_generated_asm_is_current():
     assert out.returncode == 0, out.stdout + out.stderr
     assert out.stdout.count("up to date") == 2
 
+
+
+def test_static_pmc_counters_belong_to_these_kernel_sources():
+    """bench.py quotes HBM traffic / VALU-busy from profiles/pmc_traffic.json only when its code_sha256 — sha256 over abea_fill.inc +
+    abea_walk.inc + abea_kernels.hip at the time of the rocprofv3 passes — equals the tree's (round-4 verdict: a 3 % time window is
+    not a guard).  The committed json must describe the committed kernel: re-take the passes (tools/gpu_call.sh prof100a / prof100b /
+    prof10, profiles/make_pmc_traffic.py) after any change to those three files."""
+    import json
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    t = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    sha = bench.kernel_code_sha()
+    for config in ("r9_10k_8kb", "r9_100k_mixed"):
+        assert t[config]["code_sha256"] == sha, config
+        assert bench.pmc_entry(config) is not None and bench.pmc_traffic(config, 1000, 1) == int(t[config]["hbm_bytes_per_event"] * 1000)
