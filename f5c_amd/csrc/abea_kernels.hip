@@ -1258,7 +1258,10 @@ void abea_ev_create_kernel(int n_reads, const int32_t* __restrict__ order, const
         #pragma unroll
         for (int i = 0; i < 9; ++i) {                                /* b[i] = start of event j0+i = end of event j0+i-1 */
             const int j = j0 + i - 1;
-            b[i] = (j < 0) ? 0ull : (j >= n_ev - 1) ? (unsigned long long)n : (unsigned long long)pk[(size_t)min(j, wcap - 1) * 64];
+            /* boundaries past the last event this thread may write (j >= ne: a table cut off at its capacity) are never used — and
+             * their peak slots were never written: reading them would index the prefix sums with stale memory (round 5: a table
+             * overflowing 9x faulted here) */
+            b[i] = (j < 0) ? 0ull : (j >= n_ev - 1 || j >= ne) ? (unsigned long long)n : (unsigned long long)pk[(size_t)min(j, wcap - 1) * 64];
         }
         #pragma unroll
         for (int i = 0; i < 9; ++i) {                                /* one 16-byte look-up per boundary: {S, Q} side by side */

@@ -65,7 +65,7 @@ def test_generated_asm_is_current():
 
 def test_static_pmc_counters_belong_to_these_kernel_sources():
     """bench.py quotes HBM traffic / VALU-busy from profiles/pmc_traffic.json only when its code_sha256 — sha256 over abea_fill.inc +
-    abea_walk.inc + abea_kernels.hip at the time of the rocprofv3 passes — equals the tree's (round-4 verdict: a 3 % time window is
+    abea_walk.inc + abea_kernels.hip (up to its event-detection section) at the time of the rocprofv3 passes — equals the tree's (round-4 verdict: a 3 % time window is
     not a guard).  The committed json must describe the committed kernel: re-take the passes (tools/gpu_call.sh prof100a / prof100b /
     prof10, profiles/make_pmc_traffic.py) after any change to those three files."""
     import json

@@ -79,6 +79,9 @@ def main():
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--no-flatten-probe", action="store_true")
     ap.add_argument("--only", default="", help="comma-separated setting names")
+    ap.add_argument("--hi-stream-ab", action="store_true", help="instead of the sweep: two contexts on the one batch, the second created "
+                    "with ABEA_HOST_HI_STREAM=1 (the copy-out of a chunk's result block on a high-priority stream; read at slot creation), "
+                    "alignment-only and fused calls alternating")
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
 
@@ -109,6 +112,32 @@ def main():
     ev_total = int(batch["n_events"].sum())
 
     torch.cuda.set_device(0)
+    if args.hi_stream_ab:
+        ctxs = {}
+        for name, val in (("own_stream", None), ("hi_stream", "1")):
+            os.environ.pop("ABEA_HOST_HI_STREAM", None)
+            if val:
+                os.environ["ABEA_HOST_HI_STREAM"] = val
+            c = abea.AbeaContext(model, k, device_id=0, max_arena_bytes=int(100 * (1 << 30)))
+            vs = {"pairs": c.host_view(batch), "fused": c.host_view(batch, scaling=True, want_pairs=False)}
+            for v in vs.values():
+                c.align_view(v); c.align_view(v)          # creates the slots under this setting, warms staging
+            ctxs[name] = (c, vs)
+        os.environ.pop("ABEA_HOST_HI_STREAM", None)
+        rows = []
+        for rep in range(3):
+            for name, (c, vs) in ctxs.items():
+                for vname, v in vs.items():
+                    t0 = time.perf_counter()
+                    for _ in range(args.steps):
+                        c.align_view(v)
+                    dt = (time.perf_counter() - t0) / args.steps
+                    st = c.stats()
+                    row = {"copy_out": name, "view": vname, "rep": rep, "ms_per_step": round(dt * 1e3, 2), "wait_ms": round(st["wait_ms"], 1),
+                           "gpu_busy_ms": round(st["gpu_busy_ms"], 1)}
+                    rows.append(row); print(json.dumps(row), flush=True)
+        json.dump({"info": info, "rows": rows}, open(os.path.join(args.out, "hi_stream_ab.json"), "w"), indent=1)
+        return
     ctx = abea.AbeaContext(model, k, device_id=0, max_arena_bytes=int(150 * (1 << 30)))
     views = {"pairs": ctx.host_view(batch), "fused": ctx.host_view(batch, scaling=True, want_pairs=False)}
 
