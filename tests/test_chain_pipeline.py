@@ -93,7 +93,7 @@ def test_process_chain_many_chunks_and_overflowed_tables(ctx, orc, r9, monkeypat
 @pytest.mark.gpu
 def test_event_db_alone_and_repeatability(ctx, orc, r9, monkeypatch):
     """abea_events_batch_host through the same pipeline (no alignment stage): tables + method-of-moments scalings equal the
-    oracle's, with and without the sequences; a second call gives the same bytes; a fractional sample is refused."""
+    oracle's, with and without the sequences; a second call gives the same tables; a fractional sample is refused."""
     from f5c_amd import abea
     k, model = r9
     b, sig, sp, ns, sc = _batch_and_signals(r9, 60, 99, 1800)
@@ -103,6 +103,9 @@ def test_event_db_alone_and_repeatability(ctx, orc, r9, monkeypatch):
     v = ctx.signal_view(sig, sp, ns, sc, batch=b)
     ctx.events_view(v)
     first = [ctx.view_events(v, j) for j in range(60)]
+
+    def same(a, b2):                                                         # field by field: event_t has 4 bytes of tail padding
+        return len(a) == len(b2) and all((a[f] == b2[f]).all() for f in ("start", "length", "mean", "stdv"))
     for j in range(0, 60, 7):
         rs, L = int(b["read_ptr"][j]), int(b["read_len"][j])
         o_ev, _ = orc.getevents(sig[sp[j]:sp[j] + ns[j]].astype(np.int16), *[float(x) for x in sc[j]])
@@ -111,11 +114,11 @@ def test_event_db_alone_and_repeatability(ctx, orc, r9, monkeypatch):
         assert v["scalings"]["scale"][j] == np.float32(scale) and v["scalings"]["shift"][j] == np.float32(shift), j
     ctx.free_view(v)
     ctx.events_view(v)
-    assert all((ctx.view_events(v, j).tobytes() == first[j].tobytes()) for j in range(60))
+    assert all(same(ctx.view_events(v, j), first[j]) for j in range(60))
     ctx.free_view(v)
     v2 = ctx.signal_view(sig, sp, ns, sc)                                    # no sequences: tables only
     ctx.events_view(v2)
-    assert all((ctx.view_events(v2, j).tobytes() == first[j].tobytes()) for j in range(0, 60, 5))
+    assert all(same(ctx.view_events(v2, j), first[j]) for j in range(0, 60, 5))
     ctx.free_view(v2)
     bad = sig.copy(); bad[sp[3] + 10] += 0.5                                 # not an ADC count
     v3 = ctx.signal_view(bad, sp, ns, sc)
