@@ -430,17 +430,18 @@ int slot_finish(chain_state& S, abea_chain_slot& sl) {
     S.log("scatter", sl.chunk_no, sl.m, sl.n_ev);
     const int32_t m = sl.m;
     const abea_event_t* h_ev = (const abea_event_t*)sl.tab.p;
-    static uint8_t none[8];
-    uint8_t* const dnb = J->align ? sl.dn.u8() : none;              /* events only: no result block, nothing below is read */
-    const int32_t* npairs = (const int32_t*)(dnb + sl.o_np);
-    const abea_read_diag* diag = (const abea_read_diag*)(dnb + sl.o_diag);
-    const uint32_t* codes = (const uint32_t*)(dnb + sl.o_codes);
-    const abea_scalings_t* sc = (const abea_scalings_t*)(dnb + sl.o_sc);
-    const double* epb = (const double*)(dnb + sl.o_epb);
-    const int32_t* flag = (const int32_t*)(dnb + sl.o_flag);
-    const int32_t* nal = (const int32_t*)(dnb + sl.o_nal);
-    const double* var64 = (const double*)(dnb + sl.o_var);
-    const uint8_t* kcnt = dnb + sl.o_kcnt;
+    /* the result block exists in process mode only (event_db alone reads none of it) */
+    const uint8_t* const dnb = J->align ? sl.dn.u8() : nullptr;
+    auto at = [&](size_t off) { return dnb ? dnb + off : nullptr; };
+    const int32_t* npairs = (const int32_t*)at(sl.o_np);
+    const abea_read_diag* diag = (const abea_read_diag*)at(sl.o_diag);
+    const uint32_t* codes = (const uint32_t*)at(sl.o_codes);
+    const abea_scalings_t* sc = (const abea_scalings_t*)at(sl.o_sc);
+    const double* epb = (const double*)at(sl.o_epb);
+    const int32_t* flag = (const int32_t*)at(sl.o_flag);
+    const int32_t* nal = (const int32_t*)at(sl.o_nal);
+    const double* var64 = (const double*)at(sl.o_var);
+    const uint8_t* kcnt = at(sl.o_kcnt);
     const bool want_sc = J->read != nullptr;
     abea_parallel_for(S.c, m, 1, [&](int64_t lo, int64_t hi) {
         for (int64_t j = lo; j < hi; ++j) {
@@ -660,7 +661,7 @@ int abea_chain_run(abea_ctx* c, const abea_chain_job* J, const int32_t* mine, in
     struct origin_event { hipEvent_t e = nullptr; ~origin_event() { if (e) hipEventDestroy(e); } } origin;
     if (hipEventCreate(&origin.e) == hipSuccess && hipEventRecord(origin.e, c->chain_slots[0]->stream) == hipSuccess) S.origin = origin.e;
     const size_t slot_arena = c->arena_bytes / (size_t)n_slots / 4096 * 4096;
-    S.st.host_threads = abea_default_host_threads();
+    S.st.host_threads = abea_pool_threads(c);
     S.st.setup_ms = abea_now_ms() - t_start;
     /* ---- chunks: closed at chunk_samples samples (the first two a quarter / half of that) once they hold reads_min reads, at
      *      reads_max reads, or when the next read's upper bound would not fit the slot's share of the arena ---- */

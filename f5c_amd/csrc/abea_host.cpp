@@ -1373,6 +1373,24 @@ static int run_host_batch_inner(abea_ctx* c, const abea_host_batch* H, int lane_
     return ABEA_OK;
 }
 
+/* the worker pools of a context's devices at the widths of its thread plan (a multi-device parent gives every child
+ * (usable CPUs - 2) / n threads): for entries that use abea_parallel_for on the children directly (abea_chain.cpp) */
+int abea_pool_threads(abea_ctx* c) { return c->async && c->async->full.pool ? c->async->full.pool->threads() : 0; }
+
+void abea_host_prepare_pools(abea_ctx* c) {
+    const std::vector<host_thread_plan> plan = context_thread_plan(c);
+    const host_opts opt = read_opts();
+    if (c->children.empty()) {
+        std::lock_guard<std::mutex> lk(c->slots_mu);
+        ensure_lanes(c, plan[0], async_of(c)->n_lanes, opt.n_slots, false);
+        return;
+    }
+    for (size_t d = 0; d < c->children.size(); ++d) {
+        std::lock_guard<std::mutex> lk(c->children[d]->slots_mu);
+        ensure_lanes(c->children[d], plan[d], async_of(c)->n_lanes, opt.n_slots, false);
+    }
+}
+
 extern "C" int abea_align_batch_host(abea_ctx* c, const abea_host_batch* H) {
     if (!c) return abea_fail(ABEA_EINVAL, "null argument");
     int rc = check_host_batch(H);

@@ -95,6 +95,8 @@ int abea_chain_run(abea_ctx* c, const abea_chain_job* J, const int32_t* mine, in
  * the caller's thread takes part) — abea_host.cpp */
 void abea_parallel_for(abea_ctx* c, int64_t n, int64_t grain, const std::function<void(int64_t, int64_t)>& f);
 int abea_default_host_threads();
+int abea_pool_threads(abea_ctx* c);          /* abea_host.cpp: width of the device context's worker pool (0 before it exists) */
+void abea_host_prepare_pools(abea_ctx* c);   /* abea_host.cpp: every device's worker pool at the width of the context's thread plan */
 int abea_host_batches_in_flight(abea_ctx* c);   /* abea_host.cpp: submitted and not yet waited for */
 /* the single-caller-per-context contract, enforced: a public entry that uses the arena / pool / staging holds api_mu for
  * its duration and refuses to run while submitted host batches are in flight */

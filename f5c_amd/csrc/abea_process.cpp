@@ -29,6 +29,7 @@ namespace {
 /* the pipeline over the devices of a context: one device, or an LPT split on the sample count with one host thread each */
 int chain_over_devices(abea_ctx* c, const abea_chain_job* J, abea_stats* st_out) {
     const double t0 = abea_now_ms();
+    abea_host_prepare_pools(c);
     if (c->children.empty()) return abea_chain_run(c, J, nullptr, J->n_reads, st_out);
     const int32_t n = J->n_reads, nd = (int32_t)c->children.size();
     std::vector<int64_t> weight((size_t)n);

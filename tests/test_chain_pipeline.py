@@ -125,3 +125,24 @@ def test_event_db_alone_and_repeatability(ctx, orc, r9, monkeypatch):
     with pytest.raises(abea.AbeaError, match="int16 ADC count"):
         ctx.events_view(v3)
     assert (v3["ev_pp"] == 0).all()                                          # nothing half-built is handed back
+
+
+@pytest.mark.gpu
+def test_process_chain_on_a_two_device_context(orc, r9, monkeypatch):
+    """abea_process_batch_host on a multi-device context (one GPU listed twice, as the alignment's multi-device test does): the reads
+    are LPT-split on the sample count, each device context runs the pipeline on its share from its own host thread; the outputs are
+    those of the single-device call."""
+    from f5c_amd import abea
+    k, model = r9
+    b, sig, sp, ns, sc = _batch_and_signals(r9, 50, 777, 2000)
+    monkeypatch.setenv("ABEA_CHAIN_SLOTS", "2")
+    monkeypatch.setenv("ABEA_CHAIN_CHUNK_SAMPLES", str(500_000))
+    monkeypatch.setenv("ABEA_CHAIN_CHUNK_READS", "4")
+    with abea.AbeaContext(model, k, device_ids=[0, 0], max_arena_bytes=3 << 30) as c2:
+        assert c2.device_count() == 2
+        v = c2.signal_view(sig, sp, ns, sc, batch=b, want_pairs=True)
+        c2.process_view(v)
+        st = c2.stats()
+        assert st["n_devices"] == 2 and st["n_sub_batches"] >= 4
+        assert _compare(c2, orc, model, k, b, v, sig, sp, ns, sc, range(0, 50, 3), True) >= 12
+        c2.free_view(v)
