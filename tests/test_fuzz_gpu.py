@@ -30,3 +30,13 @@ def test_fuzz_event_detection_slice():
     0 pA: device event detection + method-of-moments scalings bit-exact against the oracle."""
     nb, ns, ne, dt = _tool("fuzz_events").run(budget=40.0, seed=20250903, max_batches=400)
     assert nb >= 3 and ns > 30 and ne > 1000, (nb, ns, ne, dt)
+
+
+def test_fuzz_event_db_host_entry_slice(monkeypatch):
+    """The same adversarial signals as float ADC counts through abea_events_batch_host (the chunk pipeline of abea_chain.cpp) with
+    random chunk sizes, slot counts and first-guess table capacities — overflowing tables are redone from the int16 staging after
+    the pipeline has drained — DNA and RNA: tables and method-of-moments scalings bit-exact against the oracle."""
+    for var in ("ABEA_CHAIN_CAP_DIV", "ABEA_CHAIN_SLOTS", "ABEA_CHAIN_CHUNK_SAMPLES", "ABEA_CHAIN_CHUNK_READS"):
+        monkeypatch.setenv(var, "1")                        # restored by monkeypatch after the fuzzer has overwritten them
+    nb, ns, ne, dt = _tool("fuzz_events").run(budget=20.0, seed=20250905, max_batches=200, host_entry=True)
+    assert nb >= 3 and ns > 30 and ne > 1000, (nb, ns, ne, dt)

@@ -12,8 +12,10 @@ from oracle import orc
 
 
 
-def run(budget=60.0, seed=1, ctx=None, max_batches=None):
-    """Fuzz for `budget` seconds (or max_batches); returns (batches, signals, events, seconds).  Raises on any mismatch."""
+def run(budget=60.0, seed=1, ctx=None, max_batches=None, host_entry=False):
+    """Fuzz for `budget` seconds (or max_batches); returns (batches, signals, events, seconds).  Raises on any mismatch.
+    host_entry: the same signals as FLOAT ADC counts through abea_events_batch_host — the chunk pipeline of abea_chain.cpp — with
+    random chunk sizes, slot counts and first-guess table capacities (n/1 .. n/64 + 16 events: overflowing tables take the redo path)."""
     k, model = load_model_f32(os.path.join(ROOT, "tests/golden/r9.4_450bps.6mer.f32"))
     rng = np.random.default_rng(seed)
     own = ctx is None
@@ -51,7 +53,33 @@ def run(budget=60.0, seed=1, ctx=None, max_batches=None):
         if nb % 2 == 1:                                                  # every other batch also asks for the scalings
             seqs = [bytes(rng.choice(list(b"ACGT"), int(rng.integers(k, 4000))).astype(np.uint8)) for _ in range(m)]
         rna = bool(nb % 3 == 2)                                          # every third batch with the RNA detector (events.c:59-65) + reversal
-        evs, ne, dsc = ctx.detect_events_device(list(sigs), scal, seqs=seqs, cap_div=1, rna=rna)
+        if host_entry:
+            os.environ["ABEA_CHAIN_CAP_DIV"] = str(int(rng.choice([1, 4, 16, 64])))
+            os.environ["ABEA_CHAIN_SLOTS"] = str(int(rng.integers(1, 5)))
+            os.environ["ABEA_CHAIN_CHUNK_SAMPLES"] = str(int(rng.choice([2000, 60000, 1 << 20])))
+            os.environ["ABEA_CHAIN_CHUNK_READS"] = str(int(rng.integers(1, 9)))
+            nsamp = np.array([len(x) for x in sigs], dtype=np.int64)
+            pad = (nsamp + 7) // 8 * 8
+            sp = np.concatenate([[0], np.cumsum(pad)[:-1]]).astype(np.int64)
+            flat = np.zeros(int(pad.sum()) + 8, dtype=np.float32)
+            for i, sg in enumerate(sigs):
+                flat[sp[i]:sp[i] + nsamp[i]] = sg
+            bt = None
+            if seqs is not None:
+                rl = np.array([len(x) for x in seqs], dtype=np.int32)
+                rp = np.concatenate([[0], np.cumsum(rl.astype(np.int64) + 1)[:-1]]).astype(np.int64)
+                rd = np.zeros(int((rl.astype(np.int64) + 1).sum()), dtype=np.uint8)
+                for i, x in enumerate(seqs):
+                    rd[rp[i]:rp[i] + rl[i]] = np.frombuffer(x, dtype=np.uint8)
+                bt = dict(reads=rd, read_len=rl, read_ptr=rp)
+            v = ctx.signal_view(flat, sp, nsamp, scal, batch=bt, rna=rna)
+            ctx.events_view(v)
+            evs = [ctx.view_events(v, i) for i in range(m)]
+            ne = v["n_events"].astype(np.int64)
+            dsc = v["scalings"]
+            ctx.free_view(v)
+        else:
+            evs, ne, dsc = ctx.detect_events_device(list(sigs), scal, seqs=seqs, cap_div=1, rna=rna)
         for i, sg in enumerate(sigs):
             o_ev, _ = orc.getevents(sg, scal[i, 0], scal[i, 1], scal[i, 2], rna=rna)
             tag = f"batch {nb} signal {i} n={len(sg)} scaling={scal[i]}"
@@ -71,5 +99,7 @@ def run(budget=60.0, seed=1, ctx=None, max_batches=None):
 
 
 if __name__ == "__main__":
-    nb, ns, ne_tot, dt = run(float(sys.argv[1]) if len(sys.argv) > 1 else 60.0, int(sys.argv[2]) if len(sys.argv) > 2 else 1)
-    print(f"fuzz OK: {nb} batches, {ns} signals, {ne_tot} events bit-exact in {dt:.0f} s")
+    nb, ns, ne_tot, dt = run(float(sys.argv[1]) if len(sys.argv) > 1 else 60.0, int(sys.argv[2]) if len(sys.argv) > 2 else 1,
+                             host_entry=len(sys.argv) > 3 and sys.argv[3] == "host")
+    print(f"fuzz OK ({'host entry' if len(sys.argv) > 3 and sys.argv[3] == 'host' else 'device entry'}): {nb} batches, {ns} signals, "
+          f"{ne_tot} events bit-exact in {dt:.0f} s")
