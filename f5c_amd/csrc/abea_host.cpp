@@ -94,9 +94,20 @@ static std::string format_cpulist(const std::vector<int>& v) {
  *            and that set holds at least `threads` CPUs; otherwise unbound.  A device's flatten then reads the caller's
  *            event tables from wherever they are but WRITES its pinned staging (allocated by hipHostMalloc on the node
  *            nearest the current device) locally, and un-flatten reads it locally. */
-struct host_thread_plan { int threads; std::vector<int> cpus; };
-/* ONE switch for the binding, read by the run-time path and by the host-only report alike: opt-in, ABEA_HOST_NUMA=1
- * (measured to hurt unless the caller places each device's share of the batch on that device's node) */
+struct host_thread_plan {
+    int threads; std::vector<int> cpus;
+    std::vector<std::vector<int>> spread;      /* ABEA_HOST_NUMA=spread: worker t binds to spread[t % size] (one CPU list per NUMA node) */
+    std::string key() const { return std::to_string(threads) + "/" + std::to_string(cpus.size()) + "/" + std::to_string(spread.size()); }
+};
+/* Worker placement (round 5).  DEFAULT = spread: the workers alternate over the NUMA nodes (worker t on node t mod n, free to move
+ * among that node's CPUs).  The flatten loop streams the caller's event tables from wherever they lie — on a two-socket host
+ * typically both sockets — and an unbound pool lands where the scheduler happens to put it: with most workers on ONE socket every
+ * remote line crosses the inter-socket link in the same direction.  Measured on the MI355X host (2 x EPYC, configs[2], same
+ * process, alternating): unbound 231 / 268 / 333 ms of flatten per step (and 260-316 ms on other boxes), spread 214 / 215 / 219 ms
+ * (profiles/r05/s_numa_spread_ab.txt).  ABEA_HOST_NUMA=0: unbound; =1: every worker on the DEVICE's node (pays only when the
+ * caller's tables are there too: 599 ms when they are not); =spread: explicit.  Hosts with one node: unbound. */
+static bool host_numa_spread() { const char* nu = getenv("ABEA_HOST_NUMA"); return !nu || !nu[0] || strcmp(nu, "spread") == 0; }
+/* ONE switch for the device-node binding, read by the run-time path and by the host-only report alike: opt-in, ABEA_HOST_NUMA=1 */
 static bool host_numa_enabled() { const char* nu = getenv("ABEA_HOST_NUMA"); return nu && nu[0] == '1'; }
 static std::vector<host_thread_plan> plan_host_threads(int usable_cpus, const std::vector<int>& allowed, int n_devices,
                                                         const int32_t* dev_node, const std::vector<std::vector<int>>& node_cpus,
@@ -203,8 +214,13 @@ struct abea_host_pool {
     bool stop = false;
 
     /* `cpus` (may be empty): the CPUs the workers bind to — the NUMA node of the pool's device (plan_host_threads) */
-    explicit abea_host_pool(int threads, const std::vector<int>& cpus = std::vector<int>()) {
-        for (int t = 1; t < threads; ++t) th.emplace_back([this, cpus]() { bind_this_thread(cpus); worker(); });
+    std::string key;                                          /* of the plan it was built for (threads + binding) */
+    explicit abea_host_pool(int threads, const std::vector<int>& cpus = std::vector<int>(),
+                            const std::vector<std::vector<int>>& spread = std::vector<std::vector<int>>()) {
+        for (int t = 1; t < threads; ++t) {
+            const std::vector<int> mine = spread.empty() ? cpus : spread[(size_t)t % spread.size()];
+            th.emplace_back([this, mine]() { bind_this_thread(mine); worker(); });
+        }
     }
     ~abea_host_pool() {
         { std::lock_guard<std::mutex> lk(mu); stop = true; }
@@ -352,7 +368,7 @@ static std::vector<host_thread_plan> context_thread_plan(abea_ctx* c) {
      * per-call overhead on the latency-bound default f5c batches (round-3 advisor finding); the key is the two switches */
     const bool numa = host_numa_enabled();
     abea_host_async* a = async_of(c);
-    const std::string key = std::string(e ? e : "") + "|" + (numa ? "1" : "0");
+    const std::string key = std::string(e ? e : "") + "|" + (numa ? "1" : host_numa_spread() ? "s" : "0");
     if (a->plan_key == key && a->plan.size() == nodes.size()) return a->plan;
     /* Binding is OPT-IN at run time (ABEA_HOST_NUMA=1).  Measured on the MI355X box (2 sockets, bench.py, 100 k reads): with
      * the workers of the one device bound to its node, flatten went from 217 to 602 ms per step — the loop READS 24 B per
@@ -361,6 +377,16 @@ static std::vector<host_thread_plan> context_thread_plan(abea_ctx* c) {
      * socket.  It pays only when the caller places each device's share of the batch on that device's node. */
     a->plan = plan_host_threads(effective_cpus(), numa ? allowed_cpus() : std::vector<int>(), (int)nodes.size(), nodes.data(),
                                 numa ? numa_node_cpus() : std::vector<std::vector<int>>(), e ? std::max(1, atoi(e)) : 0, numa);
+    if (host_numa_spread()) {                                  /* one CPU list per NUMA node the process may run on */
+        const std::vector<int> allowed = allowed_cpus();
+        std::vector<std::vector<int>> per_node;
+        for (const std::vector<int>& nc : numa_node_cpus()) {
+            std::vector<int> local;
+            std::set_intersection(nc.begin(), nc.end(), allowed.begin(), allowed.end(), std::back_inserter(local));
+            if (!local.empty()) per_node.push_back(local);
+        }
+        if (per_node.size() >= 2) for (host_thread_plan& pl : a->plan) pl.spread = per_node;
+    }
     a->plan_key = key;
     return a->plan;
 }
@@ -379,7 +405,8 @@ void abea_parallel_for(abea_ctx* c, int64_t n, int64_t grain, const std::functio
     abea_host_async* a = async_of(c);
     if (!a->full.pool) {
         const host_thread_plan pl = context_thread_plan(c)[0];
-        a->full.pool = new abea_host_pool(pl.threads, pl.cpus);
+        a->full.pool = new abea_host_pool(pl.threads, pl.cpus, pl.spread);
+        a->full.pool->key = pl.key();
     }
     a->full.pool->run(n, grain, f);
 }
@@ -938,9 +965,10 @@ struct slot_guard {
  * is only used while no share is (the top-level context's bookkeeping guarantees it). */
 static void ensure_lanes(abea_ctx* c, const host_thread_plan& pl, int n_lanes, int n_slots, bool want_shares) {
     abea_host_async* a = async_of(c);
-    if (!a->full.pool || a->full.pool->threads() != pl.threads) {
+    if (!a->full.pool || a->full.pool->key != pl.key()) {
         delete a->full.pool;
-        a->full.pool = new abea_host_pool(pl.threads, pl.cpus);
+        a->full.pool = new abea_host_pool(pl.threads, pl.cpus, pl.spread);
+        a->full.pool->key = pl.key();
     }
     a->full.first_slot = 0; a->full.n_slots = n_slots; a->full.arena_off = 0; a->full.arena_bytes = c->arena_bytes;
     /* the share lanes (and their worker pools) exist only once a batch has been SUBMITTED: a context that is only ever
@@ -955,7 +983,7 @@ static void ensure_lanes(abea_ctx* c, const host_thread_plan& pl, int n_lanes, i
         for (int l = 0; l < n_lanes; ++l) {
             a->lanes[(size_t)l].first_slot = l * per_slots; a->lanes[(size_t)l].n_slots = per_slots;
             a->lanes[(size_t)l].arena_off = (size_t)l * per_arena; a->lanes[(size_t)l].arena_bytes = per_arena;
-            a->lanes[(size_t)l].pool = new abea_host_pool(per_threads, pl.cpus);
+            a->lanes[(size_t)l].pool = new abea_host_pool(per_threads, pl.cpus, pl.spread);
         }
     }
 }

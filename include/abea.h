@@ -380,7 +380,9 @@ int abea_host_plan_chunks(const int32_t* read_len, const int32_t* n_events, int3
 /* The worker-thread / CPU-affinity plan of the host entry (host-only, pure): per DEVICE context
  * threads = (usable_cpus - 2) / n_devices clamped to [1, 16] (ABEA_HOST_THREADS overrides, per device), bound to the CPUs of
  * the device's NUMA node that the process may run on when the machine has several nodes and that set is at least as large
- * — when ABEA_HOST_NUMA=1.  The binding is opt-in, and this report and the run-time path read the SAME switch: the host
+ * — when ABEA_HOST_NUMA=1.  (The run-time DEFAULT, round 5, is ABEA_HOST_NUMA=spread: the workers alternate over the NUMA nodes, which
+ * took the box-to-box spread out of the flatten loop — 214-219 ms per 100 k reads where an unbound pool measured 231-333; =0 leaves
+ * them unbound.  This report covers the =1 mode only.)  The =1 binding is opt-in, and this report and the run-time path read the SAME switch: the host
  * loops read the caller's event tables (24 B per event) from wherever the caller placed them and write 4 B per event of
  * staging, so binding a device's workers to its node pays only if the caller's buffers are on that node too (measured:
  * DESIGN.md §5); without ABEA_HOST_NUMA=1 every bind list is "".  cpulists use the sysfs format ("0-63,128-191"); allowed_cpulist NULL or "" = all.

@@ -168,6 +168,13 @@ def main():
         ("fused_slots16", "fused", s16, False),
         ("fused_rmin512_slots16", "fused", {**r512, **s16}, False),
         ("base_again", "pairs", {}, False),
+        ("spread", "pairs", {"ABEA_HOST_NUMA": "spread"}, False),
+        ("base_3", "pairs", {}, False),
+        ("spread_2", "pairs", {"ABEA_HOST_NUMA": "spread"}, False),
+        ("fused_spread", "fused", {"ABEA_HOST_NUMA": "spread"}, False),
+        ("fused_base_2", "fused", {}, False),
+        ("base_4", "pairs", {}, False),
+        ("spread_3", "pairs", {"ABEA_HOST_NUMA": "spread"}, False),
     ]
     extra = os.environ.get("SWEEP_EXTRA")            # JSON list of [name, view, env, trace] appended by the caller
     if extra:
