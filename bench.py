@@ -274,12 +274,13 @@ def main():
             out["per_rank"] = rows
             # the caller thread of the slowest rank either works (flatten + un-flatten) or waits for its GPU
             # N = 1: the caller's thread working >= 95 % of the step means the GPU is fed late ("host"), whatever the device's own
-            # clock says about gaps; otherwise "gpu" when the device has (almost) no gaps of its own
+            # clock says about gaps; "ramp" = neither side saturated: the device idles >= 10 % of the step by its own clock while
+            # the pipeline fills and drains (small batches); otherwise "gpu"
             h0 = out["host_to_host"]["host_ms_per_step"]
             hb = (h0["flatten"] + h0["unflatten"] + h0["plan"] + h0["setup"]) / max(1e-9, out["host_to_host"]["ms_per_step"]) if world == 1 else None
             if world == 1:
                 out["host_to_host"]["host_busy_frac"] = round(hb, 4)
-            out["bound"] = ("host" if hb >= 0.95 or out["host_to_host"]["gpu_idle_frac"] >= 0.10 else "gpu") if world == 1 else \
+            out["bound"] = ("host" if hb >= 0.95 else "ramp" if out["host_to_host"]["gpu_idle_frac"] >= 0.10 else "gpu") if world == 1 else \
                            ("host" if busy >= slow["host_ms_per_step"]["wait_for_gpu"] else "gpu")
             out["bound_note"] = ("rank 0's device idle %.1f %% of the step by its own clock; " % (100 * out["host_to_host"]["gpu_idle_frac"]) +
                                  "slowest rank %d: %.0f ms of host loops and %.0f ms waiting for the GPU per %.0f-ms step; all ranks share one "
