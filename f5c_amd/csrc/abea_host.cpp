@@ -654,7 +654,9 @@ struct host_opts {
 
 static host_opts read_opts() {
     host_opts o;
-    o.chunk_events = (size_t)48 << 20; o.chunk_reads_min = 2048; o.chunk_reads_max = 16384; o.n_slots = 8; o.device_pairs = false;
+    /* >= 1024 reads and >= 24 M events per chunk on 8 slots (round 5, 16 hardware queues, spread workers, configs[2] in one process:
+     * 344 ms against 355-357 with 2048 reads / 48 M events, 384 with 4096 / 96 M, 392 with 16 slots: profiles/r05/k_chunk_slot_sweep.txt) */
+    o.chunk_events = (size_t)24 << 20; o.chunk_reads_min = 1024; o.chunk_reads_max = 16384; o.n_slots = 8; o.device_pairs = false;
     if (const char* e = getenv("ABEA_HOST_CHUNK_EVENTS")) o.chunk_events = std::max<size_t>(1, strtoull(e, nullptr, 10));
     if (const char* e = getenv("ABEA_HOST_CHUNK_READS")) o.chunk_reads_min = std::max(1, atoi(e));
     if (const char* e = getenv("ABEA_HOST_CHUNK_READS_MAX")) o.chunk_reads_max = std::max(1, atoi(e));

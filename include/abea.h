@@ -371,7 +371,7 @@ int abea_expand_kmer_counts_to_map(const uint8_t* count, int32_t n_kmers, int32_
 int abea_flatten_event_means(const abea_event_t* events, int32_t n_events, float* means, int32_t prefetch_bytes, int32_t hint);
 /* The chunk plan abea_align_batch_host() uses for a batch on an arena of arena_bytes (host-only; pairs returned, no
  * fused scaling): chunk_of[i] = launch-order number of the chunk read i goes into, -1 for reads skipped by the
- * align_single guards (src/f5c.c:813-814).  Reads go longest first; a chunk holds >= 2048 reads and >= 48 M events (the
+ * align_single guards (src/f5c.c:813-814).  Reads go longest first; a chunk holds >= 1024 reads and >= 24 M events (the
  * first two a quarter / half of that), at most 16384 reads, and fits an eighth of the arena; ABEA_HOST_CHUNK_* and
  * ABEA_HOST_SLOTS in the environment override the numbers. */
 int abea_host_plan_chunks(const int32_t* read_len, const int32_t* n_events, int32_t n_reads, uint32_t kmer_size,

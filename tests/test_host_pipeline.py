@@ -168,7 +168,7 @@ def test_walk_code_expansion_matches_the_traceback(orc, r9):
 
 def test_chunk_plan_of_the_host_entry(monkeypatch):
     """abea_host_plan_chunks = the carving abea_align_batch_host applies: every runnable read in exactly one chunk, size rules
-    (>= 2048 reads and >= 48 M events, first two chunks a quarter / half, <= 16384 reads), the arena share respected, over-long
+    (>= 1024 reads and >= 24 M events, first two chunks a quarter / half, <= 16384 reads), the arena share respected, over-long
     reads alone, guard failures left out.  Launch order (round 5): an ascending ramp — every other read above 18 000 bands,
     shortest first — then everything else longest first; ABEA_HOST_ORDER=lpt = plain longest-first."""
     import ctypes
@@ -196,7 +196,7 @@ def test_chunk_plan_of_the_host_entry(monkeypatch):
         else:
             monkeypatch.delenv("ABEA_HOST_ORDER")
         rc, ch, n = plan(L, E, 150 << 30)
-        assert rc == 0 and 20 <= n <= 40
+        assert rc == 0 and 40 <= n <= 80
         assert (ch[skipped] == -1).all() and (ch[~skipped] >= 0).all() and ch.max() == n - 1
         hi = np.array([bands[ch == c].max() for c in range(n)]); lo = np.array([bands[ch == c].min() for c in range(n)])
         if order == "lpt":
@@ -209,21 +209,21 @@ def test_chunk_plan_of_the_host_entry(monkeypatch):
             assert (hi[:top - 1] <= lo[1:top]).all() and lo[0] >= 18000             # ascending up to the chunk holding the turn; nothing below the ramp's floor
             ramp_reads = np.isin(ch, np.arange(top + 1)) & ~skipped
             above = (bands >= 18000) & ~skipped
-            assert abs(int(ramp_reads.sum()) - int(above.sum()) // 2) <= 16384       # ~half of the long reads (the chunk holding the turn is mixed)
+            assert abs(int(ramp_reads.sum()) - int(above.sum()) // 2) <= 8192       # ~half of the long reads (the chunk holding the turn is mixed)
             desc_from = top + 1
             assert (lo[desc_from:-1] >= hi[desc_from + 1:]).all()       # the LPT tail is untouched
-            assert hi[-1] < 4000 and (ch == 0).sum() >= 512 and E[ch == 0].sum() < 40 << 20   # a cheap first chunk: the GPU starts after ~2 ms
+            assert hi[-1] < 4000 and (ch == 0).sum() >= 256 and E[ch == 0].sum() < 20 << 20   # a cheap first chunk: the GPU starts after ~2 ms
         for c in range(n):
             m = ch == c
             cnt, ev = int(m.sum()), int(E[m].sum())
             ramp = 4 if c == 0 else 2 if c == 1 else 1
             if c < n - 1:
-                assert cnt >= 2048 // ramp and (ev >= (48 << 20) // ramp or cnt == 16384)
+                assert cnt >= 1024 // ramp and (ev >= (24 << 20) // ramp or cnt == 16384)
             assert cnt <= 16384
             # closing rule (descending part): without its last (shortest) read the chunk would have been below one of the two thresholds
             last = np.nonzero(m)[0][np.argmin(bands[m])]
             if desc_from <= c < n - 1 and cnt < 16384:
-                assert cnt - 1 < 2048 // ramp or ev - int(E[last]) < (48 << 20) // ramp
+                assert cnt - 1 < 1024 // ramp or ev - int(E[last]) < (24 << 20) // ramp
     # small batches keep plain longest-first: nothing to ramp with fewer than 8192 long reads
     rc, chs, ns = plan(L[:6000], 2 * L[:6000], 150 << 30)
     assert rc == 0
@@ -254,7 +254,7 @@ def test_both_pair_return_modes_many_chunks(ctx, orc, r9, monkeypatch, mode):
                              lengths=np.exp(np.random.default_rng(1).uniform(np.log(300), np.log(9000), 150)).astype(int))
     ora = orc.align_batch(batch, model, k, n_threads=8)
     monkeypatch.setenv("ABEA_HOST_PAIRS", "device" if mode == "device" else "host")
-    for chunk_reads, chunk_events in ((7, 30000), (2048, 48 << 20)):
+    for chunk_reads, chunk_events in ((7, 30000), (1024, 24 << 20)):
         monkeypatch.setenv("ABEA_HOST_CHUNK_READS", str(chunk_reads))
         monkeypatch.setenv("ABEA_HOST_CHUNK_EVENTS", str(chunk_events))
         plist, n_pairs, diag = ctx.align_flat_host(batch)
