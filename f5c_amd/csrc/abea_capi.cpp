@@ -326,10 +326,12 @@ extern "C" int abea_align_batch_device(abea_ctx* c, const abea_device_batch* B) 
         for (size_t j = 0; j < m; ++j) {
             const plan_read& r = reads[(size_t)seq[pos + j]];
             abea_read_desc& d = c->h_desc[j];
-            plan_desc(d, r, B->scalings[r.idx], lay, st);
+            plan_desc_layout(d, r, B->scalings[r.idx], lay, st);
             d.read_off = B->read_ptr[r.idx]; d.event_off = B->event_ptr[r.idx]; d.pair_off = B->pair_ptr[r.idx];
             d.kmer_off = B->kmer_ptr ? B->kmer_ptr[r.idx] : 0;
         }
+        /* the per-read log-probabilities (four libm calls each: 25 ms for 100 k reads on one thread) on the worker pool */
+        abea_parallel_for(c, (int64_t)m, 512, [&](int64_t lo, int64_t hi) { for (int64_t j = lo; j < hi; ++j) plan_desc_consts(c->h_desc[j]); });
         const size_t n_kpar = lay.n_kpar, n_evm = lay.n_evm, n_code = lay.n_code, n_trace = lay.n_trace;
         uint8_t* p = c->arena;
         abea_read_desc* d_desc = (abea_read_desc*)p;        p += align_up(m * sizeof(abea_read_desc), 256);
