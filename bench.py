@@ -37,6 +37,10 @@ sys.path.insert(0, ROOT)
 import f5c_amd  # noqa: E402,F401  first: sets GPU_MAX_HW_QUEUES=16 (unless given) before torch initialises the HIP runtime
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (≈6.3 TB/s achievable)
+# every value `bound` can take in the line (tests import these instead of repeating the literals: the round-5 GPU suite went red
+# on a test that still listed two of the three)
+BOUND_VALUES = ("host", "ramp", "gpu")
+ROOFLINE_BOUND_VALUES = ("valu", "hbm")
 
 
 def main():
@@ -309,9 +313,14 @@ def main():
             out["kernel_only"] = {"mevents_per_s": round(total_events * dsteps / dev["kernel_s_max"] / 1e6, 1),
                                   "ms_per_step": {"pre": round(dev["pre_ms"] / dsteps, 3), "align": round(dev["fill_ms"] / dsteps, 3)},
                                   "align_launches_per_step": int(dev["launches_per_step"])}
-            out["roofline"] = {"bound": "hbm", "kernel": "abea_align_kernel", "achieved": round(achieved, 2),
-                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                               "target_frac": 0.40, "target_met": bool(achieved / HBM_PEAK_GBS >= 0.40),
+            hbm_frac = achieved / HBM_PEAK_GBS
+            out["roofline"] = {"bound": "valu", "kernel": "abea_align_kernel", "achieved": round(achieved, 2),
+                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm_frac, 5),
+                               "bound_note": "`bound` is what the counters say limits the kernel: VALU issue (valu_roofline.frac = the share of the "
+                                             "launch the fill loop's class-weighted issue cycles account for; LDS conflicts 0; real HBM traffic "
+                                             "= `traffic`, about half of the algorithmic bytes).  achieved / peak / frac stay the HBM figures the "
+                                             "metric asks for: algorithmic bytes A_ref of one launch / its measured duration against 8 TB/s",
+                               "target_frac": 0.40, "target_met": bool(hbm_frac >= 0.40),
                                "target_note": "north_star asks for >= 0.40 of the HBM roofline on A_ref; NOT met and not reachable with the CPU "
                                               "path's arithmetic (27 of ~50 VALU instructions per band are fp64-class, align.c:382-384): the kernel "
                                               "sits on the VALU issue ceiling, see valu_roofline",
@@ -326,6 +335,7 @@ def main():
                                "measured_on": "the device-resident leg of this run (one launch per step; HIP events on the "
                                               "library's stream); the host-to-host steps launch the same kernel once per chunk",
                                "limiter": valu_issue(args.config, sum_events, fill_avg_ms, dev["launches_per_step"])}
+            out["roofline_pre"] = pre_roofline(args.config, batch, k, sum_events, dev["pre_ms"] / max(1, dev["launches"]), dev["launches_per_step"])
         if world == 1 and not args.single_process and not args.no_small_batch and host_stats is not None:
             out["f5c_default_batch"] = small_batch(ctx, batch)
             out["fused_scaling"] = fused_scaling(ctx, batch, view)
@@ -562,26 +572,25 @@ def pmc_traffic(config, sum_events, launches):
 
 
 def valu_issue(config, sum_events, launch_ms, launches):
-    """What actually bounds the kernel: VALU issue.  `frac` is a MEASURED ratio on this config — the gfx9 VALUBusy formula,
-    SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs), from the committed rocprofv3 PMC pass of
-    `bench.py --mode device` on the same workload (profiles/pmc_traffic.json, built by profiles/make_pmc_traffic.py) — not an
-    instruction count times a cost constant (round 2's model gave 1.025, an impossible fraction)."""
+    """The counters behind `roofline.bound = "valu"`: VALU wave-instructions per launch, how the waves' time splits into issuing /
+    issue-stalled / waiting on s_waitcnt, and the LDS bank-conflict cycles, from the committed rocprofv3 SQ passes of `bench.py --mode
+    device` on the same workload (profiles/pmc_traffic.json, built by profiles/make_pmc_traffic.py).  No busy FRACTION is derived from
+    them: the gfx9 VALUBusy formula books 4 cycles per VALU instruction of any class, which over-counts full-rate instructions on a
+    SIMD that issues a wave64 f32 / int instruction in 2 passes (it read 1.06 — rounds 2-5 printed it; the class-weighted
+    valu_roofline.class_floor is the model that holds)."""
     try:
         t = pmc_entry(config)
         if t is None:
-            return {"unit": "valu-busy", "static": True, "stale": True, "code_sha256": kernel_code_sha(),
+            return {"static": True, "stale": True, "code_sha256": kernel_code_sha(),
                     "static_note": "profiles/pmc_traffic.json was taken on other kernel sources (code_sha256 differs): no counters quoted"}
-        # the counter books one quad-cycle per VALU instruction of any class and the per-XCD GRBM clocks are averaged, so the
-        # measured ratio is good to about 1 %: it reads 1.0015 on this workload ("saturated"); frac is capped at 1, raw kept
         prof_ms = t["kernel_ms_in_each_pass"].get("sqb")
-        return {"unit": "valu-busy", "static": True, "code_sha256": t["code_sha256"],
-                "static_note": "counter ratio of the committed PMC pass (profiles/pmc_traffic.json), NOT measured in this run; tied to the "
+        return {"static": True, "code_sha256": t["code_sha256"],
+                "static_note": "counters of the committed PMC passes (profiles/pmc_traffic.json), NOT measured in this run; tied to the "
                                "kernel sources by code_sha256 (abea_fill.inc + abea_walk.inc + abea_kernels.hip, recomputed here), and "
                                "stale as well if kernel_ms_this_run is more than 3 % from kernel_ms_in_the_pmc_pass",
                 "stale": bool(prof_ms is None or abs(launch_ms - prof_ms) > 0.03 * prof_ms),
-                "frac": round(min(1.0, t["valu_busy"]), 4), "raw_counter_ratio": round(t["valu_busy"], 4),
-                "formula": t["valu_busy_formula"],
                 "valu_wave_instr_per_launch": int(t["valu_wave_instr_per_event"] * sum_events / max(1, launches)),
+                "valu_wave_instr_per_event": round(t["valu_wave_instr_per_event"], 2),
                 "wave_time_split": {k: round(v, 3) for k, v in t["wave_time_split"].items()},
                 "lds_bank_conflict_cycles": t.get("lds_bank_conflict_cycles"),
                 "kernel_ms_in_the_pmc_pass": t["kernel_ms_in_each_pass"].get("sqb"), "kernel_ms_this_run": round(launch_ms, 3),
@@ -591,37 +600,45 @@ def valu_issue(config, sum_events, launch_ms, launches):
 
 
 def valu_roofline(config, sum_events, launch_ms, launches, n_right=0, n_down=0):
-    """The ceiling the kernel actually sits on: VALU issue.  Two models, both against this run's measured launch time:
-      issue_slots   every VALU wave-instruction holds its SIMD for 4 cycles: VALU wave-instructions per launch (SQ_INSTS_VALU of
-                    the committed SQ pass of the same workload, per event, scaled to this launch) / (1024 SIMDs x clock / 4).
-                    Not a bound: full-rate f32 / int instructions issue a wave64 in 2 passes on CDNA3/4, so frac can pass 1.
-      class_floor   the fill loop only, from the COMMITTED instruction stream (tools/isa_audit.py over abea_fill.inc): per band
-                    `slow` instructions (fp64 add/mul, converts, DPP, cross-lane, compares: 4 cycles) and `fast` ones (f32 / int
-                    full rate: 2 cycles), times the right-move and down-move bands of this launch.  A true lower bound of the
-                    kernel time (walk and expansion add to it)."""
+    """The ceiling the kernel actually sits on: VALU issue.  class_floor = the fill loop only, from the COMMITTED instruction stream
+    (tools/isa_audit.py over abea_fill.inc): per band `slow` instructions (fp64 add/mul, converts, DPP, cross-lane, compares: 4 cycles
+    per wave64 on a SIMD) and `fast` ones (f32 / int full rate: 2 cycles), times the right-move and down-move bands of this launch,
+    over 1024 SIMDs at the measured shader clock.  A true lower bound of the kernel time (walk and expansion add to it), so
+    frac = floor / measured <= 1."""
     try:
         t = pmc_entry(config) or {}
         clk = t.get("shader_clock_ghz", 2.4)                    # measured GRBM clock of the SQ pass; 2.4 GHz nominal without one
         out = {"measured_ms": round(launch_ms, 3), "shader_clock_ghz": round(clk, 3)}
-        if "valu_wave_instr_per_event" in t:
-            instr = t["valu_wave_instr_per_event"] * sum_events / max(1, launches)
-            ceiling_ms = instr / (1024 * clk * 1e9 / 4) * 1e3
-            out["issue_slots"] = {"valu_wave_instr_per_launch": int(instr), "simds": 1024, "cycles_per_instr": 4,
-                                  "ms": round(ceiling_ms, 2), "frac": round(ceiling_ms / launch_ms, 4),
-                                  "counters": "static: " + str(t.get("passes", {}).get("sqa"))}
-        try:
-            sys.path.insert(0, os.path.join(ROOT, "tools"))
-            import isa_audit
-            c = isa_audit.interior_classes()
-            cyc = n_right * (4 * c["R"]["slow"] + 2 * c["R"]["fast"]) + n_down * (4 * c["D"]["slow"] + 2 * c["D"]["fast"])
-            floor_ms = cyc / (1024 * clk * 1e9) * 1e3
-            out["class_floor"] = {"per_band": c, "right_move_bands": int(n_right), "down_move_bands": int(n_down),
-                                  "cycles": {"slow": 4, "fast": 2}, "ms": round(floor_ms, 2), "frac": round(floor_ms / launch_ms, 4),
-                                  "source": "f5c_amd/csrc/abea_fill.inc (interior bodies) via tools/isa_audit.py"}
-            out["frac"] = out["class_floor"]["frac"]
-        except Exception:
-            out["frac"] = out.get("issue_slots", {}).get("frac")
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import isa_audit
+        c = isa_audit.interior_classes()
+        cyc = n_right * (4 * c["R"]["slow"] + 2 * c["R"]["fast"]) + n_down * (4 * c["D"]["slow"] + 2 * c["D"]["fast"])
+        floor_ms = cyc / (1024 * clk * 1e9) * 1e3
+        out["class_floor"] = {"per_band": c, "right_move_bands": int(n_right), "down_move_bands": int(n_down),
+                              "cycles": {"slow": 4, "fast": 2}, "ms": round(floor_ms, 2), "frac": round(floor_ms / launch_ms, 4),
+                              "source": "f5c_amd/csrc/abea_fill.inc (interior bodies) via tools/isa_audit.py"}
+        out["frac"] = out["class_floor"]["frac"]
         return out
+    except Exception:
+        return None
+
+
+def pre_roofline(config, batch, k, sum_events, pre_ms, launches):
+    """abea_pre_kernel (align-pre: k-mer ranks, model gather, read-scaled parameters, AoS event_t -> SoA means), HBM-bound streaming.
+    Algorithmic bytes per launch: in 24 B per event (the AoS table) + L + 1 per read (sequence) + 112 (descriptor),
+    out 4 B per event (mean) + 16 B per k-mer (gpm, ck, istd); the 4^k-entry model is gathered from L2.  achieved = those bytes /
+    the launch time of the device-resident leg (HIP events); traffic = FETCH_SIZE x 2 + WRITE_SIZE of the committed PMC passes."""
+    try:
+        import numpy as np
+        L = batch["read_len"].astype(np.int64)
+        K = (L - k + 1).clip(min=0)
+        a = (28 * sum_events + int((L + 1).sum()) + 112 * len(L) + 16 * int(K.sum())) / max(1, launches)
+        achieved = a / (pre_ms * 1e-3) / 1e9
+        t = (pmc_entry(config) or {}).get("pre_kernel")
+        return {"bound": "hbm", "kernel": "abea_pre_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "avg_launch_ms": round(pre_ms, 3), "algorithmic_bytes_per_launch": int(a),
+                "traffic": int(t["hbm_bytes_per_event"] * sum_events / max(1, launches)) if t else None,
+                "traffic_source": t.get("passes") if t else None}
     except Exception:
         return None
 

@@ -18,7 +18,7 @@ EXPORTS = ["abea_init", "abea_init_multi", "abea_device_count", "abea_free", "ab
            "abea_device_info", "abea_selftest", "abea_rsq_format", "abea_lpt_split", "abea_hmm_score_batch_host", "abea_expand_walk_codes", "abea_expand_walk_codes_to_map",
            "abea_host_plan_chunks", "abea_host_plan_threads", "abea_set_inflight", "abea_align_batch_host_submit",
            "abea_align_batch_host_wait", "abea_events_batch_host", "abea_process_batch_host", "abea_rsq_format_batch",
-           "abea_hmm_score_batch_device", "abea_expand_kmer_counts_to_map", "abea_flatten_event_means"]
+           "abea_hmm_score_batch_device", "abea_expand_kmer_counts_to_map", "abea_flatten_event_means", "abea_link_probe"]
 SHIM_EXPORTS = ["abea_f5c_init", "abea_f5c_align", "abea_f5c_align_scale", "abea_f5c_free", "abea_f5c_align_submit",
                 "abea_f5c_align_wait", "abea_f5c_event_db", "abea_f5c_process"]      # include/abea_f5c_shim.h
 
@@ -261,6 +261,15 @@ class AbeaContext:
         arena = C.c_uint64()
         self._chk(self._lib.abea_device_info(self._h, arch, 64, C.byref(ncu), C.byref(arena)), "abea_device_info")
         return dict(arch=arch.value.decode(), n_cu=ncu.value, arena_bytes=arena.value)
+
+    def link_probe(self, nbytes=0, reps=0):
+        """abea_link_probe: GB/s of the host<->device link with pinned memory, one direction at a time and both at once."""
+        out = (C.c_double * 7)()
+        self._lib.abea_link_probe.restype = C.c_int
+        self._lib.abea_link_probe.argtypes = [C.c_void_p, C.c_uint64, C.c_int32, C.POINTER(C.c_double), C.c_int32]
+        self._chk(self._lib.abea_link_probe(self._h, nbytes, reps, out, 7), "abea_link_probe")
+        keys = ("h2d_copy", "d2h_copy", "d2h_kernel", "both_h2d_copy", "both_d2h_kernel", "both_copy_h2d", "both_copy_d2h")
+        return {k_: round(float(v), 2) for k_, v in zip(keys, out)}
 
     def stats(self):
         s = Stats()

@@ -73,8 +73,11 @@ extern "C" int abea_init(abea_ctx** out, const abea_cfg* cfg) {
      * (default 4) and kernels of streams that share a queue run one after the other (measured: 422 -> 370 ms per 100 k reads
      * with 16 queues, profiles/r05/hw_queues_ab.txt).  The runtime reads the variable when it initialises, i.e. at the first HIP
      * call of the process: if that is the call below (f5c: init_cuda is the first thing that touches the device) this takes
-     * effect; a process that has already used HIP must export it itself.  Never overrides the caller's value. */
-    setenv("GPU_MAX_HW_QUEUES", "16", 0);
+     * effect; a process that has already used HIP must export it itself.  Never overrides the caller's value, and
+     * ABEA_KEEP_HW_QUEUES=1 (any value) keeps the library's hands off the environment altogether: setenv is not safe against other
+     * threads calling getenv/setenv at the same moment and changes the runtime's configuration for every HIP user of the process —
+     * a host application that runs threads before init_cuda's replacement should export the variable itself and set the opt-out. */
+    if (!getenv("ABEA_KEEP_HW_QUEUES")) setenv("GPU_MAX_HW_QUEUES", "16", 0);
     int n_dev = 0;
     if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0)
         return abea_fail(ABEA_ENODEV, "abea_init: no HIP device visible (this library has no CPU fallback)");

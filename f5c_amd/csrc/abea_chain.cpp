@@ -33,6 +33,7 @@
 
 extern "C" __global__ void abea_ev_compact_kernel(int, const abea_event_t*, const int64_t*, const int64_t*, const int32_t*,
                                                   abea_event_t*);
+extern "C" __global__ void abea_ev_pack_kernel(int, const abea_event_t*, const int64_t*, const int64_t*, const int32_t*, uint4*);
 
 namespace {
 
@@ -47,8 +48,10 @@ struct pinned_buf {
 
 /* one chunk in flight */
 struct abea_chain_slot {
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr, dstream = nullptr;  /* dstream: the tables' own device-to-host stream (copy-engine mode) */
     hipEvent_t e_cnt = nullptr, e_done = nullptr, t0 = nullptr, t1 = nullptr, t2 = nullptr, t3 = nullptr, t4 = nullptr;
+    hipEvent_t e_cmp = nullptr, e_tab = nullptr;     /* compaction done (kernel stream) / tables down (dstream) */
+    bool tab_on_dstream = false, packed = false;
     pinned_buf up, cnt, desc, dn, tab;
     void* idx_p = nullptr; size_t idx_cap = 0;       /* grown by abea_detect_events_on */
     bool busy = false, staged = false;
@@ -59,7 +62,7 @@ struct abea_chain_slot {
     std::vector<float> sc3;
     std::vector<uint8_t> run;                        /* aligned on the GPU (process mode) */
     std::vector<abea_scalings_t> est;                /* method-of-moments scalings */
-    size_t n_sig = 0, n_slot = 0, n_seq = 0, n_ev = 0, u_end = 0, o_seq = 0;
+    size_t n_sig = 0, n_slot = 0, n_seq = 0, n_ev = 0, n_rec = 0, u_end = 0, o_seq = 0;   /* n_rec: table records incl. per-read padding */
     uint8_t* arena = nullptr; size_t arena_bytes = 0;
     uint8_t* d_up = nullptr; abea_event_t* d_ev = nullptr; abea_event_t* d_evc = nullptr; uint8_t* d_cnt = nullptr;
     int64_t* d_idx = nullptr; uint8_t* d_rest = nullptr; size_t rest_bytes = 0;
@@ -69,21 +72,32 @@ struct abea_chain_slot {
     std::vector<abea_read_desc> descs;               /* host copy: code_off / kmer_off / n_kmers at retire */
 };
 
+static void abea_chain_slot_destroy(abea_chain_slot* s);
+
 void abea_chain_release(abea_ctx* c) {
     for (abea_chain_slot* s : c->chain_slots) {
         if (!s) continue;
-        if (s->stream) { hipStreamSynchronize(s->stream); hipStreamDestroy(s->stream); }
-        for (hipEvent_t e : {s->e_cnt, s->e_done, s->t0, s->t1, s->t2, s->t3, s->t4}) if (e) hipEventDestroy(e);
-        s->up.release(); s->cnt.release(); s->desc.release(); s->dn.release(); s->tab.release();
-        if (s->idx_p) hipHostFree(s->idx_p);
-        delete s;
+        abea_chain_slot_destroy(s);
     }
     c->chain_slots.clear();
 }
 
+static void abea_chain_slot_destroy(abea_chain_slot* s) {
+    if (s->stream) { hipStreamSynchronize(s->stream); hipStreamDestroy(s->stream); }
+    if (s->dstream) { hipStreamSynchronize(s->dstream); hipStreamDestroy(s->dstream); }
+    for (hipEvent_t e : {s->e_cnt, s->e_done, s->t0, s->t1, s->t2, s->t3, s->t4, s->e_cmp, s->e_tab}) if (e) hipEventDestroy(e);
+    s->up.release(); s->cnt.release(); s->desc.release(); s->dn.release(); s->tab.release();
+    if (s->idx_p) hipHostFree(s->idx_p);
+    delete s;
+}
+
 namespace {
 
-struct chain_opts { size_t chunk_samples; int32_t reads_min, reads_max; int n_slots; size_t cap_div; };
+/* packed: the tables cross PCIe as 12-byte {start, mean, stdv} records and the retire loop rebuilds event_t from them (half the bytes
+ * of the call's dominant transfer); copy_engine: they come down by hipMemcpyAsync on the slot's own device-to-host stream instead of
+ * abea_copy_out_kernel.  Defaults = what measured fastest on the MI355X box (profiles/r06/chain_*); ABEA_CHAIN_TABLE_FORMAT=full|packed
+ * and ABEA_CHAIN_TABLE_COPY=kernel|engine override (read per call: A/B runs in one process). */
+struct chain_opts { size_t chunk_samples; int32_t reads_min, reads_max; int n_slots; size_t cap_div; bool packed, copy_engine; };
 
 chain_opts read_chain_opts() {
     chain_opts o;
@@ -93,17 +107,30 @@ chain_opts read_chain_opts() {
     if (const char* e = getenv("ABEA_CHAIN_CHUNK_READS_MAX")) o.reads_max = std::max(1, atoi(e));
     if (const char* e = getenv("ABEA_CHAIN_SLOTS")) o.n_slots = std::min(ABEA_MAX_SLOTS, std::max(1, atoi(e)));
     if (const char* e = getenv("ABEA_CHAIN_CAP_DIV")) o.cap_div = (size_t)std::max(1, atoi(e));
+    o.packed = true; o.copy_engine = false;
+    if (const char* e = getenv("ABEA_CHAIN_TABLE_FORMAT")) o.packed = strcmp(e, "full") != 0;
+    if (const char* e = getenv("ABEA_CHAIN_TABLE_COPY")) o.copy_engine = strcmp(e, "engine") == 0;
     o.reads_max = std::max(o.reads_max, o.reads_min);
     return o;
 }
 
-int slot_make(abea_chain_slot** out) {
-    abea_chain_slot* s = new abea_chain_slot();
-    *out = s;
+int slot_make_parts(abea_chain_slot* s) {
     HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&s->dstream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&s->e_cnt, hipEventDisableTiming | hipEventBlockingSync));
     HIP_TRY(hipEventCreateWithFlags(&s->e_done, hipEventDisableTiming | hipEventBlockingSync));
+    HIP_TRY(hipEventCreateWithFlags(&s->e_tab, hipEventDisableTiming | hipEventBlockingSync));
+    HIP_TRY(hipEventCreateWithFlags(&s->e_cmp, hipEventDisableTiming));
     for (hipEvent_t* e : {&s->t0, &s->t1, &s->t2, &s->t3, &s->t4}) HIP_TRY(hipEventCreate(e));
+    return ABEA_OK;
+}
+
+/* a slot that could not be built completely is destroyed, never cached half-made (round-5 advisor finding) */
+int slot_make(abea_chain_slot** out) {
+    abea_chain_slot* s = new abea_chain_slot();
+    const int rc = slot_make_parts(s);
+    if (rc) { abea_chain_slot_destroy(s); *out = nullptr; return rc; }
+    *out = s;
     return ABEA_OK;
 }
 
@@ -125,19 +152,53 @@ struct chain_state {
     }
 };
 
-/* device + pinned bytes a read adds to a chunk's share of the arena (upper bound: the event count is only known to be <= cap) */
-size_t read_arena_bytes(int64_t ns, int32_t cap, int32_t L, int32_t K, bool align) {
-    const size_t EV_SEG = 512, SEG_BYTES_PER_LANE = EV_SEG * 2 + 48 * 4 + 12 * 4 + 2 * 8 + 4 * 4;
-    const size_t fixed = align_up((size_t)ns * 2, 16) + (size_t)L + 17 + (size_t)cap * 48 + 128;         /* signal, sequence, slots + compacted, index records */
-    const size_t det = ((size_t)ns + 1) * 24 + (size_t)cap * 8 + (size_t)std::max(K, 1) * 4 + ((size_t)ns / EV_SEG + 1) * SEG_BYTES_PER_LANE + 80;
-    size_t aln = 0;
-    if (align && K >= 1) {
-        plan_read r = make_plan(0, L, cap, 1);
-        r.K = K; r.n_bands = (int64_t)cap + K + 2;
-        aln = scratch_bytes(r) + (size_t)K * 9 + 80 + 512;                /* + map, count bytes, result scalars */
+/* What a chunk takes of its slot's share of the arena, accumulated read by read in the order the chunk is carved (descending sample
+ * count).  Round 5 charged every read ONE lane of detector scratch; the detector (abea_detect_events_on) interleaves its arrays over
+ * whole 64-lane waves, each as long as the wave's longest read, so a chunk that the arena limit closed at a read count that is not
+ * a multiple of 64 — or a single very long read — passed the carving and then failed the whole batch in stage D with "internal: the
+ * detector needs ..." (round-5 advisor finding).  Now the carving runs the detector's own arithmetic (abea_detect_scratch_bytes:
+ * same constants, same wave rule) and the layout of stage_detect / stage_align:
+ *   [signal | sequences][event slots][compacted tables][counts | scalings][index records][max(detector scratch, alignment scratch)] */
+struct chunk_charge {
+    bool align = false;
+    size_t n = 0, up = 0, seq = 0, slots = 0, det_waves = 0, aln = 0;
+    int32_t wave_cap = 0, wave_k = 0;                 /* maxima of the wave being filled */
+    size_t wave_len = 0;
+    static size_t wave_bytes(size_t len, int32_t cap, int32_t wk) {
+        const size_t EV_SEG = 512, EV_FIXCAP = 48, SEG_BYTES = 64 * (EV_SEG * 2 + EV_FIXCAP * 4 + 12 * 4 + 2 * 8 + 4 * 4);   /* abea_capi.cpp */
+        const size_t nseg = std::max<size_t>(1, (len - 1 + EV_SEG - 1) / EV_SEG);
+        return len * 64 * 24 + (size_t)cap * 64 * 8 + (size_t)wk * 64 * 4 + nseg * SEG_BYTES;
     }
-    return fixed + std::max(det, aln);                                     /* stage A re-uses the detector's scratch */
-}
+    /* total with the read added; commit = keep it */
+    size_t with(int64_t ns, int32_t cap, int32_t L, int32_t K, bool commit) {
+        chunk_charge t = *this;
+        t.up += (size_t)((ns + 7) / 8 * 8) * 2;
+        t.seq += align_up((size_t)L + 1, 16);
+        t.slots += (size_t)cap;
+        const int32_t wk = std::max(K, 1);
+        if (t.n % 64 == 0) {                          /* opens a wave: as long as this read (the longest of it), +1 for S[n] */
+            t.wave_len = (size_t)ns + 1; t.wave_cap = std::max(cap, 1); t.wave_k = wk;
+            t.det_waves += wave_bytes(t.wave_len, t.wave_cap, t.wave_k);
+        } else if (cap > t.wave_cap || wk > t.wave_k) {
+            t.det_waves -= wave_bytes(t.wave_len, t.wave_cap, t.wave_k);
+            t.wave_cap = std::max(t.wave_cap, cap); t.wave_k = std::max(t.wave_k, wk);
+            t.det_waves += wave_bytes(t.wave_len, t.wave_cap, t.wave_k);
+        }
+        if (align && K >= 1) {
+            plan_read r = make_plan(0, L, cap, 1);
+            r.K = K; r.n_bands = (int64_t)cap + K + 2;
+            t.aln += scratch_bytes(r) + 768 + (size_t)K * 9 + 80 + 512;      /* + per-array alignment, map, count bytes, result scalars */
+        }
+        t.n += 1;
+        const size_t N = t.n, n_waves = (N + 63) / 64;
+        const size_t det = N * (4 + 8 + 4 + 12 + 8 + 4 + 8 + 4 + 4 + 4) + n_waves * 56 + 8192 + 4096 + 8192 + t.det_waves + ((size_t)1 << 20);
+        const size_t head = align_up(align_up(t.up, 256) + t.seq, 256) + 2 * align_up(t.slots * sizeof(abea_event_t), 256) +
+                            align_up(align_up(N * 4, 256) + N * sizeof(abea_scalings_t), 256) + align_up(N * 24, 256);
+        const size_t aln_fixed = t.align ? align_up(N * sizeof(abea_read_desc), 256) + 16 * 256 + N * 80 + 4096 : 0;
+        if (commit) *this = t;
+        return head + std::max(det, t.aln + aln_fixed) + ((size_t)2 << 20);
+    }
+};
 
 /* ------------------------------------------------------------------ stage D: signal up, detector, counts down */
 int stage_detect(chain_state& S, abea_chain_slot& sl, const int32_t* ids, int32_t m, int chunk_no, uint8_t* arena, size_t arena_bytes) {
@@ -236,6 +297,7 @@ int stage_detect(chain_state& S, abea_chain_slot& sl, const int32_t* ids, int32_
     rc = sl.cnt.need(sl.cnt_bytes);
     if (rc) return rc;
     S.log("enqueue D", chunk_no, m, n_sig);
+    sl.busy = true;                                  /* from here on the slot's streams hold work of this call: every exit drains them */
     HIP_TRY(hipMemcpyAsync(sl.d_up, sl.up.p, sl.u_end, hipMemcpyHostToDevice, sl.stream));
     S.st.h2d_bytes += sl.u_end;
     abea_signal_batch sb;
@@ -260,7 +322,6 @@ int stage_detect(chain_state& S, abea_chain_slot& sl, const int32_t* ids, int32_
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(sl.e_cnt, sl.stream));
     S.st.d2h_bytes += sl.cnt_bytes;
-    sl.busy = true;
     return ABEA_OK;
 }
 
@@ -278,7 +339,8 @@ int stage_align(chain_state& S, abea_chain_slot& sl) {
     S.log("counts", sl.chunk_no, m);
     const int32_t* h_ne = (const int32_t*)sl.cnt.u8();
     const abea_scalings_t* h_sc = (const abea_scalings_t*)(sl.cnt.u8() + sl.o_sc_cnt);
-    size_t n_ev = 0;
+    size_t n_ev = 0, n_rec = 0;
+    sl.packed = S.opt.packed; sl.tab_on_dstream = S.opt.copy_engine;
     for (int32_t j = 0; j < m; ++j) {
         int32_t ne = std::max(h_ne[j], 0);
         if (ne > sl.cap[(size_t)j]) {                        /* overflowed its slots: redone after the pipeline, from the int16 staging */
@@ -290,12 +352,14 @@ int stage_align(chain_state& S, abea_chain_slot& sl) {
             ne = 0;
         }
         sl.ne[(size_t)j] = ne;
-        sl.out_ptr[(size_t)j] = (int64_t)n_ev; n_ev += (size_t)ne;
+        /* a packed table starts on a multiple of 4 records (the pack kernel stores 4 records = 48 bytes per thread) */
+        sl.out_ptr[(size_t)j] = (int64_t)n_rec; n_ev += (size_t)ne; n_rec += sl.packed ? ((size_t)ne + 3) / 4 * 4 : (size_t)ne;
         if (want_sc) sl.est[(size_t)j] = h_sc[j];
     }
-    sl.n_ev = n_ev;
+    sl.n_ev = n_ev; sl.n_rec = n_rec;
+    const size_t rec_bytes = sl.packed ? 12 : sizeof(abea_event_t);
     /* ---- compaction and the tables down: [src_ptr][dst_ptr][count] up, one kernel, one copy-out into pinned memory ---- */
-    int rc = sl.tab.need(align_up(n_ev * sizeof(abea_event_t), 16) + 256);
+    int rc = sl.tab.need(align_up(n_rec * rec_bytes, 16) + 256);
     if (rc) return rc;
     size_t need_desc = (size_t)m * 24 + 256;
     if (J->align) need_desc += align_up((size_t)m * sizeof(abea_read_desc), 256) + align_up((size_t)m * sizeof(abea_scalings_t), 256) + align_up((size_t)m * 4, 256);
@@ -306,13 +370,25 @@ int stage_align(chain_state& S, abea_chain_slot& sl) {
         int32_t* h_cnt = (int32_t*)(h_idx + 2 * (size_t)m);
         for (int32_t j = 0; j < m; ++j) { h_idx[j] = sl.ev_ptr[(size_t)j]; h_idx[m + j] = sl.out_ptr[(size_t)j]; h_cnt[j] = sl.ne[(size_t)j]; }
         HIP_TRY(hipMemcpyAsync(sl.d_idx, h_idx, (size_t)m * 20, hipMemcpyHostToDevice, sl.stream));
-        hipLaunchKernelGGL(abea_ev_compact_kernel, dim3((unsigned)m), dim3(256), 0, sl.stream, (int)m, (const abea_event_t*)sl.d_ev,
-                           (const int64_t*)sl.d_idx, (const int64_t*)(sl.d_idx + m), (const int32_t*)(sl.d_idx + 2 * (size_t)m), sl.d_evc);
-        const size_t n16 = (n_ev * sizeof(abea_event_t) + 15) / 16;
-        if (n16)
+        if (sl.packed)
+            hipLaunchKernelGGL(abea_ev_pack_kernel, dim3((unsigned)m), dim3(256), 0, sl.stream, (int)m, (const abea_event_t*)sl.d_ev,
+                               (const int64_t*)sl.d_idx, (const int64_t*)(sl.d_idx + m), (const int32_t*)(sl.d_idx + 2 * (size_t)m), (uint4*)sl.d_evc);
+        else
+            hipLaunchKernelGGL(abea_ev_compact_kernel, dim3((unsigned)m), dim3(256), 0, sl.stream, (int)m, (const abea_event_t*)sl.d_ev,
+                               (const int64_t*)sl.d_idx, (const int64_t*)(sl.d_idx + m), (const int32_t*)(sl.d_idx + 2 * (size_t)m), sl.d_evc);
+        const size_t n16 = (n_rec * rec_bytes + 15) / 16;
+        if (n16 && sl.tab_on_dstream) {
+            /* the copy engine on the slot's own device-to-host stream, behind the compaction only: the chunk's alignment kernels
+             * (process mode) run on sl.stream meanwhile and no CU spends its time storing across PCIe */
+            HIP_TRY(hipEventRecord(sl.e_cmp, sl.stream));
+            HIP_TRY(hipStreamWaitEvent(sl.dstream, sl.e_cmp, 0));
+            HIP_TRY(hipMemcpyAsync(sl.tab.p, sl.d_evc, n16 * 16, hipMemcpyDeviceToHost, sl.dstream));
+        } else if (n16) {
             hipLaunchKernelGGL(abea_copy_out_kernel, dim3((unsigned)std::min<size_t>(512, (n16 + 255) / 256)), dim3(256), 0, sl.stream,
                                (const uint4*)sl.d_evc, (uint4*)sl.tab.p, n16);
+        }
         HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(sl.e_tab, sl.tab_on_dstream ? sl.dstream : sl.stream));
         S.st.d2h_bytes += n16 * 16; S.st.h2d_bytes += (size_t)m * 20;
     }
     HIP_TRY(hipEventRecord(sl.t2, sl.stream));
@@ -331,7 +407,9 @@ int stage_align(chain_state& S, abea_chain_slot& sl) {
         if (r.run && r.n_bands > ABEA_MAX_BANDS)
             return abea_fail(ABEA_EINVAL, "read %d has %lld bands; the limit is %lld", sl.rd[(size_t)j], (long long)r.n_bands, (long long)ABEA_MAX_BANDS);
         sl.run[(size_t)j] = r.run ? 1 : 0;
-        if (r.run) ++S.st.n_reads_gpu; else ++S.st.n_reads_skipped;
+        /* a read whose table overflowed comes through here with E = 0 and is aligned later by redo_overflowed, which counts it */
+        const bool redone = sl.ne[(size_t)j] == 0 && h_ne[j] > sl.cap[(size_t)j];
+        if (r.run) ++S.st.n_reads_gpu; else if (!redone) ++S.st.n_reads_skipped;
         abea_read_desc& d = sl.descs[(size_t)j];
         plan_desc_layout(d, r, sl.est[(size_t)j], lay, S.st);
         d.read_off = sl.read_ptr[(size_t)j];
@@ -416,6 +494,22 @@ void not_aligned(const abea_chain_job* J, int32_t i, const abea_scalings_t& est)
     J->n_event_alignment[i] = 0;
 }
 
+/* event_t from the 12-byte records the tables crossed PCIe in: {uint32 start, float mean, float stdv}.  The events of a read tile
+ * [0, n_samples) (events.c:466-513: event j runs from peak j-1 to peak j, the first from 0, the last to n_samples), so the end of an
+ * event is the start of its successor IN DETECTION ORDER — the next record, or the previous one in an RNA table, which event_single
+ * reversed (f5c.c:711-719) — and length = (float)(end - start), the very expression of events.c:498. */
+void unpack_events(const uint32_t* rec, size_t ne, uint64_t n_samples, bool rna, abea_event_t* out) {
+    for (size_t p = 0; p < ne; ++p) {
+        const uint64_t start = rec[3 * p];
+        const uint64_t end = !rna ? (p + 1 < ne ? (uint64_t)rec[3 * (p + 1)] : n_samples) : (p > 0 ? (uint64_t)rec[3 * (p - 1)] : n_samples);
+        abea_event_t e;
+        e.start = start;
+        e.length = (float)(end - start);
+        memcpy(&e.mean, rec + 3 * p + 1, 4); memcpy(&e.stdv, rec + 3 * p + 2, 4);
+        out[p] = e;
+    }
+}
+
 /* ------------------------------------------------------------------ retire: the caller's db */
 int slot_finish(chain_state& S, abea_chain_slot& sl) {
     if (!sl.busy) return ABEA_OK;
@@ -425,11 +519,14 @@ int slot_finish(chain_state& S, abea_chain_slot& sl) {
     double t0 = abea_now_ms();
     S.log("wait", sl.chunk_no, sl.m);
     HIP_TRY(hipEventSynchronize(sl.e_done));
+    HIP_TRY(hipEventSynchronize(sl.e_tab));
     S.st.wait_ms += abea_now_ms() - t0;
     t0 = abea_now_ms();
     S.log("scatter", sl.chunk_no, sl.m, sl.n_ev);
     const int32_t m = sl.m;
     const abea_event_t* h_ev = (const abea_event_t*)sl.tab.p;
+    const uint32_t* h_rec = (const uint32_t*)sl.tab.p;                        /* packed form: 3 words per event */
+    const bool packed = sl.packed, rna = J->rna != 0;
     /* the result block exists in process mode only (event_db alone reads none of it) */
     const uint8_t* const dnb = J->align ? sl.dn.u8() : nullptr;
     auto at = [&](size_t off) { return dnb ? dnb + off : nullptr; };
@@ -451,7 +548,8 @@ int slot_finish(chain_state& S, abea_chain_slot& sl) {
             /* getevents() returns a malloc()ed table (events.c:562-582); released by the caller like free_db_tmp does */
             abea_event_t* t = (abea_event_t*)malloc(std::max<size_t>(ne, 1) * sizeof(abea_event_t));
             if (!t) { S.oom.store(true); continue; }
-            memcpy(t, h_ev + sl.out_ptr[(size_t)j], ne * sizeof(abea_event_t));
+            if (!packed) memcpy(t, h_ev + sl.out_ptr[(size_t)j], ne * sizeof(abea_event_t));
+            else unpack_events(h_rec + (size_t)sl.out_ptr[(size_t)j] * 3, ne, (uint64_t)sl.ns32[(size_t)j], rna, t);
             J->events[i] = t; J->n_events[i] = ne;
             if (J->scalings_estimated && want_sc) J->scalings_estimated[i] = sl.est[(size_t)j];
             if (!J->align) { if (J->scalings) J->scalings[i] = sl.est[(size_t)j]; continue; }
@@ -475,7 +573,7 @@ int slot_finish(chain_state& S, abea_chain_slot& sl) {
                 J->base_to_event_map[i] = map;
             }
             abea_scalings_t o = sc[j];
-            if (var64[j] >= 0.0) o.log_var = (float)log(var64[j]);                    /* align.c:758-760 */
+            abea_apply_log_var(o, var64[j]);                                          /* align.c:758-760 */
             J->scalings[i] = o;
             J->events_per_base[i] = epb[j];
             J->read_stat_flag[i] = flag[j];
@@ -510,7 +608,7 @@ struct chain_guard {
     ~chain_guard() {
         for (int q = 0; q < n_slots && q < (int)c->chain_slots.size(); ++q) {
             abea_chain_slot* s = c->chain_slots[(size_t)q];
-            if (s && s->busy) { hipStreamSynchronize(s->stream); s->busy = false; }
+            if (s && s->busy) { hipStreamSynchronize(s->stream); hipStreamSynchronize(s->dstream); s->busy = false; }
         }
     }
 };
@@ -638,6 +736,7 @@ int abea_chain_run(abea_ctx* c, const abea_chain_job* J, const int32_t* mine, in
             if (J->align) {                                   /* align_single's first guard (f5c.c:812, 826-828) + scaling_single (f5c.c:786-794) */
                 abea_scalings_t z; memset(&z, 0, sizeof z);
                 not_aligned(J, i, z);
+                if (J->scalings_estimated) J->scalings_estimated[i] = z;
                 ++S.st.n_reads_skipped;
             }
             continue;
@@ -654,7 +753,7 @@ int abea_chain_run(abea_ctx* c, const abea_chain_job* J, const int32_t* mine, in
         if (c->chain_slots.size() < (size_t)ABEA_MAX_SLOTS) c->chain_slots.resize((size_t)ABEA_MAX_SLOTS, nullptr);
     }
     for (int q = 0; q < n_slots; ++q) {
-        if (!c->chain_slots[(size_t)q]) { abea_chain_slot* s = nullptr; const int rc = slot_make(&s); c->chain_slots[(size_t)q] = s; if (rc) return rc; }
+        if (!c->chain_slots[(size_t)q]) { abea_chain_slot* s = nullptr; const int rc = slot_make(&s); if (rc) return rc; c->chain_slots[(size_t)q] = s; }
         c->chain_slots[(size_t)q]->busy = false;
     }
     chain_guard guard{c, n_slots};
@@ -671,19 +770,20 @@ int abea_chain_run(abea_ctx* c, const abea_chain_job* J, const int32_t* mine, in
         const int ramp = chunk_no == 0 ? 4 : chunk_no == 1 ? 2 : 1;
         const size_t want_s = S.opt.chunk_samples / (size_t)ramp;
         const int32_t want_r = std::max(1, S.opt.reads_min / ramp);
-        size_t bytes = (size_t)4 << 20, samples = 0, end = pos;
+        size_t samples = 0, end = pos;
+        chunk_charge charge; charge.align = J->align;
         while (end < todo.size()) {
             const int32_t i = todo[end];
             const int64_t ns = J->n_samples[i];
             const int32_t L = want_sc ? J->read_len[i] : (int32_t)c->k;
             const int32_t cap = (int32_t)std::min<size_t>((size_t)ns / S.opt.cap_div + 16, INT32_MAX / 2);
-            /* the interleaved scratch of a wave is as long as its longest read: charge every read the chunk's longest */
-            const size_t need = read_arena_bytes(std::max<int64_t>(ns, end == pos ? ns : J->n_samples[todo[pos]]), cap, L, L - (int32_t)c->k + 1, J->align);
-            if (bytes + need > slot_arena) {
+            if (charge.with(ns, cap, L, L - (int32_t)c->k + 1, false) > slot_arena) {
                 if (end > pos) break;
-                return abea_fail(ABEA_ENOMEM, "read %d (%" PRId64 " samples) does not fit a %zu-byte share of the arena", i, ns, slot_arena);
+                return abea_fail(ABEA_ENOMEM, "read %d (%" PRId64 " samples) does not fit a %zu-byte share of the arena: the detector's scratch is "
+                                 "laid out in 64-lane waves as long as their longest read (%zu bytes for this one)", i, ns, slot_arena,
+                                 chunk_charge::wave_bytes((size_t)ns + 1, cap, std::max(L - (int32_t)c->k + 1, 1)));
             }
-            bytes += need; samples += (size_t)ns; ++end;
+            charge.with(ns, cap, L, L - (int32_t)c->k + 1, true); samples += (size_t)ns; ++end;
             const int32_t cnt = (int32_t)(end - pos);
             if ((cnt >= want_r && samples >= want_s) || cnt >= S.opt.reads_max) break;
         }

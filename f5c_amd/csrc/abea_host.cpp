@@ -922,7 +922,7 @@ static int slot_retire(host_run_state& S, abea_host_slot& sl) {
                     expand_codes_to_map(codes + descs[j].code_off, np, descs[j].n_kmers - 1, diag[j].best_event, map);
                 if (H->scalings_out) {
                     abea_scalings_t o = sc[j];
-                    if (var64[j] >= 0.0) o.log_var = (float)log(var64[j]);      /* align.c:758-760 (CACHED_LOG): double log, glibc's */
+                    abea_apply_log_var(o, var64[j]);                             /* align.c:758-760 (CACHED_LOG): double log, glibc's */
                     H->scalings_out[i] = o;
                 }
                 if (H->events_per_base) H->events_per_base[i] = epb[j];

@@ -169,6 +169,14 @@ static inline void plan_desc(abea_read_desc& d, const plan_read& r, const abea_s
 
 int ensure_pinned(void** p, size_t* cap, size_t need);
 
+/* scaling_single's last line for a recalibrated read (align.c:758-760, CACHED_LOG): log_var = log(var) in double, glibc's, on the
+ * host.  The kernel hands var down as a double, -1.0 = "not recalibrated" (log_var keeps its input value); a NaN var (NaN sum / n_M)
+ * is a recalibrated read whose log_var is log(NaN) = NaN in the reference too — `>= 0` would have left the input value there
+ * (round-5 advisor finding).  One helper for both retire paths (abea_host.cpp, abea_chain.cpp). */
+static inline void abea_apply_log_var(abea_scalings_t& o, double var_f64) {
+    if (!(var_f64 < 0.0)) o.log_var = (float)log(var_f64);
+}
+
 /* length of the union of [begin, end) intervals (the chunks' kernel spans on the GPU clock) */
 static inline double interval_union_ms(std::vector<std::pair<float, float>>& iv) {
     std::sort(iv.begin(), iv.end());

@@ -1305,6 +1305,34 @@ void abea_ev_compact_kernel(int n_reads, const abea_event_t* __restrict__ src, c
     for (int64_t i = threadIdx.x; i < words; i += blockDim.x) d[i] = s[i];
 }
 
+/* The same compaction into the 12-byte form the tables cross PCIe in (round 6): {uint32 start, float mean, float stdv}.  The events
+ * of a read tile its samples (events.c:466-513: start(j+1) = start(j) + the integer length(j), start(0) = 0, the last one ends at
+ * n_samples), so `start` of the neighbour and n_samples give every (uint64 start, float length) back on the host — half the bytes
+ * of event_t over the link.  Block = read, a thread packs 4 consecutive events into three 16-byte stores; dst_ptr counts records and
+ * is a multiple of 4 per read. */
+extern "C" __global__ __launch_bounds__(256)
+void abea_ev_pack_kernel(int n_reads, const abea_event_t* __restrict__ src, const int64_t* __restrict__ src_ptr,
+                         const int64_t* __restrict__ dst_ptr, const int32_t* __restrict__ n_events, uint4* __restrict__ dst) {
+    const int r = blockIdx.x;
+    if (r >= n_reads) return;
+    const abea_event_t* __restrict__ s = src + src_ptr[r];
+    uint4* __restrict__ d = dst + dst_ptr[r] / 4 * 3;
+    const int ne = max(n_events[r], 0);
+    for (int g = threadIdx.x; g * 4 < ne; g += blockDim.x) {
+        uint32_t w[12];
+        #pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int j = g * 4 + i;
+            abea_event_t e;
+            if (j < ne) e = s[j]; else { e.start = 0; e.length = 0.f; e.mean = 0.f; e.stdv = 0.f; }
+            w[3 * i] = (uint32_t)e.start; w[3 * i + 1] = __float_as_uint(e.mean); w[3 * i + 2] = __float_as_uint(e.stdv);
+        }
+        d[(size_t)g * 3] = make_uint4(w[0], w[1], w[2], w[3]);
+        d[(size_t)g * 3 + 1] = make_uint4(w[4], w[5], w[6], w[7]);
+        d[(size_t)g * 3 + 2] = make_uint4(w[8], w[9], w[10], w[11]);
+    }
+}
+
 /* pass 4b: model level of every k-mer of every read (align.c:75-78), parallel; interleaved like the other scratch */
 extern "C" __global__ __launch_bounds__(256)
 void abea_ev_kmer_kernel(int n_reads, const int32_t* __restrict__ order, const char* __restrict__ reads,

@@ -392,6 +392,15 @@ int abea_host_plan_threads(int32_t usable_cpus, const char* allowed_cpulist, int
                            int32_t n_nodes, const char* const* node_cpulist, int32_t* threads_per_device, char* bind_cpulists,
                            size_t cap_each);
 
+/* What the host<->device link of the context's GPU delivers, measured the way the pipelines use it (pinned host memory; `bytes`
+ * per transfer, 0 = 256 MiB; `reps` transfers per measurement, 0 = 4).  GB/s (1e9 bytes) into out[0..7):
+ *   [0] host->device, hipMemcpyAsync            [1] device->host, hipMemcpyAsync        [2] device->host, abea_copy_out_kernel
+ *   [3], [4] host->device (copy engine) and device->host (kernel) while both run at once — what the chunk pipelines do
+ *   [5], [6] the same with both directions on the copy engines.
+ * The raw-signal entries move 2 B per sample up and 24 B per event down (event_db, src/f5c.c:682-734): bench.py sets their
+ * measured rates against these ceilings.  Diagnostic; nothing in the library depends on it. */
+int abea_link_probe(abea_ctx* ctx, uint64_t bytes, int32_t reps, double* out, int32_t n_out);
+
 /* Library / device introspection: "gfx950", CU count; used by tests to assert the native path ran. */
 int abea_device_info(abea_ctx* ctx, char* arch, size_t arch_len, int32_t* n_cu, uint64_t* arena_bytes);
 

@@ -63,6 +63,17 @@ def main(prefix):
              "code_sha256": code_sha(), "code_sha256_of": list(KERNEL_SOURCES[:2]) + [KERNEL_SOURCES[2] + " (up to the event-detection section)"],
              "kernel_ms_in_each_pass": kms, "passes": src,
              "sq_counters_per_launch": {k: v for k, v in sorted(c.items()) if k.startswith("SQ_") or k.startswith("GRBM")}}
+        # abea_pre_kernel of the same passes (the device-resident leg launches it once per step, in front of the alignment)
+        pc, psrc, pms = {}, {}, {}
+        for p in ("fetch", "write"):
+            path = f"{prefix}pmc_{p}{tag}_counter_collection.csv"
+            v, ms, n = avg(path, "abea_pre_kernel")
+            pc.update(v); pms[p] = round(ms, 3) if ms else None; psrc[p] = f"{path} ({n} launches)"
+        if "FETCH_SIZE" in pc and "WRITE_SIZE" in pc:
+            phbm = pc["FETCH_SIZE"] * 1024 * 2 + pc["WRITE_SIZE"] * 1024
+            e["pre_kernel"] = {"kernel": "abea_pre_kernel", "FETCH_SIZE_KB": pc["FETCH_SIZE"], "WRITE_SIZE_KB": pc["WRITE_SIZE"],
+                               "fetch_bytes_per_event_x2": pc["FETCH_SIZE"] * 2048 / events, "write_bytes_per_event": pc["WRITE_SIZE"] * 1024 / events,
+                               "hbm_bytes_per_launch": phbm, "hbm_bytes_per_event": phbm / events, "kernel_ms_in_each_pass": pms, "passes": psrc}
         if "SQ_ACTIVE_INST_VALU" in c and "GRBM_GUI_ACTIVE" in c:
             e["valu_busy"] = c["SQ_ACTIVE_INST_VALU"] * 4 / (N_SIMD * c["GRBM_GUI_ACTIVE"] / N_XCD)
             e["valu_busy_formula"] = "SQ_ACTIVE_INST_VALU*4 / (1024 SIMDs * GRBM_GUI_ACTIVE/8 XCDs), measured on this config"

@@ -22,9 +22,25 @@ def _have_gpu():
         return False
 
 
+# Run order (round-5 verdict item 1b): under `pytest -x` a failing INFRASTRUCTURE test (a subprocess of bench.py, torchrun) must
+# never sit in front of a parity test again.  Files run in this order, everything comparing the HIP path with the oracle or the
+# reference's printed goldens first (configs[0] = the ecoli reads at the very front), tests that launch bench.py last.
+PARITY_FIRST = ["test_oracle_ecoli", "test_gpu_parity", "test_hmm_pin", "test_process_chain", "test_rna_events", "test_chain_pipeline",
+                "test_hmm_gpu", "test_fuzz_gpu", "test_full_size", "test_host_plan_and_async", "test_host_pipeline"]
+INFRA_LAST = ("test_bench_", "test_zz_")       # subprocess-of-bench.py / torch.distributed.run tests, whatever file they live in
+
+
+def _run_order(item):
+    mod = os.path.splitext(os.path.basename(str(item.fspath)))[0]
+    infra = item.name.startswith(INFRA_LAST) or mod.startswith("test_zz_")
+    return (1 if infra else 0, PARITY_FIRST.index(mod) if mod in PARITY_FIRST else len(PARITY_FIRST))
+
+
 def pytest_collection_modifyitems(config, items):
-    """Every `gpu` test is skipped before any batch is generated or context built when no device is present (a plain
-    `pytest tests` on a CPU box used to build the 60 GB full-size batch and die; round-2 advisor finding)."""
+    """Parity tests first, infrastructure last (stable sort: the order inside a file is kept).  Every `gpu` test is skipped before
+    any batch is generated or context built when no device is present (a plain `pytest tests` on a CPU box used to build the 60 GB
+    full-size batch and die; round-2 advisor finding)."""
+    items.sort(key=_run_order)
     if _have_gpu():
         return
     skip = pytest.mark.skip(reason="no GPU visible (run with -m gpu on an MI355X box)")

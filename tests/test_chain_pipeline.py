@@ -146,3 +146,74 @@ def test_process_chain_on_a_two_device_context(orc, r9, monkeypatch):
         assert st["n_devices"] == 2 and st["n_sub_batches"] >= 4
         assert _compare(c2, orc, model, k, b, v, sig, sp, ns, sc, range(0, 50, 3), True) >= 12
         c2.free_view(v)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fmt,mover", [("full", "kernel"), ("packed", "kernel"), ("full", "engine"), ("packed", "engine")])
+def test_tables_cross_pcie_in_either_form_by_either_mover(ctx, orc, r9, monkeypatch, fmt, mover):
+    """Round 6: the event tables come down as 24-byte event_t or as 12-byte {start, mean, stdv} records from which the retire loop
+    rebuilds (start, length) — the events of a read tile its samples, events.c:466-513 — and by abea_copy_out_kernel or by the copy
+    engine on the slot's own stream.  Every combination gives the oracle's tables and the oracle's chain, through both entries."""
+    k, model = r9
+    b, sig, sp, ns, sc = _batch_and_signals(r9, 48, 31337, 1700)
+    monkeypatch.setenv("ABEA_CHAIN_SLOTS", "3")
+    monkeypatch.setenv("ABEA_CHAIN_CHUNK_SAMPLES", str(300_000))
+    monkeypatch.setenv("ABEA_CHAIN_CHUNK_READS", "5")
+    monkeypatch.setenv("ABEA_CHAIN_TABLE_FORMAT", fmt)
+    monkeypatch.setenv("ABEA_CHAIN_TABLE_COPY", mover)
+    v = ctx.signal_view(sig, sp, ns, sc, batch=b, want_pairs=True)
+    ctx.process_view(v)
+    assert ctx.stats()["n_sub_batches"] >= 5
+    assert _compare(ctx, orc, model, k, b, v, sig, sp, ns, sc, range(48), True) >= 40
+    d2h_process = ctx.stats()["d2h_bytes"]
+    ctx.free_view(v)
+    ve = ctx.signal_view(sig, sp, ns, sc)                                    # event_db alone, no sequences
+    ctx.events_view(ve)
+    n_ev = int(ve["n_events"].sum())
+    for j in range(0, 48, 5):
+        o_ev, _ = orc.getevents(sig[sp[j]:sp[j] + ns[j]].astype(np.int16), *[float(x) for x in sc[j]])
+        g = ctx.view_events(ve, j)
+        assert len(g) == len(o_ev) and all((g[f] == o_ev[f]).all() for f in ("start", "length", "mean", "stdv")), j
+    d2h = ctx.stats()["d2h_bytes"]
+    ctx.free_view(ve)
+    per_event = 12 if fmt == "packed" else 24
+    assert per_event * n_ev <= d2h <= per_event * n_ev + 48 * 64 * 48 and d2h_process > d2h     # the tables dominate what comes down
+
+
+@pytest.mark.gpu
+def test_arena_limit_closes_chunks_and_whole_waves_are_charged(orc, r9, monkeypatch):
+    """Round-5 advisor finding: the detector lays its scratch out in 64-lane waves as long as their longest read, the chunk carving
+    charged one lane per read; a chunk the ARENA LIMIT closed at a read count that is not a multiple of 64 then failed the whole batch
+    with "internal: the detector needs ...".  A small arena, equal reads, chunk limits far away: the arena closes every chunk, the
+    carving charges whole waves, and the call succeeds with the oracle's tables; a read whose single wave cannot fit is refused
+    up front with the reason, not half-way with an internal error."""
+    from f5c_amd import abea
+    k, model = r9
+    b, sig, sp, ns, sc = _batch_and_signals(r9, 150, 5150, 3000)
+    monkeypatch.setenv("ABEA_CHAIN_SLOTS", "2")
+    monkeypatch.setenv("ABEA_CHAIN_CHUNK_SAMPLES", str(1 << 40))
+    monkeypatch.setenv("ABEA_CHAIN_CHUNK_READS", "100000")
+    monkeypatch.setenv("ABEA_CHAIN_CHUNK_READS_MAX", "100000")
+    n_max = int(ns.max())
+    wave = (n_max + 1) * 64 * 24                                             # S, Q, two t-statistics of one wave
+    # a slot's share holds two waves and a bit; the per-lane charge of round 5 would have packed ~2.6 x 64 reads into a chunk (three
+    # waves of scratch) and failed in stage D
+    with abea.AbeaContext(model, k, max_arena_bytes=int(2 * 2.6 * wave)) as c1:
+        for mode in ("process", "events"):
+            v = c1.signal_view(sig, sp, ns, sc, batch=b, want_pairs=(mode == "process"))
+            (c1.process_view if mode == "process" else c1.events_view)(v)
+            st = c1.stats()
+            assert 2 <= st["n_sub_batches"] <= 4, st["n_sub_batches"]         # closed by the arena: the other limits are out of reach
+            if mode == "process":
+                assert _compare(c1, orc, model, k, b, v, sig, sp, ns, sc, range(0, 150, 7), True) >= 18
+            else:
+                for j in range(0, 150, 11):
+                    o_ev, _ = orc.getevents(sig[sp[j]:sp[j] + ns[j]].astype(np.int16), *[float(x) for x in sc[j]])
+                    g = c1.view_events(v, j)
+                    assert len(g) == len(o_ev) and all((g[f] == o_ev[f]).all() for f in ("start", "length", "mean", "stdv")), j
+            c1.free_view(v)
+    with abea.AbeaContext(model, k, max_arena_bytes=int(2 * 0.8 * wave)) as c2:     # not even one wave of the longest read
+        v = c2.signal_view(sig, sp, ns, sc, batch=b)
+        with pytest.raises(abea.AbeaError, match="does not fit a .* share of the arena"):
+            c2.events_view(v)
+        assert (v["ev_pp"] == 0).all()

@@ -15,7 +15,8 @@ from oracle import orc
 def run(budget=60.0, seed=1, ctx=None, max_batches=None, host_entry=False):
     """Fuzz for `budget` seconds (or max_batches); returns (batches, signals, events, seconds).  Raises on any mismatch.
     host_entry: the same signals as FLOAT ADC counts through abea_events_batch_host — the chunk pipeline of abea_chain.cpp — with
-    random chunk sizes, slot counts and first-guess table capacities (n/1 .. n/64 + 16 events: overflowing tables take the redo path)."""
+    random chunk sizes, slot counts, first-guess table capacities (n/1 .. n/64 + 16 events: overflowing tables take the redo path) and both
+    forms / movers of the tables' trip down (ABEA_CHAIN_TABLE_FORMAT, ABEA_CHAIN_TABLE_COPY)."""
     k, model = load_model_f32(os.path.join(ROOT, "tests/golden/r9.4_450bps.6mer.f32"))
     rng = np.random.default_rng(seed)
     own = ctx is None
@@ -58,6 +59,8 @@ def run(budget=60.0, seed=1, ctx=None, max_batches=None, host_entry=False):
             os.environ["ABEA_CHAIN_SLOTS"] = str(int(rng.integers(1, 5)))
             os.environ["ABEA_CHAIN_CHUNK_SAMPLES"] = str(int(rng.choice([2000, 60000, 1 << 20])))
             os.environ["ABEA_CHAIN_CHUNK_READS"] = str(int(rng.integers(1, 9)))
+            os.environ["ABEA_CHAIN_TABLE_FORMAT"] = str(rng.choice(["full", "packed"]))      # 24-byte event_t or 12-byte records over PCIe
+            os.environ["ABEA_CHAIN_TABLE_COPY"] = str(rng.choice(["kernel", "engine"]))      # copy-out kernel or copy engine
             nsamp = np.array([len(x) for x in sigs], dtype=np.int64)
             pad = (nsamp + 7) // 8 * 8
             sp = np.concatenate([[0], np.cumsum(pad)[:-1]]).astype(np.int64)

@@ -1,11 +1,12 @@
 #!/bin/bash
-# Round-5 GPU calls, one parameterised script (replaces the per-call tools/r04_call_*.sh one-offs):
+# GPU calls, one parameterised script:
+#   bash tools/gpurun.sh <timeout-s> <stage> [tag]          (from the build container: stamps the commit, then calls gpurun)
 #   gpurun --timeout T -- 'bash tools/gpu_call.sh <stage> [tag]'
 # Every step runs under its own `timeout -k 10` (TERM to the process group, KILL 10 s later: a hung kernel or profiler
-# must not hold the box).  Output: gpurun_out/<tag>/ ; what is to be judged is copied into profiles/r05/ afterwards.
+# must not hold the box).  Output: gpurun_out/<tag>/ ; what is to be judged is copied into profiles/r06/ afterwards.
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
-STAGE=${1:-sweep}; TAG=${2:-r05_$STAGE}
+STAGE=${1:-tests}; TAG=${2:-r06_$STAGE}
 O=gpurun_out/$TAG; mkdir -p $O
 step() {   # name, timeout, command ...
   local name=$1 to=$2; shift 2
@@ -13,67 +14,37 @@ step() {   # name, timeout, command ...
   timeout -k 10 $to "$@" > $O/$name.log 2>&1
   echo "$name rc=$? $(( $(date +%s) - t0 )) s" >> $O/steps.txt
 }
+stamp() {  # which tree ran: the commit tools/gpurun.sh stamped (the snapshot carries no .git) + digests of what the suite exercises
+  { echo "tree: $(cat .gpurun_head 2>/dev/null || echo 'no .gpurun_head (not launched through tools/gpurun.sh)')"
+    echo "sha256 of the product + test sources as they ran:"
+    find f5c_amd include tests bench.py __graft_entry__.py oracle -type f \( -name '*.py' -o -name '*.cpp' -o -name '*.hip' -o -name '*.h' -o -name '*.inc' -o -name '*.c' \) \
+      | grep -v __pycache__ | sort | xargs sha256sum | sha256sum | cut -c1-64
+    sha256sum f5c_amd/libabea_hip.so oracle/libabea_oracle.so 2>/dev/null; } > $1
+}
 case $STAGE in
-  sweep)      # host-entry settings on ONE generated batch + the flatten loop alone + the changed host code against the oracle
-    step t_host 400 python -m pytest tests/test_host_pipeline.py -m gpu -x -q -k "not torchrun and not two_ranks"
-    tail -3 $O/t_host.log
-    step sweep 700 python tools/host_sweep.py --out $O ${SWEEP_ARGS:-}
-    grep -v "^first-touch\|^interleave" $O/sweep.log | tail -40
+  chain)      # what bounds the raw-signal chain (round-5 verdict item 2): link ceilings, table form x mover A/B, GPU-clock timeline, kernel trace
+    step gen 300 python tools/chain_trace.py ${CHAIN_READS:-10000} /tmp/ct
+    step chain_ab 900 python tools/chain_trace.py ${CHAIN_READS:-10000} /tmp/ct ${CHAIN_MODES:-full:kernel:trace packed:kernel:trace full:engine packed:engine:trace}
+    grep -v "^\[abea\|^----" $O/chain_ab.log | tail -40
+    step chain_kt 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/chain_kt -o chain -- python tools/chain_trace.py ${CHAIN_READS:-10000} /tmp/ct ${CHAIN_PROFILE_MODE:-packed:kernel}
+    find $O/chain_kt -name "*kernel_stats.csv" | head -2
     ;;
-  hwq)        # the same sweep under GPU_MAX_HW_QUEUES = 8 / 16 / 24 (read by the HIP runtime at initialisation: one process each)
-    step t_changed 400 python -m pytest tests/test_host_pipeline.py tests/test_process_chain.py tests/test_rna_events.py -m gpu -x -q -k "not torchrun and not two_ranks"
-    tail -3 $O/t_changed.log
-    for q in ${HWQS:-8 16 24}; do
-      GPU_MAX_HW_QUEUES=$q step sweep_q$q 400 python tools/host_sweep.py --out $O/q$q --no-flatten-probe --steps 3 --only ${ONLY:-base,slots16,chunk24M_slots16,chunk96M,chunk96M_slots16,rmin512,rmin512_slots16,fused_base,fused_slots16,fused_rmin512_slots16,base_again}
-      grep '"name"' $O/sweep_q$q.log | python3 -c "
-import sys, json
-for ln in sys.stdin:
-    r = json.loads(ln); print('q$q %-24s %7.1f ms  flat %6.1f unfl %5.1f wait %6.1f plan %4.1f  fill_sum %7.1f' % (r['name'], r['ms_per_step'], r['flatten_ms'], r['unflatten_ms'], r['wait_ms'], r['plan_ms'], r['fill_ms']))"
-    done
+  n2prof)     # the detector alone (device entry, 2048 reads): kernel trace + HBM counters of its kernels (separate passes)
+    step n2_kt 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/n2 -o n2 -- python tools/n2_profile.py 2048
+    grep "parameters" $O/n2_kt.log
+    step n2_fetch 300 rocprofv3 --kernel-trace --output-format csv -d $O/n2_fetch -o n2 --pmc FETCH_SIZE -- python tools/n2_profile.py 2048
+    step n2_write 300 rocprofv3 --kernel-trace --output-format csv -d $O/n2_write -o n2 --pmc WRITE_SIZE -- python tools/n2_profile.py 2048
+    find $O -name "*.csv" | head
     ;;
-  chain)      # round-5 rewrite of the raw-signal entries + the ramp launch order + where GPU_MAX_HW_QUEUES is set
-    step t_changed 500 python -m pytest tests/test_host_pipeline.py tests/test_process_chain.py tests/test_rna_events.py tests/test_fuzz_gpu.py -m gpu -x -q -k "not torchrun and not two_ranks" --durations=5
-    tail -9 $O/t_changed.log
-    step bench10k 400 python bench.py --config r9_10k_8kb --steps 3 --warmup 1
-    tail -c 2500 $O/bench10k.log
-    step sweep 400 python tools/host_sweep.py --out $O/py --no-flatten-probe --steps 3 --only base,lpt,fused_base,fused_lpt,base_again
-    ABEA_KEEP_HW_QUEUES=1 step sweep_lib 400 python tools/host_sweep.py --out $O/lib --no-flatten-probe --steps 3 --only base
-    for f in sweep sweep_lib; do grep '"name"\|GPU_MAX' $O/$f.log | python3 -c "
-import sys, json
-for ln in sys.stdin:
-    r = json.loads(ln)
-    if 'name' not in r: print('$f', r); continue
-    print('$f %-12s %7.1f ms  flat %6.1f unfl %5.1f wait %6.1f plan %4.1f  gpu_busy %7.1f' % (r['name'], r['ms_per_step'], r['flatten_ms'], r['unflatten_ms'], r['wait_ms'], r['plan_ms'], r.get('gpu_busy_ms', 0)))"; done
-    ;;
-  exp)        # round-5 experiments: where GPU_MAX_HW_QUEUES takes effect for a C++ caller, the method-of-moments kernel, the Markstein quotient
-    step t_n2 500 python -m pytest tests/test_rna_events.py tests/test_process_chain.py tests/test_oracle_ecoli.py tests/test_fuzz_gpu.py -m gpu -x -q -k "not alignment_and_scaling" --durations=5
-    tail -8 $O/t_n2.log
-    step ab_markstein 300 python tools/ab_quick.py ship=f5c_amd/libabea_hip.so markstein=build/libabea_markstein.so ship2=f5c_amd/libabea_hip.so markstein2=build/libabea_markstein.so --config r9_10k_8kb --launches 6
-    grep "kernel ms" $O/ab_markstein.log
-    step n2prof 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/n2 -o n2 -- python tools/n2_profile.py 2048
-    grep "parameters" $O/n2prof.log; find $O/n2 -name "*kernel_stats.csv" | head -2
-    g++ -std=c++11 -O2 tests/shim_driver.cpp -o /tmp/shim_driver -Lf5c_amd -labea_hip -Wl,-rpath,$GRAFT_REPO_ROOT/f5c_amd
-    step dump 200 python tools/probe/dump_batch.py r9_10k_8kb /tmp/b10k.bin
-    for q in lib 4 16; do
-      if [ $q = lib ]; then unset GPU_MAX_HW_QUEUES; else export GPU_MAX_HW_QUEUES=$q; fi
-      SHIM_REPS=6 SHIM_NOPRINT=1 timeout -k 10 200 /tmp/shim_driver /tmp/b10k.bin /dev/null 2> $O/shim_q$q.log
-      echo "C++ caller, GPU_MAX_HW_QUEUES=$q: $(grep wall $O/shim_q$q.log | awk '{print $4}' | tr '\n' ' ')"
-    done | tee $O/hw_queues_cpp_caller.txt
-    unset GPU_MAX_HW_QUEUES
-    ;;
-  exp2)       # the two-wave-per-read model of a band (tools/ubench/two_wave_band.hip) + the method-of-moments kernel again
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -w tools/ubench/two_wave_band.hip -o /tmp/two_wave_band && step two_wave 120 /tmp/two_wave_band
-    cat $O/two_wave.log
-    step t_n2 300 python -m pytest tests/test_rna_events.py tests/test_process_chain.py tests/test_oracle_ecoli.py -m gpu -x -q
-    tail -3 $O/t_n2.log
-    step n2prof 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/n2 -o n2 -- python tools/n2_profile.py 2048
-    grep "parameters" $O/n2prof.log; grep "scalings\|copyBuffer" $O/n2/n2_kernel_stats.csv | cut -d, -f1-6
-    ;;
-  tests)      # the whole GPU suite + the bench line of the build that ships
-    step gpu_tests 900 python -m pytest tests -m gpu -x -q --durations=10
-    tail -16 $O/gpu_tests.log
-    t0=$(date +%s); timeout -k 10 600 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$? $(( $(date +%s) - t0 )) s" >> $O/steps.txt
-    python tools/bench_summary.py $O/bench.json
+  tests)      # the whole GPU suite at the stamped commit (the round's gate: parity tests first, infrastructure last — tests/conftest.py)
+    stamp $O/gpu_tests_tree.txt; cat $O/gpu_tests_tree.txt
+    step gpu_tests ${SUITE_TIMEOUT:-1500} python -m pytest tests -m gpu -x -q --durations=12 -p no:cacheprovider
+    cat $O/gpu_tests_tree.txt $O/gpu_tests.log > $O/gpu_tests_full_suite.log
+    tail -22 $O/gpu_tests.log
+    if [ -z "$NO_BENCH" ]; then
+      t0=$(date +%s); timeout -k 10 600 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$? $(( $(date +%s) - t0 )) s" >> $O/steps.txt
+      python tools/bench_summary.py $O/bench.json
+    fi
     ;;
   bench)      # the bench line alone (the driver's command)
     t0=$(date +%s); timeout -k 10 600 python bench.py ${BENCH_ARGS:-} > $O/bench.json 2> $O/bench.err; echo "bench rc=$? $(( $(date +%s) - t0 )) s" >> $O/steps.txt
@@ -112,12 +83,6 @@ for ln in sys.stdin:
     fi
     find $O -name "*kernel_trace.csv" -size +20M -delete
     find $O -name "*.csv" | head -40
-    ;;
-  phase4)     # A/B of the fused scaling_single phase (device-resident launches, one process) + the GPU suite without the full-size configs
-    step ab_phase4 400 python tools/ab_quick.py r04before=build/libabea_r05_before_phase4_prefetch.so r04after=f5c_amd/libabea_hip.so r04before2=build/libabea_r05_before_phase4_prefetch.so r04after2=f5c_amd/libabea_hip.so --config r9_10k_8kb --launches 4 --scaling-launches 5
-    grep "kernel ms" $O/ab_phase4.log
-    step gpu_tests 600 python -m pytest tests -m gpu -x -q --durations=6 --deselect tests/test_full_size.py
-    tail -12 $O/gpu_tests.log
     ;;
   fusedtrace) # the fused align + scaling_single HOST call under rocprofv3: kernel timeline (8 chunks in flight) and one SQ pass
     step ft_gen 200 python tools/fused_trace.py 20000 /tmp/ft
