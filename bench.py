@@ -92,6 +92,7 @@ def main():
     else:
         model = synthetic_model(k, seed=9)
     n_total = args.reads or cfg["n_reads"]
+    shard_idx = None               # strong scaling: which reads of the ONE batch this rank aligns
 
     # ---- the batch: every rank builds only the reads it aligns ----
     interleaved = numa_interleave(True) if args.host_buffers == "interleave" else False
@@ -107,6 +108,7 @@ def main():
         # (E is ~2.04 L for this generator, so 3L stands for E + K) and each rank generates just its shard
         L_all = synth.batch_lengths(n_total, cfg["seed"], cfg["law"])
         mine = np.nonzero(synth.lpt_bins(3 * L_all, world) == rank)[0]
+        shard_idx = mine
         batch = synth.make_batch(n_total, model, k, seed=cfg["seed"], law=cfg["law"], workers=workers, subset=mine)
     elif world > 1:
         batch = synth.make_batch(n_total, model, k, seed=cfg["seed"] + 1000 * rank, law=cfg["law"], workers=workers)
@@ -206,6 +208,15 @@ def main():
     qc_pass = float(((host_n_pairs if host_stats is not None else dev["n_pairs"]) > 0).sum())
 
     gdev = "cuda" if (dist is not None and args.backend == "nccl") else "cpu"
+    # n_event_align_pairs[] of the WHOLE batch, reassembled from the shards (4 B per read: the "trivial final gather" of the
+    # north star).  Its digest equals the single-rank run's iff every read got the same n_pairs wherever it ran; `covered` = how
+    # many ranks claimed each read (all ones = the LPT shards partition the batch).
+    np_local = host_n_pairs if host_stats is not None else dev["n_pairs"]
+    if shard_idx is not None and dist is not None:
+        np_all = dist_util.gather_per_read(shard_idx, np_local, n_total, device=gdev)
+        covered = dist_util.gather_per_read(shard_idx, np.ones(len(shard_idx), dtype=np.int32), n_total, device=gdev)
+    else:
+        np_all, covered = np.asarray(np_local, dtype=np.int32), np.ones(len(np_local), dtype=np.int32)
     g = dist_util.gather_stats(dict(elapsed=elapsed, events=float(sum_events), reads=float(n_reads), pairs=qc_pass), device=gdev)
     t_max, total_events, total_reads = g["t_max"], g["events"], g["reads"]
     # what every rank's host side did per step (flatten / un-flatten are the caller thread's loops, wait = idle on the GPU):
@@ -251,6 +262,13 @@ def main():
             "qc_pass_frac": round(g["pairs"] / total_reads, 4),
             "gen_s": round(t_gen, 1),
         }
+        if world == 1 or shard_idx is not None:
+            import hashlib
+            out["n_pairs"] = {"reads": int(len(np_all)), "sum": int(np_all.astype(np.int64).sum()),
+                              "sha256": hashlib.sha256(np.ascontiguousarray(np_all, dtype=np.int32).tobytes()).hexdigest(),
+                              "shards_partition_the_batch": bool((covered == 1).all()),
+                              "note": "n_event_align_pairs[] of the whole batch in read order" +
+                                      ("; reassembled from the ranks' shards by the final gather (f5c_amd/dist_util.gather_per_read)" if world > 1 else "")}
         if host_stats is not None:
             out["host_to_host"] = {
                 "mevents_per_s": round(sum_events * args.steps / elapsed / 1e6, 1),
@@ -291,6 +309,9 @@ def main():
                                  "host's DRAM bandwidth and CPU quota (%d usable CPUs), so host-to-host `value` stops scaling when the "
                                  "host loops dominate; device_resident / kernel_only below are the whole-job rates without host traffic"
                                  % (slow["rank"], busy, slow["host_ms_per_step"]["wait_for_gpu"], slow["ms_per_step"], effective_cpus()))
+            out["host_thread_budget"] = {"ranks": world, "threads_per_rank_incl_caller": [r["host_threads"] for r in rows],
+                                         "total": int(sum(r["host_threads"] for r in rows)), "quota_cpus": effective_cpus(),
+                                         "within_quota": bool(sum(r["host_threads"] for r in rows) <= effective_cpus())}
             out["cgroup_cpu"] = {"quota_cpus": effective_cpus(), "hw_threads": os.cpu_count(),
                                  "in_timed_region": {key: cg1.get(key, 0) - cg0.get(key, 0) for key in ("nr_periods", "nr_throttled", "throttled_usec", "usage_usec")},
                                  "note": "cpu.stat deltas of rank 0's cgroup over the timed steps: nr_throttled > 0 means CFS stopped the "
@@ -453,6 +474,7 @@ def process_chain(ctx, batch, model, k, check_cpu=True, n_reads=10000):
     t0 = time.time()
     sig, sp, ns, sc = synth.make_signals_flat(sub, seed=5, threads=max(2, effective_cpus() - 2))
     t_gen = time.time() - t0
+    link = ctx.link_probe()                                 # what the PCIe link of THIS box delivers, both directions at once
     v = ctx.signal_view(sig, sp, ns, sc, batch=sub)
     ctx.process_view(v)                                     # warm: slots, pinned staging
     ctx.free_view(v)
@@ -482,8 +504,11 @@ def process_chain(ctx, batch, model, k, check_cpu=True, n_reads=10000):
            "gpu_idle_frac": round(1.0 - (acc["gpu_busy_ms"] / reps) / (t * 1e3), 4),
            "pcie_bytes_per_call": {"h2d": int(st["h2d_bytes"]), "d2h": int(st["d2h_bytes"])},
            "chunks": int(st["n_sub_batches"]), "signal_gen_s": round(t_gen, 1),
+           "link_probe_gbs": link,
            "note": "one C-ABI call; the alignment reads the event means from the tables the detector left in HBM (no second trip up); "
-                   "what crosses PCIe: 2 B per sample up, the 24-B event_t tables (an output of event_db) + 0.9 B per event of results down"}
+                   "what crosses PCIe: 2 B per sample up; down, the event tables as 12-byte {start, mean, stdv} records (event_t's start / "
+                   "length are rebuilt on the host: the events of a read tile its samples) + 0.9 B per event of results"}
+    out.update(chain_bound(out["ms_per_call"], out["host_ms_per_call"], out["gpu_busy_ms_per_call"], out["pcie_bytes_per_call"], link))
     if check_cpu:
         from oracle import orc
         ok, checked = True, 0
@@ -525,8 +550,78 @@ def process_chain(ctx, batch, model, k, check_cpu=True, n_reads=10000):
                              "host_ms_per_call": {"flatten_signal": round(st["flatten_ms"], 1), "scatter_outputs": round(st["unflatten_ms"], 1),
                                                   "wait_for_gpu": round(st["wait_ms"], 1)},
                              "pcie_bytes_per_call": {"h2d": int(st["h2d_bytes"]), "d2h": int(st["d2h_bytes"])}}
+    e = out["event_db_alone"]
+    e.update(chain_bound(e["ms_per_call"], e["host_ms_per_call"], st["gpu_busy_ms"], e["pcie_bytes_per_call"], link))
     ctx.free_view(ve)
+    out["roofline_detector"] = detector_roofline(ctx, sub, sig, sp, ns, sc)
     return out
+
+
+def chain_bound(ms, host, gpu_busy_ms, pcie_bytes, link):
+    """What bounds a raw-signal call: `pcie` = achieved GB/s of each direction over the call against the link's own ceiling with both
+    directions busy (abea_link_probe on this box: host->device by copy engine while device->host runs — by copy engine too, the
+    mover the tables use), frac = the larger of the two shares; `bound` = "pcie" when that share is >= 0.8, "host" when the caller's
+    thread works (flatten + scatter + plan) >= 0.85 of the call, "detector" when the GPU's kernels cover >= 0.8 of it by its own clock,
+    else "ramp" (no resource saturated: the pipeline fills and drains)."""
+    t = ms * 1e-3
+    h2d, d2h = pcie_bytes["h2d"] / t / 1e9, pcie_bytes["d2h"] / t / 1e9
+    up_peak = min(link["both_h2d_copy"], link["both_copy_h2d"]) if os.environ.get("ABEA_CHAIN_TABLE_COPY", "engine") == "engine" else link["both_h2d_copy"]
+    dn_peak = link["both_copy_d2h"] if os.environ.get("ABEA_CHAIN_TABLE_COPY", "engine") == "engine" else link["both_d2h_kernel"]
+    frac = max(h2d / max(up_peak, 1e-9), d2h / max(dn_peak, 1e-9))
+    host_frac = sum(v for k_, v in host.items() if k_ != "wait_for_gpu") / ms
+    gpu_frac = gpu_busy_ms / ms
+    bound = "pcie" if frac >= 0.8 else "host" if host_frac >= 0.85 else "detector" if gpu_frac >= 0.8 else "ramp"
+    return {"pcie": {"h2d_gbs": round(h2d, 1), "d2h_gbs": round(d2h, 1),
+                     "link_peak_gbs": {"h2d": up_peak, "d2h": dn_peak, "one_direction": {"h2d": link["h2d_copy"], "d2h": link["d2h_copy"]}},
+                     "frac": round(frac, 4)},
+            "host_busy_frac": round(host_frac, 4), "gpu_busy_frac": round(gpu_frac, 4), "bound": bound}
+
+
+def detector_roofline(ctx, sub, sig, sp, ns, sc, n_reads=2048):
+    """The detector's kernels alone (abea_detect_events_device: inputs and outputs in HBM, one pass) on the first 2048 reads of the
+    chain's sample.  Algorithmic bytes: 2 B per sample in + 24 B per event out + the sequence (the scalings read
+    it once); achieved = those / the kernels' HIP-event time; `traffic` = FETCH_SIZE x 2 + WRITE_SIZE summed over the detector's
+    kernels in the committed rocprofv3 passes of tools/n2_profile.py (profiles/pmc_traffic.json["detector"], per sample, tied to the
+    event-detection section of abea_kernels.hip by its own sha256)."""
+    try:
+        import numpy as np
+        m = min(n_reads, len(ns))
+        sigs = [sig[sp[j]:sp[j] + ns[j]].astype(np.int16) for j in range(m)]
+        seqs = [sub["reads"][int(sub["read_ptr"][j]):int(sub["read_ptr"][j]) + int(sub["read_len"][j])].tobytes() for j in range(m)]
+        ctx._detect(sigs, sc[:m], seqs, 2)                   # warm
+        r = ctx._detect(sigs, sc[:m], seqs, 2)
+        ms = ctx.stats()["event_ms"]
+        n_ev = int(np.minimum(r["d_ne"].cpu().numpy(), r["cap"]).sum())
+        n_smp = int(ns[:m].sum())
+        a = 2 * n_smp + 24 * n_ev + int(sub["read_len"][:m].sum())
+        achieved = a / (ms * 1e-3) / 1e9
+        t = detector_pmc()
+        return {"bound": "latency", "kernels": "abea_ev_* (psum, pscan, pwrite, sums, tstat, spec, fix, scan, gather, detect, create, scalings)",
+                "bound_note": "a dozen short kernels per call, several of them lane-per-read or one wavefront per read over order-dependent "
+                              "fp64 chains: neither HBM (frac below) nor VALU issue is saturated; the row is priced against HBM because SURVEY §8f "
+                              "calls it HBM-bound, the fraction says how far from that it is",
+                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+                "reads": m, "samples": n_smp, "events": n_ev, "kernels_ms": round(ms, 3), "gsamples_per_s": round(n_smp / ms / 1e6, 2),
+                "algorithmic_bytes_per_launch": int(a), "algorithmic_bytes_per_sample": round(a / n_smp, 2),
+                "traffic": int(t["hbm_bytes_per_sample"] * n_smp) if t else None,
+                "traffic_per_kernel_bytes_per_sample": t.get("per_kernel") if t else None, "traffic_source": t.get("passes") if t else None}
+    except Exception as ex:                                # never fail the bench line for an extra
+        return {"error": repr(ex)}
+
+
+def detector_code_sha():
+    """sha256 of the event-detection section of abea_kernels.hip (from its banner to the end of the file)"""
+    import hashlib
+    data = open(os.path.join(ROOT, "f5c_amd/csrc/abea_kernels.hip"), "rb").read()
+    return hashlib.sha256(data[data.find(b"event detection on the device (row N2)"):]).hexdigest()
+
+
+def detector_pmc():
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["detector"]
+        return t if t.get("code_sha256") == detector_code_sha() else None
+    except Exception:
+        return None
 
 
 def cgroup_cpu_stat():

@@ -45,10 +45,8 @@ __global__ void abea_ev_gather_kernel(int, const int32_t*, const int32_t*, const
 __global__ void abea_ev_create_kernel(int, const int32_t*, const int32_t*, const int64_t*, const double*, const double*,
                                       const int64_t*, const int32_t*, const int32_t*, const int32_t*, const int32_t*,
                                       abea_event_t*, const int64_t*, float*, int);
-__global__ void abea_ev_kmer_kernel(int, const int32_t*, const char*, const int64_t*, const int32_t*, const abea_model_t*,
-                                    int, const int64_t*, const int32_t*, float*);
-__global__ void abea_ev_scalings_kernel(int, const int32_t*, const int64_t*, const float*, const int32_t*,
-                                        const int32_t*, const int32_t*, const int64_t*, const float*, int,
+__global__ void abea_ev_scalings_kernel(int, const int32_t*, const int64_t*, const int32_t*, const float*, const int32_t*,
+                                        const int32_t*, const char*, const int64_t*, const int32_t*, const abea_model_t*, int,
                                         abea_scalings_t*);
 }
 
@@ -484,7 +482,7 @@ int abea_detect_events_on(abea_ctx* c, const abea_signal_batch* B, const abea_ev
         const size_t o_ec = put(B->event_cap, N * 4), o_rp = put(B->read_ptr, N * 8), o_rl = put(B->read_len, N * 4);
         const size_t o_wb = put(wave_base.data(), (size_t)nw * 8), o_wl = put(wave_len.data(), (size_t)nw * 4);
         const size_t o_pb = put(peak_base.data(), (size_t)nw * 8), o_wc = put(wave_cap.data(), (size_t)nw * 4);
-        const size_t o_kb = put(kmer_base.data(), (size_t)nw * 8), o_wk = put(wave_k.data(), (size_t)nw * 4);
+        put(kmer_base.data(), (size_t)nw * 8); put(wave_k.data(), (size_t)nw * 4);      /* unused since round 6 (see dSegs below); the index block keeps its layout */
         const size_t o_sb = put(seg_base.data(), (size_t)nw * 8), o_wn = put(wave_nseg.data(), (size_t)nw * 4);
         const size_t o_need = put(nullptr, N * 4);                    /* per-read "segments never met" flags, zeroed */
         const size_t o_need_s = put(nullptr, N * 4);                  /* per-read "prefix sums may round" flags */
@@ -494,8 +492,9 @@ int abea_detect_events_on(abea_ctx* c, const abea_signal_batch* B, const abea_ev
         float* dT2 = dT1 + entries;
         int32_t* dPk = (int32_t*)(dT2 + entries);
         float* dMean = (float*)(dPk + pentries);
-        float* dKm = dMean + pentries;
-        uint8_t* dSegs = (uint8_t*)(dKm + kentries);
+        /* kentries floats behind the means: the k-mer level array of rounds 3-5 (the scalings kernel derives the levels itself now);
+         * the space stays in the arithmetic — abea_detect_scratch_bytes and the chunk carving charge it — as head-room */
+        uint8_t* dSegs = (uint8_t*)(dMean + pentries + kentries);
         dSegs += (256 - ((uintptr_t)dSegs & 255)) & 255;
         uint16_t* dSpec = (uint16_t*)dSegs;
         int32_t* dFix = (int32_t*)(dSpec + segs * EV_SEG * 64);
@@ -555,17 +554,11 @@ int abea_detect_events_on(abea_ctx* c, const abea_signal_batch* B, const abea_ev
                            nr, (const int32_t*)(d + o_order), (const int32_t*)(d + o_ns), (const int64_t*)(d + o_wb),
                            dS, dQ, (const int64_t*)(d + o_pb), (const int32_t*)(d + o_wc), dPk, B->n_events,
                            (const int32_t*)(d + o_ec), B->events, (const int64_t*)(d + o_ep), dMean, rna);
-        if (B->scalings) {
-            const unsigned ktiles = (unsigned)std::min<int64_t>(256, (*std::max_element(wave_k.begin(), wave_k.end()) + 3) / 4);
-            hipLaunchKernelGGL(abea_ev_kmer_kernel, dim3(ktiles, (unsigned)nw), dim3(256), 0, X.stream,
-                               nr, (const int32_t*)(d + o_order), B->reads, (const int64_t*)(d + o_rp),
-                               (const int32_t*)(d + o_rl), c->d_model, (int)c->k, (const int64_t*)(d + o_kb),
-                               (const int32_t*)(d + o_wk), dKm);
-            hipLaunchKernelGGL(abea_ev_scalings_kernel, dim3((unsigned)nw), dim3(512), 0, X.stream,
-                               nr, (const int32_t*)(d + o_order), (const int64_t*)(d + o_pb), dMean, B->n_events,
-                               (const int32_t*)(d + o_ec), (const int32_t*)(d + o_rl), (const int64_t*)(d + o_kb), dKm,
-                               (int)c->k, B->scalings);
-        }
+        if (B->scalings)                                     /* one wavefront per read (round 6): grid = reads of this pass */
+            hipLaunchKernelGGL(abea_ev_scalings_kernel, dim3((unsigned)nr), dim3(64), 0, X.stream,
+                               nr, (const int32_t*)(d + o_order), (const int64_t*)(d + o_pb), (const int32_t*)(d + o_wc), dMean,
+                               B->n_events, (const int32_t*)(d + o_ec), B->reads, (const int64_t*)(d + o_rp),
+                               (const int32_t*)(d + o_rl), c->d_model, (int)c->k, B->scalings);
         if (X.e1) HIP_TRY(hipEventRecord(X.e1, X.stream));
         HIP_TRY(hipGetLastError());
         if (X.async) {

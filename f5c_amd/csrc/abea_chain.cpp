@@ -97,7 +97,7 @@ namespace {
  * of the call's dominant transfer); copy_engine: they come down by hipMemcpyAsync on the slot's own device-to-host stream instead of
  * abea_copy_out_kernel.  Defaults = what measured fastest on the MI355X box (profiles/r06/chain_*); ABEA_CHAIN_TABLE_FORMAT=full|packed
  * and ABEA_CHAIN_TABLE_COPY=kernel|engine override (read per call: A/B runs in one process). */
-struct chain_opts { size_t chunk_samples; int32_t reads_min, reads_max; int n_slots; size_t cap_div; bool packed, copy_engine; };
+struct chain_opts { size_t chunk_samples; int32_t reads_min, reads_max; int n_slots; size_t cap_div; bool packed, copy_engine; int depth; };
 
 chain_opts read_chain_opts() {
     chain_opts o;
@@ -107,7 +107,9 @@ chain_opts read_chain_opts() {
     if (const char* e = getenv("ABEA_CHAIN_CHUNK_READS_MAX")) o.reads_max = std::max(1, atoi(e));
     if (const char* e = getenv("ABEA_CHAIN_SLOTS")) o.n_slots = std::min(ABEA_MAX_SLOTS, std::max(1, atoi(e)));
     if (const char* e = getenv("ABEA_CHAIN_CAP_DIV")) o.cap_div = (size_t)std::max(1, atoi(e));
-    o.packed = true; o.copy_engine = false;
+    o.packed = true; o.copy_engine = true;
+    o.depth = ABEA_MAX_SLOTS;                            /* chunks in flight: as many as there are slots; ABEA_CHAIN_DEPTH=2 is round 5's pairing */
+    if (const char* e = getenv("ABEA_CHAIN_DEPTH")) o.depth = std::max(1, atoi(e));
     if (const char* e = getenv("ABEA_CHAIN_TABLE_FORMAT")) o.packed = strcmp(e, "full") != 0;
     if (const char* e = getenv("ABEA_CHAIN_TABLE_COPY")) o.copy_engine = strcmp(e, "engine") == 0;
     o.reads_max = std::max(o.reads_max, o.reads_min);
@@ -764,10 +766,9 @@ int abea_chain_run(abea_ctx* c, const abea_chain_job* J, const int32_t* mine, in
     S.st.setup_ms = abea_now_ms() - t_start;
     /* ---- chunks: closed at chunk_samples samples (the first two a quarter / half of that) once they hold reads_min reads, at
      *      reads_max reads, or when the next read's upper bound would not fit the slot's share of the arena ---- */
-    size_t pos = 0;
-    int chunk_no = 0, prev = -1;
-    while (pos < todo.size()) {
-        const int ramp = chunk_no == 0 ? 4 : chunk_no == 1 ? 2 : 1;
+    std::vector<std::pair<size_t, size_t>> chunks;            /* [pos, end) into todo */
+    for (size_t pos = 0; pos < todo.size();) {
+        const int ramp = chunks.empty() ? 4 : chunks.size() == 1 ? 2 : 1;
         const size_t want_s = S.opt.chunk_samples / (size_t)ramp;
         const int32_t want_r = std::max(1, S.opt.reads_min / ramp);
         size_t samples = 0, end = pos;
@@ -787,18 +788,58 @@ int abea_chain_run(abea_ctx* c, const abea_chain_job* J, const int32_t* mine, in
             const int32_t cnt = (int32_t)(end - pos);
             if ((cnt >= want_r && samples >= want_s) || cnt >= S.opt.reads_max) break;
         }
-        abea_chain_slot& sl = *c->chain_slots[(size_t)(chunk_no % n_slots)];
-        int rc = slot_finish(S, sl);
-        if (rc) return rc;
-        rc = stage_detect(S, sl, todo.data() + pos, (int32_t)(end - pos), chunk_no, c->arena + (size_t)(chunk_no % n_slots) * slot_arena, slot_arena);
-        if (rc) return rc;
-        if (prev >= 0 && (rc = stage_align(S, *c->chain_slots[(size_t)prev]))) return rc;
-        prev = chunk_no % n_slots;
-        pos = end; ++chunk_no;
+        chunks.emplace_back(pos, end);
+        pos = end;
     }
-    for (int q = 0; q < n_slots; ++q) {                       /* drain, oldest chunk first */
-        const int rc = slot_finish(S, *c->chain_slots[(size_t)((chunk_no + q) % n_slots)]);
-        if (rc) return rc;
+    /* ---- the pipeline, driven by what has completed (round 6).  Round 5 issued stage D of chunk c + 1 and then BLOCKED on the counts
+     *      of chunk c: two chunks in flight, and when the pair finished the GPU idled until the next chunk was flattened and its
+     *      signal had crossed PCIe (GPU-clock timeline profiles/r06/chain_timeline_*: kernels 40-71 ms, 81-110 ms, 127-157 ms ...).
+     *      Now the caller's thread never waits while it could work: (1) every chunk whose counts are back gets its stage A at once,
+     *      (2) while a slot is free the next chunk is flattened and sent up — up to `depth` chunks ahead of the detector, so a
+     *      signal is in HBM before the kernels that read it can start —, (3) finished chunks are retired, oldest first, and only
+     *      when none of the three is possible does the thread block, on the oldest chunk in flight. ---- */
+    std::vector<int> inflight;                                /* slot numbers, in issue order */
+    std::vector<char> slot_busy((size_t)n_slots, 0);
+    size_t next_chunk = 0;
+    const int depth = std::max(1, std::min(n_slots, S.opt.depth));
+    auto ready = [](hipEvent_t e) { return hipEventQuery(e) == hipSuccess; };
+    while (next_chunk < chunks.size() || !inflight.empty()) {
+        bool progressed = false;
+        for (int q : inflight) {                              /* (1) counts are back: tables down, alignment */
+            abea_chain_slot& sl = *c->chain_slots[(size_t)q];
+            if (!sl.staged && ready(sl.e_cnt)) { const int rc = stage_align(S, sl); if (rc) return rc; progressed = true; }
+        }
+        if (next_chunk < chunks.size() && (int)inflight.size() < depth) {      /* (2) the next chunk up */
+            int q = 0;
+            while (slot_busy[(size_t)q]) ++q;
+            const std::pair<size_t, size_t> ck = chunks[next_chunk];
+            const int rc = stage_detect(S, *c->chain_slots[(size_t)q], todo.data() + ck.first, (int32_t)(ck.second - ck.first), (int)next_chunk,
+                                        c->arena + (size_t)q * slot_arena, slot_arena);
+            if (rc) return rc;
+            slot_busy[(size_t)q] = 1; inflight.push_back(q); ++next_chunk;
+            continue;
+        }
+        if (!inflight.empty()) {                              /* (3) retire the oldest chunk if it is complete */
+            abea_chain_slot& sl = *c->chain_slots[(size_t)inflight.front()];
+            if (sl.staged && ready(sl.e_done) && ready(sl.e_tab)) {
+                const int rc = slot_finish(S, sl);
+                if (rc) return rc;
+                slot_busy[(size_t)inflight.front()] = 0; inflight.erase(inflight.begin());
+                continue;
+            }
+        }
+        if (progressed) continue;
+        /* nothing to do but wait: for the counts of the oldest chunk that has none yet, else for the oldest chunk's results */
+        double t0 = abea_now_ms();
+        abea_chain_slot* waitfor = nullptr;
+        for (int q : inflight) if (!c->chain_slots[(size_t)q]->staged) { waitfor = c->chain_slots[(size_t)q]; break; }
+        if (waitfor) HIP_TRY(hipEventSynchronize(waitfor->e_cnt));
+        else {
+            abea_chain_slot& sl = *c->chain_slots[(size_t)inflight.front()];
+            HIP_TRY(hipEventSynchronize(sl.e_done));
+            HIP_TRY(hipEventSynchronize(sl.e_tab));
+        }
+        S.st.wait_ms += abea_now_ms() - t0;
     }
     S.st.gpu_busy_ms = interval_union_ms(S.spans);
     int rc = redo_overflowed(S);

@@ -88,9 +88,29 @@ extern "C" __global__ void abea_selftest_kernel(int* out) {
 }
 
 /* ---------------------------------------------------------------- align-pre */
-static __device__ __forceinline__ uint32_t base_code(char c) {
-    /* align.c:19-32: A0 C1 G2 T3, anything else ranks as 0 */
-    return c == 'C' ? 1u : (c == 'G' ? 2u : (c == 'T' ? 3u : 0u));
+static __device__ __forceinline__ uint32_t base_code(uint32_t c) {
+    /* align.c:19-32: A0 C1 G2 T3, anything else ranks as 0.  Arithmetic on the three comparisons, not a chain of ?: — the
+     * compiler turned that chain into a switch and the switch into four exec-masked branches per base (round 6: 25 instructions
+     * and a full s_waitcnt per base in every rank loop of the library). */
+    return (uint32_t)(c == (uint32_t)'C') + 2u * (uint32_t)(c == (uint32_t)'G') + 3u * (uint32_t)(c == (uint32_t)'T');
+}
+
+/* Rank of the k-mer that starts at seq[i] (align.c:36-47, first base most significant); the read has L bases and a NUL behind
+ * them.  One 12-byte load (any alignment; k <= 9) and the codes picked out of registers where the window stays inside the read's
+ * L + 1 bytes, base by base for the last few k-mers of a read: never a byte beyond the read's own terminator is touched (the
+ * device entry reads sequences from caller-owned memory). */
+static __device__ __forceinline__ uint32_t kmer_rank_at(const char* __restrict__ seq, int i, int L, int kmer_size) {
+    uint32_t rank = 0;
+    if (i + 12 <= L + 1) {
+        uint32_t w[3];
+        __builtin_memcpy(w, seq + i, 12);
+        #pragma unroll
+        for (int j = 0; j < ABEA_MAX_KMER_SIZE; ++j)
+            if (j < kmer_size) rank = (rank << 2) | base_code((w[j >> 2] >> (8 * (j & 3))) & 0xFFu);
+    } else {
+        for (int j = 0; j < kmer_size; ++j) rank = (rank << 2) | base_code((uint32_t)(unsigned char)seq[i + j]);
+    }
+    return rank;
 }
 
 extern "C" __global__ __launch_bounds__(256)
@@ -104,9 +124,9 @@ void abea_pre_kernel(const abea_read_desc* __restrict__ descs,
     const float scale = d->scale, shift = d->shift;
     const char* seq = reads + d->read_off;
     abea_kpar_t* kp = kpar_all + d->kpar_off;
+    const int L = K + kmer_size - 1;
     for (int i = threadIdx.x; i < K; i += blockDim.x) {
-        uint32_t rank = 0;                             /* align.c:36-47, first base most significant */
-        for (int j = 0; j < kmer_size; ++j) rank = (rank << 2) | base_code(seq[i + j]);
+        const uint32_t rank = kmer_rank_at(seq, i, L, kmer_size);
         const abea_model_t m = model[rank];
         abea_kpar_t p;
         p.gpm  = __fadd_rn(__fmul_rn(scale, m.level_mean), shift);   /* align.c:137-138, mul then add, no FMA */
@@ -117,7 +137,13 @@ void abea_pre_kernel(const abea_read_desc* __restrict__ descs,
     if (!events) return;                               /* host path: the means were uploaded straight into evm */
     const abea_event_t* ev = events + d->event_off;
     float* evm = evm_all + d->evm_off;
-    for (int i = threadIdx.x; i < E; i += blockDim.x) evm[i] = ev[i].mean;   /* align.c:131 reads .mean only */
+    /* align.c:131 reads .mean only.  Four loads in flight per thread before the first store: the loop is pure streaming */
+    int i = threadIdx.x;
+    for (; i + 3 * (int)blockDim.x < E; i += 4 * blockDim.x) {
+        const float m0 = ev[i].mean, m1 = ev[i + blockDim.x].mean, m2 = ev[i + 2 * blockDim.x].mean, m3 = ev[i + 3 * blockDim.x].mean;
+        evm[i] = m0; evm[i + blockDim.x] = m1; evm[i + 2 * blockDim.x] = m2; evm[i + 3 * blockDim.x] = m3;
+    }
+    for (; i < E; i += blockDim.x) evm[i] = ev[i].mean;
 }
 
 /* ---------------------------------------------------------------- band fill */
@@ -172,96 +198,118 @@ static __device__ void abea_fused_not_aligned(const abea_fused_scaling& fs, int 
     }
 }
 
+/* 16 bytes this wavefront stored a moment ago, read past the CU's L1 (the trace lines were loaded through it by the walk) */
+static __device__ __forceinline__ uint4 load_u4_l2(const uint4* p) {
+    const unsigned long long* q = reinterpret_cast<const unsigned long long*>(p);
+    const unsigned long long a = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long b = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return make_uint4((uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32));
+}
+
+/* 64 terms of one chain, in order, 16 bytes per LDS read; lanes outside the chain's set idle through the same instructions */
+static __device__ __forceinline__ double chain64(const double* col, int cnt, double acc) {
+    const double2* c2 = reinterpret_cast<const double2*>(col);
+    int i = 0;
+    for (; i + 8 <= cnt; i += 8) {
+        const double2 a = c2[i / 2], b = c2[i / 2 + 1], c = c2[i / 2 + 2], d = c2[i / 2 + 3];
+        acc += a.x; acc += a.y; acc += b.x; acc += b.y; acc += c.x; acc += c.y; acc += d.x; acc += d.y;
+    }
+    for (; i < cnt; ++i) acc += col[i];
+    return acc;
+}
+
 /* The map has been written by phase 3 of the alignment kernel; event_span = read_pos of the list's last pair minus that of its
- * first (align.c:602); lds = 64 x 5 doubles of wave-private LDS */
+ * first (align.c:602); lds = 5 columns of ABEA_P4_COL doubles of wave-private LDS; recs = the read's own trace scratch, dead since
+ * the walk, at least n_kmers uint4 long.
+ * Round 6 (the "diet"): rounds 4-5 swept the k-mers twice, and each sweep recomputed every k-mer's rank base by base (the compiler
+ * had made four branches and a full memory wait out of every base), reloaded the map and gathered the model again.  Now the first
+ * sweep leaves one 16-byte record {level_mean, level_stdv, event mean} per 'M' state, in 'M'-state order, in the trace scratch,
+ * and the variance pass reads those records DENSELY, 64 'M' states per step — no ranks, no map, no ballots —, the ranks of the first
+ * sweep come from one 12-byte load per lane, and every chain takes its terms from LDS 16 bytes at a time. */
+#define ABEA_P4_COL 66            /* doubles per column: 5 columns start 4 banks apart */
 static __device__ void abea_scaling_single_wave(const abea_read_desc* d, const abea_fused_scaling& fs, int lane, int event_span,
-                                                const float* __restrict__ evm, double* lds) {
+                                                const float* __restrict__ evm, double* lds, uint4* __restrict__ recs) {
     const int out_idx = d->out_idx;
     const int K = d->n_kmers;
     const int kmer_size = fs.kmer_size;
+    const int L = K + kmer_size - 1;
     const abea_index_pair_t* map = fs.b2e + d->kmer_off;
     const char* __restrict__ seq = fs.reads + d->read_off;
     const abea_model_t* __restrict__ model = fs.model;
     const double events_per_base = (double)event_span / K;   /* align.c:602 */
 
-    /* ---- one sweep over the k-mers in k order, 64 at a time: the 'M' states and, in their order, term(s) of a sum.
-     *      PASS 0: the five normal-equation sums + the counts; PASS 1: the variance sum (needs shift / scale). ---- */
+    /* ---- sweep over the k-mers in k order, 64 at a time: the 'M' states, their records, and the terms of the five
+     *      normal-equation sums (align.c:697-706), added by lanes 0..4 in 'M'-state order ---- */
     int n_M = 0, n_align = 0;
-    double acc = 0.0;                                    /* lanes 0..4: A00, A01, A11, b0, b1 (pass 0); lane 0: var (pass 1) */
-    double shift = 0, scale = 0;
-    for (int pass = 0; pass < 2; ++pass) {
-        int carry_rank = -1;
-        if (pass == 1) acc = 0.0;
-        for (int k0 = 0; k0 < K; k0 += 64) {
-            const int k = k0 + lane;
-            abea_index_pair_t m; m.start = -1; m.stop = -1;
-            int rank = 0;
-            if (k < K) {
-                m = load_map_l2(map + k);
-                for (int j = 0; j < kmer_size; ++j) rank = (rank << 2) | (int)base_code(seq[k + j]);
-            }
-            const bool valid = m.start != -1;
-            /* the map's entries tile the events of the path in k order (every event is new for exactly one k-mer), so the number
-             * of events per k-mer IS the map: one byte per k-mer for the host entry instead of eight (255 = "255 or more": the
-             * host then rebuilds that read's map from the walk) */
-            if (pass == 0 && fs.kcnt && k < K)
-                fs.kcnt[d->kmer_off + k] = valid ? (uint8_t)min(m.stop - m.start + 1, 255) : (uint8_t)0;
-            const unsigned long long vm = __ballot(valid);
-            const unsigned long long lower = vm & ((1ull << lane) - 1ull);
-            const int src = lower ? 63 - __clzll(lower) : 0;
-            const int below = __shfl(rank, src, 64);      /* every lane takes part: the source lane may have lower == 0 */
-            const int prev_rank = lower ? below : carry_rank;
-            const bool isM = valid && (rank != prev_rank);
-            const unsigned long long mm = __ballot(isM);
-            const int cnt = __popcll(mm);
-            const int pos = __popcll(mm & ((1ull << lane) - 1ull));   /* this 'M' state's place among the block's */
-            if (isM) {
-                const abea_model_t mo = model[rank];
-                const double level_stdv = mo.level_stdv, level_mean = mo.level_mean, raw_event = evm[m.start];
-                if (pass == 0) {                          /* align.c:697-706 */
-                    const double inv_var = 1. / (level_stdv * level_stdv);
-                    const double mu = level_mean, e = raw_event;
-                    lds[pos * 5 + 0] = inv_var;
-                    lds[pos * 5 + 1] = mu * inv_var;
-                    lds[pos * 5 + 2] = mu * mu * inv_var;
-                    lds[pos * 5 + 3] = e * inv_var;
-                    lds[pos * 5 + 4] = mu * e * inv_var;
-                } else {                                  /* align.c:738-751 */
-                    const double yi = (raw_event - shift - scale * level_mean);
-                    lds[pos] = yi * yi / (level_stdv * level_stdv);
-                }
-            }
-            if (pass == 0) { n_M += cnt; n_align += valid ? (m.stop - m.start + 1) : 0; }
-            if (vm) carry_rank = __shfl(rank, 63 - __clzll(vm), 64);
-            __syncthreads();
-            /* the chains: lane t adds column t of the block's terms, in 'M'-state order; reads issued eight ahead */
-            const int col = pass == 0 ? lane : 0, stride = pass == 0 ? 5 : 1;
-            if (lane < (pass == 0 ? 5 : 1)) {
-                int i = 0;
-                for (; i + 8 <= cnt; i += 8) {
-                    const double v0 = lds[(i + 0) * stride + col], v1 = lds[(i + 1) * stride + col];
-                    const double v2 = lds[(i + 2) * stride + col], v3 = lds[(i + 3) * stride + col];
-                    const double v4 = lds[(i + 4) * stride + col], v5 = lds[(i + 5) * stride + col];
-                    const double v6 = lds[(i + 6) * stride + col], v7 = lds[(i + 7) * stride + col];
-                    acc += v0; acc += v1; acc += v2; acc += v3; acc += v4; acc += v5; acc += v6; acc += v7;
-                }
-                for (; i < cnt; ++i) acc += lds[i * stride + col];
-            }
-            __syncthreads();
+    double acc = 0.0;                                    /* lanes 0..4: A00, A01, A11, b0, b1 */
+    int carry_rank = -1;
+    for (int k0 = 0; k0 < K; k0 += 64) {
+        const int k = k0 + lane;
+        abea_index_pair_t m; m.start = -1; m.stop = -1;
+        int rank = 0;
+        if (k < K) {
+            m = load_map_l2(map + k);
+            rank = (int)kmer_rank_at(seq, k, L, kmer_size);
         }
-        if (pass == 0) {
-            if (n_M < fs.min_rescale) break;             /* align.c:688: not enough 'M' states, no recalibration */
-            const double A00 = __shfl(acc, 0, 64), A01 = __shfl(acc, 1, 64), A11 = __shfl(acc, 2, 64);
-            const double b0 = __shfl(acc, 3, 64), b1 = __shfl(acc, 4, 64);
-            const double A10 = A01;
-            const double div = A00 * A11 - A01 * A10;     /* align.c:721-723 */
-            shift = -(A01 * b1 - A11 * b0) / div;
-            scale = (A00 * b1 - A10 * b0) / div;
+        const bool valid = m.start != -1;
+        /* the map's entries tile the events of the path in k order (every event is new for exactly one k-mer), so the number
+         * of events per k-mer IS the map: one byte per k-mer for the host entry instead of eight (255 = "255 or more": the
+         * host then rebuilds that read's map from the walk) */
+        if (fs.kcnt && k < K)
+            fs.kcnt[d->kmer_off + k] = valid ? (uint8_t)min(m.stop - m.start + 1, 255) : (uint8_t)0;
+        const unsigned long long vm = __ballot(valid);
+        const unsigned long long lower = vm & ((1ull << lane) - 1ull);
+        const int src = lower ? 63 - __clzll(lower) : 0;
+        const int below = __shfl(rank, src, 64);      /* every lane takes part: the source lane may have lower == 0 */
+        const int prev_rank = lower ? below : carry_rank;
+        const bool isM = valid && (rank != prev_rank);    /* hmm_state 'M', align.c:637; counted at align.c:677-686 */
+        const unsigned long long mm = __ballot(isM);
+        const int cnt = __popcll(mm);
+        const int pos = __popcll(mm & ((1ull << lane) - 1ull));   /* this 'M' state's place among the block's */
+        if (isM) {
+            const abea_model_t mo = model[rank];
+            const float raw = evm[m.start];
+            recs[n_M + pos] = make_uint4(__float_as_uint(mo.level_mean), __float_as_uint(mo.level_stdv), __float_as_uint(raw), 0u);
+            const double level_stdv = mo.level_stdv, mu = mo.level_mean, e = raw;
+            const double inv_var = 1. / (level_stdv * level_stdv);
+            lds[0 * ABEA_P4_COL + pos] = inv_var;
+            lds[1 * ABEA_P4_COL + pos] = mu * inv_var;
+            lds[2 * ABEA_P4_COL + pos] = mu * mu * inv_var;
+            lds[3 * ABEA_P4_COL + pos] = e * inv_var;
+            lds[4 * ABEA_P4_COL + pos] = mu * e * inv_var;
+        }
+        n_M += cnt; n_align += valid ? (m.stop - m.start + 1) : 0;
+        if (vm) carry_rank = __shfl(rank, 63 - __clzll(vm), 64);
+        __syncthreads();
+        if (lane < 5) acc = chain64(lds + lane * ABEA_P4_COL, cnt, acc);
+        __syncthreads();
+    }
+    const bool calibrated = n_M >= fs.min_rescale;        /* align.c:688: not enough 'M' states, no recalibration */
+    double shift = 0, scale = 0;
+    if (calibrated) {
+        const double A00 = __shfl(acc, 0, 64), A01 = __shfl(acc, 1, 64), A11 = __shfl(acc, 2, 64);
+        const double b0 = __shfl(acc, 3, 64), b1 = __shfl(acc, 4, 64);
+        const double A10 = A01;
+        const double div = A00 * A11 - A01 * A10;         /* align.c:721-723 */
+        shift = -(A01 * b1 - A11 * b0) / div;
+        scale = (A00 * b1 - A10 * b0) / div;
+        /* ---- the variance sum (align.c:738-751) over the records, 64 'M' states per step; lane 0 owns the chain ---- */
+        acc = 0.0;
+        for (int i0 = 0; i0 < n_M; i0 += 64) {
+            const int i = i0 + lane;
+            if (i < n_M) {
+                const uint4 rc = load_u4_l2(recs + i);
+                const double level_mean = __uint_as_float(rc.x), level_stdv = __uint_as_float(rc.y), raw_event = __uint_as_float(rc.z);
+                const double yi = (raw_event - shift - scale * level_mean);
+                lds[lane] = yi * yi / (level_stdv * level_stdv);
+            }
+            __syncthreads();
+            if (lane == 0) acc = chain64(lds, min(64, n_M - i0), acc);
+            __syncthreads();
         }
     }
     for (int off = 32; off > 0; off >>= 1) n_align += __shfl_xor(n_align, off, 64);
     if (lane == 0) {
-        const bool calibrated = n_M >= fs.min_rescale;
         int flag = 0;
         float fvar = fs.sc_io[out_idx].var;
         double var = -1.0;
@@ -608,7 +656,7 @@ void abea_align_kernel(const abea_read_desc* __restrict__ descs,
         } else {
             for (int off = 32; off > 0; off >>= 1) e_first = max(e_first, __shfl_xor(e_first, off, 64));   /* one lane had it */
             __syncthreads();                             /* phase 3's map stores are complete (and in L2) before the sweeps */
-            abea_scaling_single_wave(d, fs, lane, best_e - e_first, evm, reinterpret_cast<double*>(smem));
+            abea_scaling_single_wave(d, fs, lane, best_e - e_first, evm, reinterpret_cast<double*>(smem), trace);
         }
     }
 }
@@ -1286,7 +1334,7 @@ void abea_ev_create_kernel(int n_reads, const int32_t* __restrict__ order, const
              * usable: the caller redoes the read with a larger table (include/abea.h; abea_events_batch_host does). */
             const int at = rna ? n_ev - 1 - j : j;
             if (at < event_cap[r]) ev[at] = e;
-            mean_all[peak_base[w] + (int64_t)j * 64 + lane] = e.mean;
+            mean_all[peak_base[w] + (int64_t)lane * wcap + j] = e.mean;   /* linear per read, detection order: the scalings kernel's input */
         }
     }
 }
@@ -1333,133 +1381,96 @@ void abea_ev_pack_kernel(int n_reads, const abea_event_t* __restrict__ src, cons
     }
 }
 
-/* pass 4b: model level of every k-mer of every read (align.c:75-78), parallel; interleaved like the other scratch */
-extern "C" __global__ __launch_bounds__(256)
-void abea_ev_kmer_kernel(int n_reads, const int32_t* __restrict__ order, const char* __restrict__ reads,
-                         const int64_t* __restrict__ read_ptr, const int32_t* __restrict__ read_len,
-                         const abea_model_t* __restrict__ model, int kmer_size, const int64_t* __restrict__ kmer_base,
-                         const int32_t* __restrict__ wave_k, float* __restrict__ kmean_all) {
-    const int w = blockIdx.y;
-    const int lane = threadIdx.x & 63;
-    const int slot = w * 64 + lane;
+/* pass 5: estimate_scalings_using_mom (align.c:58-106), one wavefront per READ (round 6).
+ * Four sums per read: Σ event mean, Σ level, Σ level², then Σ (mean − shift)², all accumulated in double in index order.
+ * Rounds 1-5 gave a read one LANE (the detector's layout) and 64 reads a wavefront: the kernel was as long as the longest read's
+ * ~10^5 dependent additions times the LDS feed of 64 chains — 6.7 ms per 2048 reads alone, 12.6 ms per chunk inside the pipeline,
+ * more than the rest of the detector together (profiles/r06/chain_kernel_stats_before.csv), on 32 busy wavefronts of a 1024-SIMD
+ * chip.  Now:
+ *   - Σ mean and Σ level are sums of FLOATS in double.  All terms are multiples of the smallest term's ulp 2^(emin-150) and every
+ *     partial sum of any subset is below n * 2^(emax-126): when ceil(log2 n) + emax - emin <= 29 no addition of the sum can round,
+ *     in ANY order, so 64 lanes add strided subsets and a butterfly finishes — the sequential sum bit for bit (the test the
+ *     prefix sums of pass 1 use).  Checked per read and per sum; a sum that fails (a mean of 1e-9 next to means of 100) takes the
+ *     sequential form below.
+ *   - Σ level² and Σ (mean − shift)² have full-mantissa terms: no re-association is exact, the chains stay sequential — but their
+ *     TERMS are computed 64 wide (k-mer rank, model gather, the fp64 product) and parked in LDS, and two lanes add one column each
+ *     in order, both chains at once, 64 additions per tile fed by 16-byte LDS reads.  A 100 k-event read is ~0.5 ms of dependent
+ *     v_add_f64 on its own wavefront, and thousands of reads run side by side.
+ * Event means arrive in detection order from the create kernel's linear per-read array (RNA tables are reversed only afterwards,
+ * f5c.c:707-719); the k-mer levels are derived here from the sequence (no intermediate array). */
+extern "C" __global__ __launch_bounds__(64)
+void abea_ev_scalings_kernel(int n_reads, const int32_t* __restrict__ order, const int64_t* __restrict__ peak_base,
+                             const int32_t* __restrict__ wave_cap, const float* __restrict__ mean_lin,
+                             const int32_t* __restrict__ n_events, const int32_t* __restrict__ event_cap,
+                             const char* __restrict__ reads, const int64_t* __restrict__ read_ptr,
+                             const int32_t* __restrict__ read_len, const abea_model_t* __restrict__ model, int kmer_size,
+                             abea_scalings_t* __restrict__ scalings) {
+    __shared__ __attribute__((aligned(16))) double lds[2][64];
+    const int lane = threadIdx.x, slot = blockIdx.x;
     if (slot >= n_reads) return;
     const int r = order[slot];
-    const int K = read_len[r] - kmer_size + 1;
+    const int n_ev = n_events[r], ne = min(n_ev, event_cap[r]);
+    const int L = read_len[r], K = L - kmer_size + 1;
+    const float* __restrict__ mean = mean_lin + peak_base[slot >> 6] + (int64_t)(slot & 63) * wave_cap[slot >> 6];
     const char* __restrict__ seq = reads + read_ptr[r];
-    const int wk = wave_k[w];
-    for (int i = blockIdx.x * 4 + (threadIdx.x >> 6); i < wk; i += gridDim.x * 4) {
-        if (i >= K) continue;
-        uint32_t rank = 0;
-        for (int j = 0; j < kmer_size; ++j) rank = (rank << 2) | base_code(seq[i + j]);
-        kmean_all[kmer_base[w] + (int64_t)i * 64 + lane] = model[rank].level_mean;
+    auto level = [&](int i) { return model[kmer_rank_at(seq, i, L, kmer_size)].level_mean; };
+    /* ---- the two float sums: strided partial sums + the exponent range of the terms ---- */
+    double ps_e = 0.0, ps_k = 0.0;
+    int lo_e = 255, hi_e = 0, lo_k = 255, hi_k = 0;
+    auto range = [](float x, int& lo, int& hi) {
+        const int e = (int)((__float_as_uint(x) >> 23) & 0xFFu);
+        if (x != 0.0f) { lo = min(lo, max(e, 1)); hi = max(hi, e); }      /* NaN / Inf: e = 255 -> never "exact" */
+    };
+    for (int i = lane; i < ne; i += 64) { const float m = mean[i]; ps_e += (double)m; range(m, lo_e, hi_e); }
+    for (int i = lane; i < K; i += 64) { const float l = level(i); ps_k += (double)l; range(l, lo_k, hi_k); }
+    for (int off = 32; off > 0; off >>= 1) {
+        ps_e += __shfl_xor(ps_e, off, 64); ps_k += __shfl_xor(ps_k, off, 64);
+        lo_e = min(lo_e, __shfl_xor(lo_e, off, 64)); hi_e = max(hi_e, __shfl_xor(hi_e, off, 64));
+        lo_k = min(lo_k, __shfl_xor(lo_k, off, 64)); hi_k = max(hi_k, __shfl_xor(hi_k, off, 64));
     }
-}
-
-/* pass 5: estimate_scalings_using_mom (align.c:58-106): lane-per-read, sequential fp64 sums in the reference's order.
- * Four chains per read — Σ event mean, Σ level, Σ level², then Σ (mean − shift)² — whose terms arrive from HBM: rounds 1-4 let
- * the one wavefront of 64 reads fetch its own terms (16 rows of 64 floats in flight, ~2 µs each: 9.7 of the detector's 22.7 ms
- * per 2048 reads, profiles/r04/e_n2_kernel_stats.csv — a lone wave per 64 reads cannot keep enough loads in flight from its
- * registers).  Round 5: the chains are fed from LDS, as phase 4 of the alignment kernel feeds recalibrate_model's.  A block is
- * 8 wavefronts: wave 0 owns the 64 chains and reads its terms from LDS, waves 1..7 do nothing but stream the next tile of
- * interleaved rows into the other half of a double buffer.  The order of every addition is untouched. */
-#define EV_SC_TILE 64                       /* rows per tile in pass A (two arrays); pass B uses 2 x EV_SC_TILE rows of one array */
-extern "C" __global__ __launch_bounds__(512)
-void abea_ev_scalings_kernel(int n_reads, const int32_t* __restrict__ order, const int64_t* __restrict__ peak_base,
-                             const float* __restrict__ mean_all, const int32_t* __restrict__ n_events,
-                             const int32_t* __restrict__ event_cap, const int32_t* __restrict__ read_len,
-                             const int64_t* __restrict__ kmer_base, const float* __restrict__ kmean_all,
-                             int kmer_size, abea_scalings_t* __restrict__ scalings) {
-    __shared__ float lds[4 * EV_SC_TILE * 64];                       /* 64 KiB: [2 buffers][2 arrays][TILE][64] or [2][2 x TILE][64] */
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int slot = blockIdx.x * 64 + lane;
-    const bool live = slot < n_reads;
-    const int r = live ? order[slot] : 0;
-    const int n_ev = live ? n_events[r] : 0;
-    const int ne = live ? min(n_ev, event_cap[r]) : 0;
-    const int K = live ? read_len[r] - kmer_size + 1 : 0;
-    int ne_max = ne, k_max = K;                                       /* the same in all eight waves: they hold the same 64 reads */
-    for (int off = 32; off > 0; off >>= 1) { ne_max = max(ne_max, __shfl_xor(ne_max, off, 64)); k_max = max(k_max, __shfl_xor(k_max, off, 64)); }
-    const float* __restrict__ mean = mean_all + peak_base[blockIdx.x] + lane;
-    const float* __restrict__ km = kmean_all + kmer_base[blockIdx.x] + lane;
-    /* ---- pass A: the event-mean sum and the two k-mer sums (three independent chains per lane) ---- */
-    double ev_sum = 0.0, km_sum = 0.0, km_sq = 0.0;
-    {
-        const int n_it = max(ne_max, k_max), tiles = (n_it + EV_SC_TILE - 1) / EV_SC_TILE;
-        auto fill = [&](int t) {                                      /* waves 1..7: rows of tile t, every 7th each */
-            float* bm = lds + (size_t)(t & 1) * 2 * EV_SC_TILE * 64;
-            float* bk = bm + EV_SC_TILE * 64;
-            constexpr int PER = (EV_SC_TILE + 6) / 7;                 /* all of a loader's loads are issued before the first LDS write: */
-            float rm[PER], rk[PER];                                   /* 2 x PER rows in flight per wave, not one */
-            #pragma unroll
-            for (int j = 0; j < PER; ++j) {
-                const int row = wv - 1 + 7 * j, i = t * EV_SC_TILE + row;
-                rm[j] = (row < EV_SC_TILE && i < ne_max) ? mean[(size_t)i * 64] : 0.0f;   /* rows below the wave's longest table exist for every lane */
-                rk[j] = (row < EV_SC_TILE && i < k_max) ? km[(size_t)i * 64] : 0.0f;
-            }
-            #pragma unroll
-            for (int j = 0; j < PER; ++j) {
-                const int row = wv - 1 + 7 * j;
-                if (row < EV_SC_TILE) { bm[row * 64 + lane] = rm[j]; bk[row * 64 + lane] = rk[j]; }
-            }
+    auto clog2 = [](int n) { return n > 1 ? 32 - __clz(n - 1) : 0; };
+    const bool exact_e = hi_e < 255 && clog2(ne) + hi_e - lo_e <= 29;        /* no term at all: lo = 255, hi = 0: exact, sum = +0.0 */
+    const bool exact_k = hi_k < 255 && clog2(K) + hi_k - lo_k <= 29;
+    /* ---- sequential chains, two at a time: lane 0 adds column 0, lane 1 column 1, 64 terms per tile.  Past a chain's own end the
+     *      term is +0.0 (x + (+0.0) == x bit for bit; the sums start at +0.0 and cannot become -0.0). ---- */
+    enum { NONE, KM_SUM, KM_SQ, EV_SUM, EV_SQ };
+    double shift = 0.0;
+    auto run = [&](int kind0, int kind1, double& out0, double& out1) {
+        auto count = [&](int kind) { return kind == NONE ? 0 : (kind == KM_SUM || kind == KM_SQ) ? K : ne; };
+        auto term = [&](int kind, int i) -> double {
+            if (i >= count(kind)) return 0.0;
+            if (kind == KM_SUM) return (double)level(i);
+            if (kind == KM_SQ) { const double l = (double)level(i); return l * l; }                       /* align.c:80-81 */
+            if (kind == EV_SUM) return (double)mean[i];                                                    /* align.c:70 */
+            const double d = (double)mean[i] - shift; return d * d;                                       /* align.c:91-92 */
         };
-        if (wv > 0 && tiles > 0) fill(0);
-        __syncthreads();
-        for (int t = 0; t < tiles; ++t) {
-            if (wv > 0) { if (t + 1 < tiles) fill(t + 1); }
-            else {
-                const float* bm = lds + (size_t)(t & 1) * 2 * EV_SC_TILE * 64;
-                const float* bk = bm + EV_SC_TILE * 64;
-                const int i0 = t * EV_SC_TILE;
-                #pragma unroll 8
-                for (int row = 0; row < EV_SC_TILE; ++row) {
-                    /* past a lane's own end the term is +0.0: x + (+0.0) == x bit for bit (the sums start at +0.0 and never
-                     * become -0.0), so the tile needs no per-lane branches */
-                    const double m = (i0 + row < ne) ? (double)bm[row * 64 + lane] : 0.0;
-                    const double x = (i0 + row < K) ? (double)bk[row * 64 + lane] : 0.0;
-                    ev_sum += m; km_sum += x; km_sq += x * x;
+        const int n_it = max(count(kind0), count(kind1));
+        double acc = 0.0;
+        for (int i0 = 0; i0 < n_it; i0 += 64) {
+            lds[0][lane] = term(kind0, i0 + lane);
+            lds[1][lane] = term(kind1, i0 + lane);
+            __syncthreads();
+            if (lane < 2) {
+                const double2* col = reinterpret_cast<const double2*>(lds[lane]);
+                #pragma unroll
+                for (int q = 0; q < 32; q += 4) {
+                    const double2 a = col[q], b = col[q + 1], c2 = col[q + 2], d2 = col[q + 3];
+                    acc += a.x; acc += a.y; acc += b.x; acc += b.y; acc += c2.x; acc += c2.y; acc += d2.x; acc += d2.y;
                 }
             }
             __syncthreads();
         }
-    }
-    const double shift = ev_sum / n_ev - km_sum / K;                  /* waves 1..7 compute garbage here and never use it */
-    /* ---- pass B: Σ (mean − shift)² ---- */
-    double ev_sq = 0.0;
-    {
-        const int T2 = 2 * EV_SC_TILE, tiles = (ne_max + T2 - 1) / T2;
-        auto fill = [&](int t) {
-            float* bm = lds + (size_t)(t & 1) * T2 * 64;
-            constexpr int PER = (2 * EV_SC_TILE + 6) / 7;
-            float rm[PER];
-            #pragma unroll
-            for (int j = 0; j < PER; ++j) {
-                const int row = wv - 1 + 7 * j, i = t * T2 + row;
-                rm[j] = (row < T2 && i < ne_max) ? mean[(size_t)i * 64] : 0.0f;
-            }
-            #pragma unroll
-            for (int j = 0; j < PER; ++j) {
-                const int row = wv - 1 + 7 * j;
-                if (row < T2) bm[row * 64 + lane] = rm[j];
-            }
-        };
-        if (wv > 0 && tiles > 0) fill(0);
-        __syncthreads();
-        for (int t = 0; t < tiles; ++t) {
-            if (wv > 0) { if (t + 1 < tiles) fill(t + 1); }
-            else {
-                const float* bm = lds + (size_t)(t & 1) * T2 * 64;
-                const int i0 = t * T2;
-                #pragma unroll 8
-                for (int row = 0; row < T2; ++row) {
-                    const double d = (double)bm[row * 64 + lane] - shift;
-                    ev_sq += (i0 + row < ne) ? d * d : 0.0;
-                }
-            }
-            __syncthreads();
-        }
-    }
-    if (wv != 0 || !live) return;
-    const double scale = (ev_sq / n_ev) / (km_sq / K);
+        out0 = __shfl(acc, 0, 64); out1 = __shfl(acc, 1, 64);
+    };
+    double ev_sum = ps_e, km_sum = ps_k, unused = 0.0;
+    if (!exact_k && !exact_e) run(KM_SUM, EV_SUM, km_sum, ev_sum);
+    else if (!exact_k) run(KM_SUM, NONE, km_sum, unused);
+    else if (!exact_e) run(EV_SUM, NONE, ev_sum, unused);
+    shift = ev_sum / n_ev - km_sum / K;                                 /* align.c:86 */
+    double km_sq = 0.0, ev_sq = 0.0;
+    run(KM_SQ, EV_SQ, km_sq, ev_sq);
+    if (lane != 0) return;
+    const double scale = (ev_sq / n_ev) / (km_sq / K);                  /* align.c:95 */
     abea_scalings_t o; o.shift = (float)shift; o.scale = (float)scale; o.var = 1.0f; o.log_var = 0.0f;
     scalings[r] = o;
 }

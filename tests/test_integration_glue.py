@@ -1,4 +1,4 @@
-"""The f5c-side glue printed in INTEGRATION.md, compile-checked against the REAL reference headers (src/f5c.h,
+"""The f5c-side glue (integration/abea_glue.c, quoted in INTEGRATION.md), compile-checked against the REAL reference headers (src/f5c.h,
 src/f5cmisc.h) — build container only: /root/reference is absent on the GPU box.  htslib is not in the image, so
 opaque typedef stubs for the six htslib types f5c.h names are generated into a temp dir; nothing of this is committed
 or shipped, and nothing is linked or run (-fsyntax-only).  Also asserts the POD layouts the shim's casts rely on."""
@@ -50,12 +50,15 @@ def test_glue_compiles_against_the_reference_headers(tmp_path):
     (stub / "sam.h").write_text("#pragma once\ntypedef struct htsFile samFile; typedef struct bam1_t bam1_t; "
                                 "typedef struct bam_hdr_t bam_hdr_t; typedef struct sam_hdr_t sam_hdr_t;\n")
     (stub / "faidx.h").write_text("#pragma once\ntypedef struct faidx_t faidx_t;\n")
+    # the glue is a FILE a maintainer copies (integration/abea_glue.c); INTEGRATION.md quotes its two parts verbatim
+    glue = open(os.path.join(ROOT, "integration", "abea_glue.c")).read()
     md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
-    m = re.search(r"```c\n(// src/abea_glue\.c.*?)```", md, re.S)
+    m = re.search(r"```c\n(// src/abea_glue\.c — .*?)```", md, re.S)
     assert m, "INTEGRATION.md lost its glue block"
     m2 = re.search(r"```c\n(// src/abea_glue\.c, continued.*?)```", md, re.S)      # the process_db_rsq chain (round 4)
     assert m2, "INTEGRATION.md lost its process_db_rsq glue block"
-    (tmp_path / "abea_glue.c").write_text(m.group(1) + "\n" + m2.group(1))
+    assert m.group(1) in glue and m2.group(1) in glue, "INTEGRATION.md no longer quotes integration/abea_glue.c"
+    (tmp_path / "abea_glue.c").write_text(glue)
     (tmp_path / "layout.cpp").write_text(LAYOUT)
     inc = ["-I", str(tmp_path / "stub"), "-I", os.path.join(REF, "src"), "-I", os.path.join(REF, "slow5lib", "include"),
            "-I", os.path.join(ROOT, "include")]
@@ -64,3 +67,25 @@ def test_glue_compiles_against_the_reference_headers(tmp_path):
     for src in ("abea_glue.c", "layout.cpp"):
         r = subprocess.run(base + inc + [str(tmp_path / src)], capture_output=True, text=True)
         assert r.returncode == 0, f"{src}:\n{r.stderr[-3000:]}"
+
+
+def test_makefile_patch_applies_and_builds_the_glue(tmp_path):
+    """integration/f5c_makefile.patch against the reference's Makefile: applies cleanly to a copy, and `make -n abea=1` compiles
+    src/abea_glue.c with the reference's own rule, defines HAVE_CUDA, links -labea_hip and builds none of the .cu files."""
+    import shutil
+    shutil.copy(os.path.join(REF, "Makefile"), tmp_path / "Makefile")
+    r = subprocess.run(["patch", "-p1", "-i", os.path.join(ROOT, "integration", "f5c_makefile.patch")], cwd=tmp_path, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    (tmp_path / "src").mkdir()
+    shutil.copy(os.path.join(ROOT, "integration", "abea_glue.c"), tmp_path / "src" / "abea_glue.c")     # what the maintainer does
+    for h in ("f5c.h", "f5cmisc.h"):
+        (tmp_path / "src" / h).write_text("")                                # prerequisites of the rule; -n runs nothing
+    r = subprocess.run(["make", "-n", "-B", "abea=1", f"ABEA_ROOT={ROOT}", "build/abea_glue.o"], cwd=tmp_path, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    line = [ln for ln in r.stdout.splitlines() if "abea_glue.c" in ln][0]
+    assert "-DHAVE_CUDA=1" in line and f"-I {ROOT}/include" in line and "-x c++" in line
+    mk = (tmp_path / "Makefile").read_text()
+    assert "-labea_hip" in mk and "$(BUILD_DIR)/abea_glue.o" in mk
+    r = subprocess.run(["make", "-n", "-p", "abea=1", f"ABEA_ROOT={ROOT}"], cwd=tmp_path, capture_output=True, text=True)
+    objs = [ln for ln in r.stdout.splitlines() if ln.startswith("OBJ ")][0]
+    assert "abea_glue.o" in objs and "f5c_cuda.o" not in objs and "gpurocmcode" not in objs and "align_cuda.o" not in objs

@@ -5,7 +5,8 @@ the tables' trip down in ONE process on ONE set of signals, the per-call host sp
 ABEA_HOST_TRACE — the chunk timeline on stderr.  Two steps so that no generator pool runs under rocprofv3:
     python tools/chain_trace.py 10000 /tmp/ct                       # generates the batch (16 workers) and saves it
     [rocprofv3 --kernel-trace --stats ... --] python tools/chain_trace.py 10000 /tmp/ct [mode ...]
-mode = format:mover[:trace], e.g. packed:kernel full:engine:trace ; default = all four without a trace."""
+mode = format:mover[:trace][:dN], e.g. packed:kernel full:engine:trace packed:engine:d2 (dN = ABEA_CHAIN_DEPTH, chunks in flight);
+default = all four without a trace."""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -46,7 +47,10 @@ ref = None
 for mode in modes:
     parts = mode.split(":")
     os.environ["ABEA_CHAIN_TABLE_FORMAT"], os.environ["ABEA_CHAIN_TABLE_COPY"] = parts[0], parts[1]
-    trace = len(parts) > 2 and parts[2] == "trace"
+    trace = "trace" in parts[2:]
+    depth = [x[1:] for x in parts[2:] if x.startswith("d") and x[1:].isdigit()]
+    if depth: os.environ["ABEA_CHAIN_DEPTH"] = depth[0]
+    else: os.environ.pop("ABEA_CHAIN_DEPTH", None)
     for entry in ("events", "process"):
         v = ctx.signal_view(sig, sp, ns, sc, batch=b)
         call = ctx.events_view if entry == "events" else ctx.process_view
