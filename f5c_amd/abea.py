@@ -264,11 +264,12 @@ class AbeaContext:
 
     def link_probe(self, nbytes=0, reps=0):
         """abea_link_probe: GB/s of the host<->device link with pinned memory, one direction at a time and both at once."""
-        out = (C.c_double * 7)()
+        out = (C.c_double * 10)()
         self._lib.abea_link_probe.restype = C.c_int
         self._lib.abea_link_probe.argtypes = [C.c_void_p, C.c_uint64, C.c_int32, C.POINTER(C.c_double), C.c_int32]
-        self._chk(self._lib.abea_link_probe(self._h, nbytes, reps, out, 7), "abea_link_probe")
-        keys = ("h2d_copy", "d2h_copy", "d2h_kernel", "both_h2d_copy", "both_d2h_kernel", "both_copy_h2d", "both_copy_d2h")
+        self._chk(self._lib.abea_link_probe(self._h, nbytes, reps, out, 10), "abea_link_probe")
+        keys = ("h2d_copy", "d2h_copy", "d2h_kernel", "both_h2d_copy", "both_d2h_kernel", "both_copy_h2d", "both_copy_d2h",
+                "h2d_kernel", "both_h2d_kernel", "both_d2h_copy")
         return {k_: round(float(v), 2) for k_, v in zip(keys, out)}
 
     def stats(self):

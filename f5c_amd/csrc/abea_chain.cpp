@@ -97,7 +97,7 @@ namespace {
  * of the call's dominant transfer); copy_engine: they come down by hipMemcpyAsync on the slot's own device-to-host stream instead of
  * abea_copy_out_kernel.  Defaults = what measured fastest on the MI355X box (profiles/r06/chain_*); ABEA_CHAIN_TABLE_FORMAT=full|packed
  * and ABEA_CHAIN_TABLE_COPY=kernel|engine override (read per call: A/B runs in one process). */
-struct chain_opts { size_t chunk_samples; int32_t reads_min, reads_max; int n_slots; size_t cap_div; bool packed, copy_engine; int depth; };
+struct chain_opts { size_t chunk_samples; int32_t reads_min, reads_max; int n_slots; size_t cap_div; bool packed, copy_engine, up_kernel; int depth, copy_blocks; };
 
 chain_opts read_chain_opts() {
     chain_opts o;
@@ -110,6 +110,9 @@ chain_opts read_chain_opts() {
     o.packed = true; o.copy_engine = true;
     o.depth = ABEA_MAX_SLOTS;                            /* chunks in flight: as many as there are slots; ABEA_CHAIN_DEPTH=2 is round 5's pairing */
     if (const char* e = getenv("ABEA_CHAIN_DEPTH")) o.depth = std::max(1, atoi(e));
+    o.up_kernel = false;                                 /* ABEA_CHAIN_UP=kernel: the signal comes up by the copy kernel (loads from pinned memory) */
+    if (const char* e = getenv("ABEA_CHAIN_UP")) o.up_kernel = strcmp(e, "kernel") == 0;
+    o.copy_blocks = abea_copy_kernel_blocks();
     if (const char* e = getenv("ABEA_CHAIN_TABLE_FORMAT")) o.packed = strcmp(e, "full") != 0;
     if (const char* e = getenv("ABEA_CHAIN_TABLE_COPY")) o.copy_engine = strcmp(e, "engine") == 0;
     o.reads_max = std::max(o.reads_max, o.reads_min);
@@ -300,7 +303,13 @@ int stage_detect(chain_state& S, abea_chain_slot& sl, const int32_t* ids, int32_
     if (rc) return rc;
     S.log("enqueue D", chunk_no, m, n_sig);
     sl.busy = true;                                  /* from here on the slot's streams hold work of this call: every exit drains them */
-    HIP_TRY(hipMemcpyAsync(sl.d_up, sl.up.p, sl.u_end, hipMemcpyHostToDevice, sl.stream));
+    if (S.opt.up_kernel) {
+        hipLaunchKernelGGL(abea_copy_out_kernel, dim3((unsigned)std::min<size_t>((size_t)S.opt.copy_blocks, (sl.u_end / 16 + 255) / 256)), dim3(256), 0, sl.stream,
+                           (const uint4*)sl.up.p, (uint4*)sl.d_up, sl.u_end / 16);
+        HIP_TRY(hipGetLastError());
+    } else {
+        HIP_TRY(hipMemcpyAsync(sl.d_up, sl.up.p, sl.u_end, hipMemcpyHostToDevice, sl.stream));
+    }
     S.st.h2d_bytes += sl.u_end;
     abea_signal_batch sb;
     memset(&sb, 0, sizeof sb);
@@ -386,7 +395,7 @@ int stage_align(chain_state& S, abea_chain_slot& sl) {
             HIP_TRY(hipStreamWaitEvent(sl.dstream, sl.e_cmp, 0));
             HIP_TRY(hipMemcpyAsync(sl.tab.p, sl.d_evc, n16 * 16, hipMemcpyDeviceToHost, sl.dstream));
         } else if (n16) {
-            hipLaunchKernelGGL(abea_copy_out_kernel, dim3((unsigned)std::min<size_t>(512, (n16 + 255) / 256)), dim3(256), 0, sl.stream,
+            hipLaunchKernelGGL(abea_copy_out_kernel, dim3((unsigned)std::min<size_t>((size_t)S.opt.copy_blocks, (n16 + 255) / 256)), dim3(256), 0, sl.stream,
                                (const uint4*)sl.d_evc, (uint4*)sl.tab.p, n16);
         }
         HIP_TRY(hipGetLastError());
@@ -798,6 +807,33 @@ int abea_chain_run(abea_ctx* c, const abea_chain_job* J, const int32_t* mine, in
      *      (2) while a slot is free the next chunk is flattened and sent up — up to `depth` chunks ahead of the detector, so a
      *      signal is in HBM before the kernels that read it can start —, (3) finished chunks are retired, oldest first, and only
      *      when none of the three is possible does the thread block, on the oldest chunk in flight. ---- */
+    /* pinned staging sized once for the largest chunk of the call (the slot a chunk lands on depends on what has completed: growing
+     * a slot's blocks when a larger chunk arrives re-pinned hundreds of MB in the middle of the pipeline, 10-15 ms a time) */
+    {
+        size_t up_max = 0, tab_max = 0, cnt_max = 0;
+        for (const std::pair<size_t, size_t>& ck : chunks) {
+            size_t n_sig = 0, n_seq = 0, n_slot = 0;
+            for (size_t q = ck.first; q < ck.second; ++q) {
+                const int32_t i = todo[q];
+                const int64_t ns = J->n_samples[i];
+                n_sig += (size_t)((ns + 7) / 8 * 8);
+                n_seq += align_up((size_t)(want_sc ? J->read_len[i] : (int32_t)c->k) + 1, 16);
+                n_slot += std::min<size_t>((size_t)ns / S.opt.cap_div + 16, INT32_MAX / 2);
+            }
+            const size_t m = ck.second - ck.first;
+            up_max = std::max(up_max, align_up(align_up(n_sig * 2, 256) + n_seq, 256));
+            tab_max = std::max(tab_max, align_up((n_slot + 3 * m) * (S.opt.packed ? 12 : sizeof(abea_event_t)), 16) + 256);
+            cnt_max = std::max(cnt_max, align_up(align_up(m * 4, 256) + m * sizeof(abea_scalings_t), 256));
+        }
+        for (int q = 0; q < std::min<int>(n_slots, (int)chunks.size()); ++q) {
+            abea_chain_slot& sl = *c->chain_slots[(size_t)q];
+            int rc = sl.up.need(up_max);
+            if (!rc) rc = sl.tab.need(tab_max);
+            if (!rc) rc = sl.cnt.need(cnt_max);
+            if (rc) return rc;
+        }
+    }
+    S.st.setup_ms = abea_now_ms() - t_start;
     std::vector<int> inflight;                                /* slot numbers, in issue order */
     std::vector<char> slot_busy((size_t)n_slots, 0);
     size_t next_chunk = 0;

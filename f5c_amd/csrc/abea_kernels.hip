@@ -239,51 +239,105 @@ static __device__ void abea_scaling_single_wave(const abea_read_desc* d, const a
     const double events_per_base = (double)event_span / K;   /* align.c:602 */
 
     /* ---- sweep over the k-mers in k order, 64 at a time: the 'M' states, their records, and the terms of the five
-     *      normal-equation sums (align.c:697-706), added by lanes 0..4 in 'M'-state order ---- */
-    int n_M = 0, n_align = 0;
-    double acc = 0.0;                                    /* lanes 0..4: A00, A01, A11, b0, b1 */
-    int carry_rank = -1;
-    for (int k0 = 0; k0 < K; k0 += 64) {
-        const int k = k0 + lane;
-        abea_index_pair_t m; m.start = -1; m.stop = -1;
-        int rank = 0;
-        if (k < K) {
-            m = load_map_l2(map + k);
-            rank = (int)kmer_rank_at(seq, k, L, kmer_size);
+     *      normal-equation sums (align.c:697-706), added by lanes 0..4 in 'M'-state order.
+     *      Software-pipelined (round 6): a block's wave time was 2.8 us, two thirds of it memory latency in a row — map entry and
+     *      sequence window, then the gathers that depend on them (model entry, event mean), then the chain.  Now the loads of
+     *      block b + 2 are in flight while block b is worked on, the gathers of block b + 1 while the chain of block b runs, and
+     *      the wavefront orders its own LDS traffic without workgroup barriers (one wavefront = the workgroup; its LDS operations
+     *      execute in issue order), which also keeps the prefetched loads in flight: __syncthreads() waits for every outstanding
+     *      global load. ---- */
+    struct blk_in { abea_index_pair_t m; uint32_t d[4], sh; };            /* stage A: map entry + the 4 aligned dwords around the window */
+    struct blk_st { abea_index_pair_t m; int rank; bool valid, isM; int pos, cnt; abea_model_t mo; float raw; };
+    /* unconditional loads from clamped addresses (always inside the read's own map and its L + 1 sequence bytes): nothing for the
+     * compiler to wait for at the point of issue; lanes past K - 1, and windows that would cross the read's end, are sorted out in
+     * stage() */
+    /* The sequence window comes up as four ALIGNED dwords by relaxed atomic loads and is shifted into place (v_alignbyte): plain
+     * loads are sunk by the optimizer down to their first use, a block and a half later — the opposite of a prefetch —, atomic
+     * loads stay where they are written.  The window [kc, kc + 16) is clamped inside the read's own L + 1 bytes; an aligned dword
+     * that holds a valid byte cannot cross into an unmapped page.  Reads shorter than 16 bytes take the base-by-base path. */
+    const bool has_window = L + 1 >= 16;                                   /* wave-uniform */
+    const int win_last = L + 1 - 16;
+    auto load_in = [&](int k0) {
+        blk_in a; a.d[0] = a.d[1] = a.d[2] = a.d[3] = 0u; a.sh = 0u;
+        const int k = min(k0 + lane, K - 1);
+        a.m = load_map_l2(map + k);
+        if (has_window) {
+            const char* p = seq + min(k, win_last);
+            a.sh = (uint32_t)(reinterpret_cast<uintptr_t>(p) & 3);
+            const uint32_t* q = reinterpret_cast<const uint32_t*>(p - a.sh);
+            a.d[0] = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            a.d[1] = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            a.d[2] = __hip_atomic_load(q + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            a.d[3] = __hip_atomic_load(q + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
-        const bool valid = m.start != -1;
+        return a;
+    };
+    int n_M = 0, n_align = 0;
+    int carry_rank = -1;
+    auto stage = [&](const blk_in& a, int k0) {                           /* stage B: rank, 'M' states, gathers issued (not waited for) */
+        blk_st b; b.m = a.m; b.rank = 0; b.mo.level_mean = b.mo.level_stdv = b.mo.level_log_stdv = 0.f; b.raw = 0.f;
+        const int k = k0 + lane;
+        if (k >= K) { b.m.start = -1; b.m.stop = -1; }                    /* the clamped load fetched entry K - 1 again */
+        if (k < K) {
+            if (has_window && k <= win_last) {
+                const uint32_t w[3] = {__builtin_amdgcn_alignbyte(a.d[1], a.d[0], a.sh), __builtin_amdgcn_alignbyte(a.d[2], a.d[1], a.sh),
+                                       __builtin_amdgcn_alignbyte(a.d[3], a.d[2], a.sh)};
+                uint32_t rank = 0;
+                #pragma unroll
+                for (int j = 0; j < ABEA_MAX_KMER_SIZE; ++j)
+                    if (j < kmer_size) rank = (rank << 2) | base_code((w[j >> 2] >> (8 * (j & 3))) & 0xFFu);
+                b.rank = (int)rank;
+            } else {
+                b.rank = (int)kmer_rank_at(seq, k, L, kmer_size);        /* the last few k-mers of the read: base by base */
+            }
+        }
+        b.valid = b.m.start != -1;
         /* the map's entries tile the events of the path in k order (every event is new for exactly one k-mer), so the number
          * of events per k-mer IS the map: one byte per k-mer for the host entry instead of eight (255 = "255 or more": the
          * host then rebuilds that read's map from the walk) */
         if (fs.kcnt && k < K)
-            fs.kcnt[d->kmer_off + k] = valid ? (uint8_t)min(m.stop - m.start + 1, 255) : (uint8_t)0;
-        const unsigned long long vm = __ballot(valid);
+            fs.kcnt[d->kmer_off + k] = b.valid ? (uint8_t)min(b.m.stop - b.m.start + 1, 255) : (uint8_t)0;
+        const unsigned long long vm = __ballot(b.valid);
         const unsigned long long lower = vm & ((1ull << lane) - 1ull);
         const int src = lower ? 63 - __clzll(lower) : 0;
-        const int below = __shfl(rank, src, 64);      /* every lane takes part: the source lane may have lower == 0 */
+        const int below = __shfl(b.rank, src, 64);    /* every lane takes part: the source lane may have lower == 0 */
         const int prev_rank = lower ? below : carry_rank;
-        const bool isM = valid && (rank != prev_rank);    /* hmm_state 'M', align.c:637; counted at align.c:677-686 */
-        const unsigned long long mm = __ballot(isM);
-        const int cnt = __popcll(mm);
-        const int pos = __popcll(mm & ((1ull << lane) - 1ull));   /* this 'M' state's place among the block's */
-        if (isM) {
-            const abea_model_t mo = model[rank];
-            const float raw = evm[m.start];
-            recs[n_M + pos] = make_uint4(__float_as_uint(mo.level_mean), __float_as_uint(mo.level_stdv), __float_as_uint(raw), 0u);
-            const double level_stdv = mo.level_stdv, mu = mo.level_mean, e = raw;
-            const double inv_var = 1. / (level_stdv * level_stdv);
-            lds[0 * ABEA_P4_COL + pos] = inv_var;
-            lds[1 * ABEA_P4_COL + pos] = mu * inv_var;
-            lds[2 * ABEA_P4_COL + pos] = mu * mu * inv_var;
-            lds[3 * ABEA_P4_COL + pos] = e * inv_var;
-            lds[4 * ABEA_P4_COL + pos] = mu * e * inv_var;
+        b.isM = b.valid && (b.rank != prev_rank);         /* hmm_state 'M', align.c:637; counted at align.c:677-686 */
+        const unsigned long long mm = __ballot(b.isM);
+        b.cnt = __popcll(mm);
+        b.pos = __popcll(mm & ((1ull << lane) - 1ull));   /* this 'M' state's place among the block's */
+        if (b.isM) { b.mo = model[b.rank]; b.raw = evm[b.m.start]; }
+        n_align += b.valid ? (b.m.stop - b.m.start + 1) : 0;
+        if (vm) carry_rank = __shfl(b.rank, 63 - __clzll(vm), 64);
+        return b;
+    };
+    double acc = 0.0;                                    /* lanes 0..4: A00, A01, A11, b0, b1 */
+    {
+        blk_in a1 = load_in(0), a2 = load_in(64);
+        blk_st cur = stage(a1, 0);
+        a1 = a2;
+        for (int k0 = 0; k0 < K; k0 += 64) {
+            a2 = load_in(k0 + 128);
+            if (cur.isM) {
+                recs[n_M + cur.pos] = make_uint4(__float_as_uint(cur.mo.level_mean), __float_as_uint(cur.mo.level_stdv), __float_as_uint(cur.raw), 0u);
+                const double level_stdv = cur.mo.level_stdv, mu = cur.mo.level_mean, e = cur.raw;
+                const double inv_var = 1. / (level_stdv * level_stdv);
+                lds[0 * ABEA_P4_COL + cur.pos] = inv_var;
+                lds[1 * ABEA_P4_COL + cur.pos] = mu * inv_var;
+                lds[2 * ABEA_P4_COL + cur.pos] = mu * mu * inv_var;
+                lds[3 * ABEA_P4_COL + cur.pos] = e * inv_var;
+                lds[4 * ABEA_P4_COL + cur.pos] = mu * e * inv_var;
+            }
+            const int cnt = cur.cnt;
+            n_M += cnt;
+            const blk_st nxt = stage(a1, k0 + 64);        /* its gathers fly while the chain below runs */
+            __builtin_amdgcn_wave_barrier();
+            if (lane < 5) acc = chain64(lds + lane * ABEA_P4_COL, cnt, acc);
+            __builtin_amdgcn_wave_barrier();
+            cur = nxt; a1 = a2;
         }
-        n_M += cnt; n_align += valid ? (m.stop - m.start + 1) : 0;
-        if (vm) carry_rank = __shfl(rank, 63 - __clzll(vm), 64);
-        __syncthreads();
-        if (lane < 5) acc = chain64(lds + lane * ABEA_P4_COL, cnt, acc);
-        __syncthreads();
     }
+    __syncthreads();                                      /* the record stores are complete (and in L2) before they are read back */
     const bool calibrated = n_M >= fs.min_rescale;        /* align.c:688: not enough 'M' states, no recalibration */
     double shift = 0, scale = 0;
     if (calibrated) {
@@ -293,19 +347,22 @@ static __device__ void abea_scaling_single_wave(const abea_read_desc* d, const a
         const double div = A00 * A11 - A01 * A10;         /* align.c:721-723 */
         shift = -(A01 * b1 - A11 * b0) / div;
         scale = (A00 * b1 - A10 * b0) / div;
-        /* ---- the variance sum (align.c:738-751) over the records, 64 'M' states per step; lane 0 owns the chain ---- */
+        /* ---- the variance sum (align.c:738-751) over the records, 64 'M' states per step; lane 0 owns the chain; the records
+         *      of the next step are loaded while it runs ---- */
         acc = 0.0;
+        auto load_rec = [&](int i) { return i < n_M ? load_u4_l2(recs + i) : make_uint4(0u, 0u, 0u, 0u); };
+        uint4 rc = load_rec(lane);
         for (int i0 = 0; i0 < n_M; i0 += 64) {
-            const int i = i0 + lane;
-            if (i < n_M) {
-                const uint4 rc = load_u4_l2(recs + i);
+            const uint4 rn = load_rec(i0 + 64 + lane);
+            if (i0 + lane < n_M) {
                 const double level_mean = __uint_as_float(rc.x), level_stdv = __uint_as_float(rc.y), raw_event = __uint_as_float(rc.z);
                 const double yi = (raw_event - shift - scale * level_mean);
                 lds[lane] = yi * yi / (level_stdv * level_stdv);
             }
-            __syncthreads();
+            __builtin_amdgcn_wave_barrier();
             if (lane == 0) acc = chain64(lds, min(64, n_M - i0), acc);
-            __syncthreads();
+            __builtin_amdgcn_wave_barrier();
+            rc = rn;
         }
     }
     for (int off = 32; off > 0; off >>= 1) n_align += __shfl_xor(n_align, off, 64);
@@ -657,6 +714,9 @@ void abea_align_kernel(const abea_read_desc* __restrict__ descs,
             for (int off = 32; off > 0; off >>= 1) e_first = max(e_first, __shfl_xor(e_first, off, 64));   /* one lane had it */
             __syncthreads();                             /* phase 3's map stores are complete (and in L2) before the sweeps */
             abea_scaling_single_wave(d, fs, lane, best_e - e_first, evm, reinterpret_cast<double*>(smem), trace);
+#ifdef ABEA_PROFILE_PHASES   /* experiment build: ticks from the end of the walk to the end of phase 4 into diag.pad (minus .spanned = phase 4) */
+            if (lane == 0 && diag) diag[out_idx].pad = (int32_t)(wall_clock64() - t_walk);
+#endif
         }
     }
 }
@@ -1405,7 +1465,7 @@ void abea_ev_scalings_kernel(int n_reads, const int32_t* __restrict__ order, con
                              const char* __restrict__ reads, const int64_t* __restrict__ read_ptr,
                              const int32_t* __restrict__ read_len, const abea_model_t* __restrict__ model, int kmer_size,
                              abea_scalings_t* __restrict__ scalings) {
-    __shared__ __attribute__((aligned(16))) double lds[2][64];
+    __shared__ __attribute__((aligned(16))) double lds[2][2][64];       /* [buffer][chain][term] */
     const int lane = threadIdx.x, slot = blockIdx.x;
     if (slot >= n_reads) return;
     const int r = order[slot];
@@ -1421,8 +1481,21 @@ void abea_ev_scalings_kernel(int n_reads, const int32_t* __restrict__ order, con
         const int e = (int)((__float_as_uint(x) >> 23) & 0xFFu);
         if (x != 0.0f) { lo = min(lo, max(e, 1)); hi = max(hi, e); }      /* NaN / Inf: e = 255 -> never "exact" */
     };
-    for (int i = lane; i < ne; i += 64) { const float m = mean[i]; ps_e += (double)m; range(m, lo_e, hi_e); }
-    for (int i = lane; i < K; i += 64) { const float l = level(i); ps_k += (double)l; range(l, lo_k, hi_k); }
+    {   /* four loads in flight per lane: a lone wavefront per read is latency-bound, not bandwidth-bound */
+        int i = lane;
+        for (; i + 192 < ne; i += 256) {
+            const float m0 = mean[i], m1 = mean[i + 64], m2 = mean[i + 128], m3 = mean[i + 192];
+            ps_e += (double)m0; ps_e += (double)m1; ps_e += (double)m2; ps_e += (double)m3;
+            range(m0, lo_e, hi_e); range(m1, lo_e, hi_e); range(m2, lo_e, hi_e); range(m3, lo_e, hi_e);
+        }
+        for (; i < ne; i += 64) { const float m = mean[i]; ps_e += (double)m; range(m, lo_e, hi_e); }
+        i = lane;
+        for (; i + 64 < K; i += 128) {
+            const float l0 = level(i), l1 = level(i + 64);
+            ps_k += (double)l0; ps_k += (double)l1; range(l0, lo_k, hi_k); range(l1, lo_k, hi_k);
+        }
+        for (; i < K; i += 64) { const float l = level(i); ps_k += (double)l; range(l, lo_k, hi_k); }
+    }
     for (int off = 32; off > 0; off >>= 1) {
         ps_e += __shfl_xor(ps_e, off, 64); ps_k += __shfl_xor(ps_k, off, 64);
         lo_e = min(lo_e, __shfl_xor(lo_e, off, 64)); hi_e = max(hi_e, __shfl_xor(hi_e, off, 64));
@@ -1446,20 +1519,25 @@ void abea_ev_scalings_kernel(int n_reads, const int32_t* __restrict__ order, con
         };
         const int n_it = max(count(kind0), count(kind1));
         double acc = 0.0;
-        for (int i0 = 0; i0 < n_it; i0 += 64) {
-            lds[0][lane] = term(kind0, i0 + lane);
-            lds[1][lane] = term(kind1, i0 + lane);
+        /* software pipeline: the terms of tile t + 1 are loaded and computed while the two chain lanes add tile t (64 dependent
+         * v_add_f64 ~ 0.3 us, about the latency of the loads); two LDS buffers, one barrier per tile */
+        double t0 = term(kind0, lane), t1 = term(kind1, lane);
+        int buf = 0;
+        for (int i0 = 0; i0 < n_it; i0 += 64, buf ^= 1) {
+            lds[buf][0][lane] = t0;
+            lds[buf][1][lane] = t1;
             __syncthreads();
+            if (i0 + 64 < n_it) { t0 = term(kind0, i0 + 64 + lane); t1 = term(kind1, i0 + 64 + lane); }
             if (lane < 2) {
-                const double2* col = reinterpret_cast<const double2*>(lds[lane]);
+                const double2* col = reinterpret_cast<const double2*>(lds[buf][lane]);
                 #pragma unroll
                 for (int q = 0; q < 32; q += 4) {
                     const double2 a = col[q], b = col[q + 1], c2 = col[q + 2], d2 = col[q + 3];
                     acc += a.x; acc += a.y; acc += b.x; acc += b.y; acc += c2.x; acc += c2.y; acc += d2.x; acc += d2.y;
                 }
             }
-            __syncthreads();
         }
+        __syncthreads();
         out0 = __shfl(acc, 0, 64); out1 = __shfl(acc, 1, 64);
     };
     double ev_sum = ps_e, km_sum = ps_k, unused = 0.0;

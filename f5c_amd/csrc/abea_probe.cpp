@@ -41,9 +41,13 @@ extern "C" int abea_link_probe(abea_ctx* c, uint64_t bytes, int32_t reps, double
     uint8_t* d_up = c->arena;
     uint8_t* d_dn = c->arena + bytes;
     const size_t n16 = bytes / 16;
-    const dim3 grid((unsigned)std::min<size_t>(512, (n16 + 255) / 256));
+    const dim3 grid((unsigned)std::min<size_t>((size_t)abea_copy_kernel_blocks(), (n16 + 255) / 256));
     auto up = [&]() { return hipMemcpyAsync(d_up, R.h_up, bytes, hipMemcpyHostToDevice, R.s_up); };
     auto dn_sdma = [&]() { return hipMemcpyAsync(R.h_dn, d_dn, bytes, hipMemcpyDeviceToHost, R.s_dn); };
+    auto up_kernel = [&]() {                             /* the same kernel, loading from pinned host memory */
+        hipLaunchKernelGGL(abea_copy_out_kernel, grid, dim3(256), 0, R.s_up, (const uint4*)R.h_up, (uint4*)d_up, n16);
+        return hipGetLastError();
+    };
     auto dn_kernel = [&]() {
         hipLaunchKernelGGL(abea_copy_out_kernel, grid, dim3(256), 0, R.s_dn, (const uint4*)d_dn, (uint4*)R.h_dn, n16);
         return hipGetLastError();
@@ -54,7 +58,8 @@ extern "C" int abea_link_probe(abea_ctx* c, uint64_t bytes, int32_t reps, double
             if (mode_up) HIP_TRY(hipEventRecord(R.e[0], R.s_up));
             if (mode_dn) HIP_TRY(hipEventRecord(R.e[2], R.s_dn));
             for (int r = 0; r < (warm ? reps : 1); ++r) {
-                if (mode_up) HIP_TRY(up());
+                if (mode_up == 1) HIP_TRY(up());
+                if (mode_up == 2) HIP_TRY(up_kernel());
                 if (mode_dn == 1) HIP_TRY(dn_sdma());
                 if (mode_dn == 2) HIP_TRY(dn_kernel());
             }
@@ -75,5 +80,9 @@ extern "C" int abea_link_probe(abea_ctx* c, uint64_t bytes, int32_t reps, double
     if (!rc) rc = run(0, 2, &dummy, &out[2]);            /* d2h, abea_copy_out_kernel (stores straight into pinned host memory) */
     if (!rc) rc = run(1, 2, &out[3], &out[4]);           /* both at once: h2d by copy engine, d2h by kernel (what the pipelines do) */
     if (!rc) rc = run(1, 1, &out[5], &out[6]);           /* both at once, both by copy engine */
+    if (!rc && n_out >= 10) {
+        rc = run(2, 0, &out[7], &dummy);                 /* h2d by kernel (loads from pinned host memory) */
+        if (!rc) rc = run(2, 1, &out[8], &out[9]);       /* both at once: h2d by kernel, d2h by copy engine */
+    }
     return rc;
 }

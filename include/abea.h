@@ -396,7 +396,9 @@ int abea_host_plan_threads(int32_t usable_cpus, const char* allowed_cpulist, int
  * per transfer, 0 = 256 MiB; `reps` transfers per measurement, 0 = 4).  GB/s (1e9 bytes) into out[0..7):
  *   [0] host->device, hipMemcpyAsync            [1] device->host, hipMemcpyAsync        [2] device->host, abea_copy_out_kernel
  *   [3], [4] host->device (copy engine) and device->host (kernel) while both run at once — what the chunk pipelines do
- *   [5], [6] the same with both directions on the copy engines.
+ *   [5], [6] the same with both directions on the copy engines
+ *   [7] host->device by the copy kernel (loads from pinned host memory); [8], [9] host->device by kernel and device->host by copy
+ *   engine at once (written when n_out >= 10).
  * The raw-signal entries move 2 B per sample up and 24 B per event down (event_db, src/f5c.c:682-734): bench.py sets their
  * measured rates against these ceilings.  Diagnostic; nothing in the library depends on it. */
 int abea_link_probe(abea_ctx* ctx, uint64_t bytes, int32_t reps, double* out, int32_t n_out);

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """profiles/pmc_traffic.json from the committed rocprofv3 PMC passes of `bench.py --mode device` (tools/profile_r03.sh):
    python profiles/make_pmc_traffic.py profiles/r03/a_      (prefix of the *_counter_collection.csv files)
+   python profiles/make_pmc_traffic.py detector profiles/r06/ <samples per call>     (adds the "detector" entry: the abea_ev_* kernels)
 Every number of the json is an average over the abea_align_kernel dispatches of one pass; nothing is inferred from another
 config.  Corrections / definitions (MI355X_MICROARCH.md, HBM and rocprofv3 sections):
   hbm bytes   = FETCH_SIZE(KB) x 1024 x 2  (gfx950 tallies the 128-B requests of wide coalesced reads at 64 B)  +  WRITE_SIZE(KB) x 1024
@@ -91,5 +92,45 @@ def main(prefix):
         print(k, {x: (round(v, 4) if isinstance(v, float) else v) for x, v in e.items() if not isinstance(v, dict)})
 
 
+def detector(prefix, samples_per_call):
+    """pmc_traffic.json["detector"]: HBM bytes per SAMPLE of every abea_ev_* kernel of one DNA call of tools/n2_profile.py (2048 reads)
+    from its FETCH_SIZE / WRITE_SIZE passes: `prefix`n2_fetch_counter_collection.csv, `prefix`n2_write_counter_collection.csv.  The
+    script runs the DNA parameters twice, then the RNA parameters twice: the first two dispatches of each kernel are averaged."""
+    def first_two(path, counter):
+        acc = collections.defaultdict(list)
+        for r in csv.DictReader(open(path)):
+            if r["Kernel_Name"].startswith("abea_ev_") and r["Counter_Name"] == counter:
+                acc[r["Kernel_Name"].split("(")[0]].append((int(r["Dispatch_Id"]), float(r["Counter_Value"]),
+                                                           (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6))
+        out = {}
+        for k, v in acc.items():
+            v.sort()
+            per_call = len(v) // 4                       # launches per detector call (sub-batches)
+            take = v[:2 * per_call]
+            out[k] = (sum(x[1] for x in take) / 2, sum(x[2] for x in take) / 2)
+        return out
+    f, w = first_two(prefix + "n2_fetch_counter_collection.csv", "FETCH_SIZE"), first_two(prefix + "n2_write_counter_collection.csv", "WRITE_SIZE")
+    per = {}
+    for k in sorted(set(f) | set(w)):
+        fb, wb = f.get(k, (0, 0))[0] * 2048, w.get(k, (0, 0))[0] * 1024
+        per[k] = {"fetch_x2_bytes_per_sample": round(fb / samples_per_call, 3), "write_bytes_per_sample": round(wb / samples_per_call, 3),
+                  "kernel_ms": round(f.get(k, w.get(k))[1], 3)}
+    import hashlib
+    data = open(os.path.join(ROOT, "f5c_amd/csrc/abea_kernels.hip"), "rb").read()
+    sha = hashlib.sha256(data[data.find(ALIGN_SECTION_END):]).hexdigest()
+    total = sum(v["fetch_x2_bytes_per_sample"] + v["write_bytes_per_sample"] for v in per.values())
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "pmc_traffic.json")
+    j = json.load(open(path))
+    j["detector"] = {"kernels": "abea_ev_*", "samples_per_call": samples_per_call, "hbm_bytes_per_sample": round(total, 3), "per_kernel": per,
+                     "code_sha256": sha, "code_sha256_of": "f5c_amd/csrc/abea_kernels.hip from the event-detection banner to the end",
+                     "passes": {"fetch": prefix + "n2_fetch_counter_collection.csv", "write": prefix + "n2_write_counter_collection.csv"},
+                     "command": "tools/n2_profile.py 2048 (DNA parameters, first two calls)"}
+    json.dump(j, open(path, "w"), indent=1)
+    print("detector", round(total, 2), "B per sample;", {k: round(v["fetch_x2_bytes_per_sample"] + v["write_bytes_per_sample"], 2) for k, v in per.items()})
+
+
 if __name__ == "__main__":
-    main(sys.argv[1] if len(sys.argv) > 1 else "profiles/r03/a_")
+    if len(sys.argv) > 3 and sys.argv[1] == "detector":
+        detector(sys.argv[2], int(sys.argv[3]))
+    else:
+        main(sys.argv[1] if len(sys.argv) > 1 else "profiles/r03/a_")

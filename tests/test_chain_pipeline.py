@@ -217,3 +217,12 @@ def test_arena_limit_closes_chunks_and_whole_waves_are_charged(orc, r9, monkeypa
         with pytest.raises(abea.AbeaError, match="does not fit a .* share of the arena"):
             c2.events_view(v)
         assert (v["ev_pp"] == 0).all()
+
+
+@pytest.mark.gpu
+def test_link_probe_reports_both_directions(ctx):
+    """abea_link_probe: the ceilings bench.py prices the raw-signal entries against; sane on any PCIe generation."""
+    r = ctx.link_probe(64 << 20, 2)
+    assert set(r) == {"h2d_copy", "d2h_copy", "d2h_kernel", "both_h2d_copy", "both_d2h_kernel", "both_copy_h2d", "both_copy_d2h",
+                      "h2d_kernel", "both_h2d_kernel", "both_d2h_copy"}
+    assert all(1.0 < v < 200.0 for v in r.values()), r

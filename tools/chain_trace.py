@@ -5,7 +5,8 @@ the tables' trip down in ONE process on ONE set of signals, the per-call host sp
 ABEA_HOST_TRACE — the chunk timeline on stderr.  Two steps so that no generator pool runs under rocprofv3:
     python tools/chain_trace.py 10000 /tmp/ct                       # generates the batch (16 workers) and saves it
     [rocprofv3 --kernel-trace --stats ... --] python tools/chain_trace.py 10000 /tmp/ct [mode ...]
-mode = format:mover[:trace][:dN], e.g. packed:kernel full:engine:trace packed:engine:d2 (dN = ABEA_CHAIN_DEPTH, chunks in flight);
+mode = format:mover[:trace][:dN][:bN][:uk], e.g. packed:kernel full:engine:trace packed:engine:d2 packed:kernel:b32:uk (dN = ABEA_CHAIN_DEPTH,
+chunks in flight; bN = ABEA_CHAIN_COPY_BLOCKS, workgroups of a copy kernel; uk = ABEA_CHAIN_UP=kernel, the signal comes up by kernel);
 default = all four without a trace."""
 import os, sys, time
 import numpy as np
@@ -32,6 +33,11 @@ print(f"{n} reads, {n_smp/1e6:.1f} Msamples, signals in {time.time()-t0:.1f} s",
 ctx = abea.AbeaContext(model, k, max_arena_bytes=150 << 30)
 link = ctx.link_probe()
 print("link GB/s:", link, flush=True)
+for blocks in (8, 16, 64, 512):
+    os.environ["ABEA_CHAIN_COPY_BLOCKS"] = str(blocks)
+    lk = ctx.link_probe()
+    print(f"link GB/s with {blocks:3d}-workgroup copy kernels:", {k_: v for k_, v in lk.items() if "kernel" in k_ or k_ == "both_d2h_copy" or k_ == "both_h2d_copy"}, flush=True)
+os.environ.pop("ABEA_CHAIN_COPY_BLOCKS", None)
 
 
 def digest(v):
@@ -48,9 +54,12 @@ for mode in modes:
     parts = mode.split(":")
     os.environ["ABEA_CHAIN_TABLE_FORMAT"], os.environ["ABEA_CHAIN_TABLE_COPY"] = parts[0], parts[1]
     trace = "trace" in parts[2:]
-    depth = [x[1:] for x in parts[2:] if x.startswith("d") and x[1:].isdigit()]
-    if depth: os.environ["ABEA_CHAIN_DEPTH"] = depth[0]
-    else: os.environ.pop("ABEA_CHAIN_DEPTH", None)
+    for key, var in (("d", "ABEA_CHAIN_DEPTH"), ("b", "ABEA_CHAIN_COPY_BLOCKS")):      # dN = chunks in flight, bN = workgroups of a copy kernel
+        val = [x[1:] for x in parts[2:] if x.startswith(key) and x[1:].isdigit()]
+        if val: os.environ[var] = val[0]
+        else: os.environ.pop(var, None)
+    if "uk" in parts[2:]: os.environ["ABEA_CHAIN_UP"] = "kernel"                       # uk = the signal comes up by the copy kernel
+    else: os.environ.pop("ABEA_CHAIN_UP", None)
     for entry in ("events", "process"):
         v = ctx.signal_view(sig, sp, ns, sc, batch=b)
         call = ctx.events_view if entry == "events" else ctx.process_view

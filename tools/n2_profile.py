@@ -16,6 +16,6 @@ ctx = abea.AbeaContext(model, k, mem_frac=0.5)
 for rna in (False, False, True, True):
     evs, ne, scal = ctx.detect_events_device(sigs, sc, seqs=seqs, rna=rna)
     ms = ctx.stats()["event_ms"]
-    print(f"{'RNA' if rna else 'DNA'} parameters: {n} reads, {ns/1e6:.1f} Msamples, {int(ne.sum())/1e6:.2f} Mevents: kernels {ms:.2f} ms = "
+    print(f"{'RNA' if rna else 'DNA'} parameters: {n} reads, samples={ns} ({ns/1e6:.1f} Msamples), {int(ne.sum())/1e6:.2f} Mevents: kernels {ms:.2f} ms = "
           f"{ns/ms/1e3:.1f} Msamples/s, {ne.sum()/ms/1e3:.1f} Mevents/s", flush=True)
 ctx.close()

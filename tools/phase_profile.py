@@ -7,13 +7,14 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from f5c_amd import abea, synth, load_model_f32
 ap = argparse.ArgumentParser(); ap.add_argument("--reads", type=int, default=10000); ap.add_argument("--config", default="r9_10k_8kb")
+ap.add_argument("--scaling", action="store_true", help="fused scaling_single on: reports phase 4's share of the wave time (diag.pad of the profile build)")
 a = ap.parse_args()
 cfg = synth.CONFIGS[a.config]
 k, model = load_model_f32("tests/golden/r9.4_450bps.6mer.f32")
 b = synth.make_batch(a.reads, model, k, seed=cfg["seed"], law=cfg["law"], workers=32)
 d = abea.AbeaContext.upload(b)
 ctx = abea.AbeaContext(model, k)
-ctx.align_db_device(d); ctx.align_db_device(d)
+ctx.align_db_device(d, scaling=a.scaling); ctx.align_db_device(d, scaling=a.scaling)
 st = ctx.stats()
 _, n_pairs, dg = ctx.download(d)
 ok = dg["n_aligned"] > 0
@@ -23,6 +24,13 @@ base = t0.min(); end = (t0 + fill + walk + exp)
 tick = 10e-9
 print(f"kernel {st['fill_ms']:.2f} ms; span by timestamps {(end.max()-base)*tick*1e3:.2f} ms; reads {ok.sum()}")
 print(f"sum fill {fill.sum()*tick*1e3:.1f} ms-wave, walk {walk.sum()*tick*1e3:.1f}, expand {exp.sum()*tick*1e3:.1f}")
+if a.scaling:
+    sel = n_pairs[ok] > 0
+    p4 = (dg["pad"][ok].astype(np.float64) - exp)[sel]
+    kk = (b["read_len"] - k + 1)[ok][sel].astype(np.float64)
+    tot = fill.sum() + walk.sum() + exp.sum() + p4.sum()
+    print(f"phase 4 (scaling_single): sum {p4.sum()*tick*1e3:.1f} ms-wave = {100*p4.sum()/tot:.2f} % of the wave time; per k-mer median {np.median(p4/kk)*10:.1f} ns, "
+          f"per 64 k-mers {np.median(p4/kk)*640:.0f} ns")
 print(f"per band: median {np.median(fill/bands)*10:.1f} ns, p10 {np.percentile(fill/bands,10)*10:.1f}, p90 {np.percentile(fill/bands,90)*10:.1f}")
 print(f"per step: median {np.median(walk/steps)*10:.1f} ns, p10 {np.percentile(walk/steps,10)*10:.1f}, p90 {np.percentile(walk/steps,90)*10:.1f}")
 print(f"expand per step: median {np.median(exp/steps)*10:.1f} ns")
