@@ -513,11 +513,12 @@ void unpack_events(const uint32_t* rec, size_t ne, uint64_t n_samples, bool rna,
     for (size_t p = 0; p < ne; ++p) {
         const uint64_t start = rec[3 * p];
         const uint64_t end = !rna ? (p + 1 < ne ? (uint64_t)rec[3 * (p + 1)] : n_samples) : (p > 0 ? (uint64_t)rec[3 * (p - 1)] : n_samples);
-        abea_event_t e;
-        e.start = start;
-        e.length = (float)(end - start);
-        memcpy(&e.mean, rec + 3 * p + 1, 4); memcpy(&e.stdv, rec + 3 * p + 2, 4);
-        out[p] = e;
+        /* three 8-byte words: event_t is 20 bytes of fields + 4 of tail padding, written as zero (a caller that dumps or compares
+         * whole structs must not see stack garbage there) */
+        const float length = (float)(end - start);
+        uint32_t lb; memcpy(&lb, &length, 4);
+        const uint64_t w[3] = {start, (uint64_t)lb | ((uint64_t)rec[3 * p + 1] << 32), (uint64_t)rec[3 * p + 2]};
+        memcpy(out + p, w, sizeof w);
     }
 }
 

@@ -32,6 +32,8 @@ case $STAGE in
   phase4)     # where the fused scaling_single phase spends its wave time (profile build: make -C f5c_amd/csrc prof)
     ABEA_LIB_PATH=build/libabea_prof.so step phase_profile 300 python tools/phase_profile.py --scaling --reads 10000
     grep -v "^  t=\|^  [0-9]" $O/phase_profile.log | tail -12
+    ABEA_LIB_PATH=build/libabea_prof.so step phase_profile_align_only 300 python tools/phase_profile.py --reads 10000
+    grep "^kernel\|^sum" $O/phase_profile_align_only.log
     ;;
   n2prof)     # the detector alone (device entry, 2048 reads): kernel trace + HBM counters of its kernels (separate passes)
     step n2_kt 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/n2 -o n2 -- python tools/n2_profile.py 2048
