@@ -604,9 +604,29 @@ def detector_roofline(ctx, sub, sig, sp, ns, sc, n_reads=2048):
                 "reads": m, "samples": n_smp, "events": n_ev, "kernels_ms": round(ms, 3), "gsamples_per_s": round(n_smp / ms / 1e6, 2),
                 "algorithmic_bytes_per_launch": int(a), "algorithmic_bytes_per_sample": round(a / n_smp, 2),
                 "traffic": int(t["hbm_bytes_per_sample"] * n_smp) if t else None,
+                "traffic_over_algorithmic": round(t["hbm_bytes_per_sample"] * n_smp / a, 2) if t else None,
+                "dominant_kernels": detector_kernel_rooflines(t) if t else None,
                 "traffic_per_kernel_bytes_per_sample": t.get("per_kernel") if t else None, "traffic_source": t.get("passes") if t else None}
     except Exception as ex:                                # never fail the bench line for an extra
         return {"error": repr(ex)}
+
+
+def detector_kernel_rooflines(t):
+    """The two streaming kernels of the detector against the HBM roofline, from the committed passes alone (static): algorithmic bytes
+    per sample (abea_ev_pwrite_kernel: 2 B of signal in, the 16-byte {S, Q} prefix-sum pair out; abea_ev_tstat_kernel: that pair in,
+    two float t-statistics out), counter bytes per sample (FETCH_SIZE x 2 + WRITE_SIZE) and the rate the counters imply over the
+    kernel's duration in the same passes."""
+    out = {}
+    for name, alg in (("abea_ev_pwrite_kernel", 18.0), ("abea_ev_tstat_kernel", 24.0)):
+        k_ = t["per_kernel"].get(name)
+        if not k_:
+            continue
+        moved = k_["fetch_x2_bytes_per_sample"] + k_["write_bytes_per_sample"]
+        gbs = moved * t["samples_per_call"] / (k_["kernel_ms"] * 1e-3) / 1e9
+        out[name] = {"bound": "hbm", "algorithmic_bytes_per_sample": alg, "counter_bytes_per_sample": round(moved, 2),
+                     "kernel_ms": k_["kernel_ms"], "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(gbs / HBM_PEAK_GBS, 4), "static": True}
+    return out
 
 
 def detector_code_sha():

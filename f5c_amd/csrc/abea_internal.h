@@ -168,11 +168,10 @@ static inline void plan_desc(abea_read_desc& d, const plan_read& r, const abea_s
 }
 
 int ensure_pinned(void** p, size_t* cap, size_t need);
-/* workgroups of an abea_copy_out_kernel launch that moves a LARGE block across PCIe (the raw-signal pipeline's tables and signals).
- * A wave whose stores sit in front of the PCIe link holds its CU's memory pipeline: with the copy spread over 512 workgroups every
- * CU of the chip had such waves and the detector's kernels of the neighbouring chunks ran 2.7 x longer (round 6,
- * profiles/r06/chain_*); a few dozen workgroups keep the link just as busy (16 B x 256 lanes x 32 blocks = 128 KiB in flight) and
- * leave the other CUs alone.  ABEA_CHAIN_COPY_BLOCKS overrides. */
+/* workgroups of an abea_copy_out_kernel launch that moves a LARGE block across PCIe (the raw-signal pipeline's tables, when
+ * ABEA_CHAIN_TABLE_COPY=kernel, or its signals, ABEA_CHAIN_UP=kernel; abea_link_probe's kernel legs).  32 workgroups keep the link
+ * as busy as 512 (16 B x 256 lanes x 32 = 128 KiB in flight: profiles/r06/c_chain_movers_copy_kernel_width_ab.log, link probe at 8 /
+ * 16 / 64 / 512) and occupy an eighth of the CUs.  ABEA_CHAIN_COPY_BLOCKS overrides. */
 static inline int abea_copy_kernel_blocks() {
     const char* e = getenv("ABEA_CHAIN_COPY_BLOCKS");
     return e ? std::max(1, std::min(4096, atoi(e))) : 32;
