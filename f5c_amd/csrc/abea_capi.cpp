@@ -100,6 +100,18 @@ extern "C" int abea_init(abea_ctx** out, const abea_cfg* cfg) {
     const size_t n_model = (size_t)1 << (2 * cfg->kmer_size);
     INIT_TRY(hipMalloc(&c->d_model, n_model * sizeof(abea_model_t)));
     INIT_TRY(hipMemcpy(c->d_model, cfg->model, n_model * sizeof(abea_model_t), hipMemcpyHostToDevice));
+    {   /* the model-only terms of recalibrate_model's normal equations (align.c:697-706), once per model entry, with the
+         * reference's own double expressions (this file is built -ffp-contract=off; IEEE division on both sides) */
+        std::vector<double> mt(n_model * 3);
+        for (size_t r = 0; r < n_model; ++r) {
+            const double level_mean = cfg->model[r].level_mean, level_stdv = cfg->model[r].level_stdv;
+            const double inv_var = 1. / (level_stdv * level_stdv);
+            const double mu = level_mean;
+            mt[3 * r] = inv_var; mt[3 * r + 1] = mu * inv_var; mt[3 * r + 2] = mu * mu * inv_var;
+        }
+        INIT_TRY(hipMalloc(&c->d_mterms, mt.size() * sizeof(double)));
+        INIT_TRY(hipMemcpy(c->d_mterms, mt.data(), mt.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
     /* one-shot arena (f5c.cu:110-199 sizes its arrays once from free memory x MEM_FACTOR) */
     size_t free_b = 0, total_b = 0;
     INIT_TRY(hipMemGetInfo(&free_b, &total_b));
@@ -164,7 +176,7 @@ extern "C" void abea_free(abea_ctx* c) {
         abea_host_release(c);
         abea_chain_release(c);
         abea_hmm_release(c);
-        hipFree(c->d_model); hipFree(c->arena);
+        hipFree(c->d_model); hipFree(c->d_mterms); hipFree(c->arena);
         hipHostFree(c->h_desc);
         for (auto& e : c->ev) if (e) hipEventDestroy(e);
         if (c->stream) hipStreamDestroy(c->stream);
@@ -312,7 +324,7 @@ extern "C" int abea_align_batch_device(abea_ctx* c, const abea_device_batch* B) 
         while (end < seq.size()) {
             const plan_read& r = reads[(size_t)seq[end]];
             const size_t need = (r.run ? scratch_bytes(r) : sizeof(abea_read_desc)) + 4;
-            if (bytes + need + 65536 > c->arena_bytes) break;
+            if (bytes + need + 65536 + 256 > c->arena_bytes) break;
             bytes += need; ++end;
         }
         if (end == pos)
@@ -337,6 +349,7 @@ extern "C" int abea_align_batch_device(abea_ctx* c, const abea_device_batch* B) 
         uint8_t* p = c->arena;
         abea_read_desc* d_desc = (abea_read_desc*)p;        p += align_up(m * sizeof(abea_read_desc), 256);
         abea_kpar_t* d_kpar = (abea_kpar_t*)p;              p += align_up(n_kpar * sizeof(abea_kpar_t), 256);
+        uint32_t* d_krank = (uint32_t*)p;                   p += align_up(n_kpar * 4, 256);     /* k-mer ranks for phase 4 (fused scaling only) */
         float* d_evm = (float*)p;                           p += align_up(n_evm * 4 + 512, 256);
         uint32_t* d_codes = (uint32_t*)p;                   p += align_up(n_code * 4, 256);
         uint4* d_trace = (uint4*)p;                         p += n_trace * sizeof(uint4);
@@ -346,7 +359,8 @@ extern "C" int abea_align_batch_device(abea_ctx* c, const abea_device_batch* B) 
         HIP_TRY(hipMemcpyAsync(d_desc, c->h_desc, m * sizeof(abea_read_desc), hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipEventRecord(c->ev[0], c->stream));
         hipLaunchKernelGGL(abea_pre_kernel, dim3((unsigned)m), dim3(256), 0, c->stream,
-                           d_desc, B->reads, B->events, c->d_model, (int)c->k, d_kpar, d_evm);
+                           d_desc, B->reads, B->events, c->d_model, (int)c->k, d_kpar, d_evm,
+                           B->base_to_event_map ? d_krank : (uint32_t*)nullptr);
         HIP_TRY(hipEventRecord(c->ev[1], c->stream));
         abea_fused_scaling fs;                               /* row N1: scaling_single as the last phase of the kernel */
         memset(&fs, 0, sizeof fs);
@@ -355,6 +369,7 @@ extern "C" int abea_align_batch_device(abea_ctx* c, const abea_device_batch* B) 
             fs.epb = B->events_per_base; fs.flag_io = B->read_stat_flag; fs.nalign = B->n_event_alignment;
             fs.kmer_size = (int32_t)c->k;
             fs.min_rescale = B->min_num_events_to_rescale > 0 ? B->min_num_events_to_rescale : 200;
+            fs.krank = d_krank; fs.mterms = c->d_mterms;
         }
         hipLaunchKernelGGL(abea_align_kernel, dim3((unsigned)m), dim3(64), 0, c->stream,
                            d_desc, d_evm, d_kpar, d_trace, d_codes, B->pairs, B->n_pairs, B->diag,

@@ -447,6 +447,7 @@ int stage_align(chain_state& S, abea_chain_slot& sl) {
     uint8_t* p = sl.d_rest;
     abea_read_desc* d_desc = (abea_read_desc*)p;       p += align_up((size_t)m * sizeof(abea_read_desc), 256);
     abea_kpar_t* d_kpar = (abea_kpar_t*)p;             p += align_up(lay.n_kpar * sizeof(abea_kpar_t), 256);
+    uint32_t* d_krank = (uint32_t*)p;                  p += align_up(lay.n_kpar * 4, 256);
     float* d_evm = (float*)p;                          p += align_up(lay.n_evm * 4 + 512, 256);
     uint4* d_trace = (uint4*)p;                        p += align_up(lay.n_trace * sizeof(uint4), 256);
     uint8_t* d_dn = p;                                 p += sl.dn_copy;
@@ -471,7 +472,7 @@ int stage_align(chain_state& S, abea_chain_slot& sl) {
     S.st.h2d_bytes += (size_t)m * (sizeof(abea_read_desc) + sizeof(abea_scalings_t) + 4);
     const char* d_reads = (const char*)(sl.d_up + sl.o_seq);
     hipLaunchKernelGGL(abea_pre_kernel, dim3((unsigned)m), dim3(256), 0, sl.stream,
-                       (const abea_read_desc*)d_desc, d_reads, (const abea_event_t*)sl.d_ev, c->d_model, (int)c->k, d_kpar, d_evm);
+                       (const abea_read_desc*)d_desc, d_reads, (const abea_event_t*)sl.d_ev, c->d_model, (int)c->k, d_kpar, d_evm, d_krank);
     HIP_TRY(hipEventRecord(sl.t3, sl.stream));
     abea_fused_scaling fs;
     memset(&fs, 0, sizeof fs);
@@ -480,6 +481,7 @@ int stage_align(chain_state& S, abea_chain_slot& sl) {
     fs.flag_io = (int32_t*)(d_dn + sl.o_flag); fs.nalign = (int32_t*)(d_dn + sl.o_nal);
     fs.kcnt = (uint8_t*)(d_dn + sl.o_kcnt); fs.var_f64 = (double*)(d_dn + sl.o_var);
     fs.kmer_size = (int32_t)c->k; fs.min_rescale = J->min_num_events_to_rescale > 0 ? J->min_num_events_to_rescale : 200;
+    fs.krank = d_krank; fs.mterms = c->d_mterms;
     hipLaunchKernelGGL(abea_align_kernel, dim3((unsigned)m), dim3(64), 0, sl.stream,
                        (const abea_read_desc*)d_desc, (const float*)d_evm, (const abea_kpar_t*)d_kpar, d_trace,
                        (uint32_t*)(d_dn + sl.o_codes), (abea_pair_t*)nullptr, (int32_t*)(d_dn + sl.o_np),

@@ -51,6 +51,12 @@ typedef struct {
     double* var_f64;                    /* optional [out_idx]: recalibrate_model's var in double when the read was recalibrated, -1 otherwise:
                                            the host entries set scalings_t.log_var = (float)log(var) from it with glibc (align.c:760) */
     int32_t kmer_size, min_rescale;
+    /* round 6: what phase 4 used to re-derive per k-mer and sweep.  krank[desc.kpar_off + k] = the k-mer's rank, left by align-pre
+     * (which has it in a register anyway); mterms[3 * rank + {0, 1, 2}] = 1/sd^2, mu/sd^2... exactly: inv_var = 1. / (sd * sd),
+     * mu * inv_var, mu * mu * inv_var in double for every model entry — the three normal-equation terms of align.c:697-706 that
+     * depend on the model alone, computed once at abea_init with the reference's expressions. */
+    const uint32_t* krank;
+    const double* mterms;
 } abea_fused_scaling;
 
 #endif

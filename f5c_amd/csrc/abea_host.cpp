@@ -1153,6 +1153,7 @@ static int host_run(abea_ctx* c, const abea_host_batch* H, const int32_t* mine, 
         uint8_t* p = arena;
         uint8_t* d_up = p;                                  p += u_end;
         abea_kpar_t* d_kpar = (abea_kpar_t*)p;              p += align_up(lay.n_kpar * sizeof(abea_kpar_t), 256);
+        uint32_t* d_krank = (uint32_t*)p;                   p += align_up(lay.n_kpar * 4, 256);     /* k-mer ranks for phase 4 */
         uint4* d_trace = (uint4*)p;                         p += align_up(lay.n_trace * sizeof(uint4), 256);
         uint8_t* d_dn = p;                                  p += dn_copy;
         uint32_t* d_codes_scratch = nullptr;                /* codes stay on the device when nobody wants them */
@@ -1224,7 +1225,8 @@ static int host_run(abea_ctx* c, const abea_host_batch* H, const int32_t* mine, 
         }
         HIP_TRY(hipEventRecord(sl.k0, sl.stream));
         hipLaunchKernelGGL(abea_pre_kernel, dim3((unsigned)m), dim3(256), 0, sl.stream,
-                           d_desc, d_reads, (const abea_event_t*)nullptr, c->d_model, (int)c->k, d_kpar, d_evm);
+                           d_desc, d_reads, (const abea_event_t*)nullptr, c->d_model, (int)c->k, d_kpar, d_evm,
+                           scaling ? d_krank : (uint32_t*)nullptr);
         HIP_TRY(hipEventRecord(sl.k1, sl.stream));
         /* scaling_single, when requested, is the last phase of the alignment kernel: the wavefront that aligned a read builds
          * its base_to_event_map and recalibrates its scalings (round 4; rounds 1-3 launched one / two kernels behind it, which
@@ -1238,6 +1240,7 @@ static int host_run(abea_ctx* c, const abea_host_batch* H, const int32_t* mine, 
             fs.kcnt = (uint8_t*)(d_dn + sl.o_cnt);
             fs.var_f64 = (double*)(d_dn + sl.o_var);
             fs.kmer_size = (int32_t)c->k; fs.min_rescale = min_rescale;
+            fs.krank = d_krank; fs.mterms = c->d_mterms;
         }
         hipLaunchKernelGGL(abea_align_kernel, dim3((unsigned)m), dim3(64), 0, sl.stream,
                            d_desc, d_evm, d_kpar, d_trace, d_codes, d_pairs, d_np, d_diag,

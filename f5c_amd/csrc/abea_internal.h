@@ -18,7 +18,7 @@
 extern "C" {
 __global__ void abea_selftest_kernel(int* out);
 __global__ void abea_pre_kernel(const abea_read_desc*, const char*, const abea_event_t*, const abea_model_t*, int,
-                                abea_kpar_t*, float*);
+                                abea_kpar_t*, float*, uint32_t*);
 __global__ void abea_align_kernel(const abea_read_desc*, const float*, const abea_kpar_t*, uint4*, uint32_t*,
                                   abea_pair_t*, int32_t*, abea_read_diag*, unsigned long long*, int64_t*, const abea_fused_scaling);
 __global__ void abea_copy_out_kernel(const uint4*, uint4*, size_t);
@@ -51,6 +51,7 @@ struct abea_ctx {
     int verbosity = 0;
     hipStream_t stream = nullptr;
     abea_model_t* d_model = nullptr;
+    double* d_mterms = nullptr;              /* 3 doubles per model entry: the model-only terms of recalibrate_model (abea_fused_scaling.mterms) */
     uint8_t* arena = nullptr;      size_t arena_bytes = 0;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     /* pinned staging for descriptors (device entry, event detection) */
@@ -142,7 +143,7 @@ static inline plan_read make_plan(int32_t idx, int32_t L, int32_t E, uint32_t k)
 /* per-read scratch bytes (kpar, evm, codes, trace, desc) */
 static inline size_t scratch_bytes(const plan_read& r) {
     const size_t n_groups = (size_t)(r.n_bands + ABEA_GROUP - 1) / ABEA_GROUP;
-    return align_up((size_t)r.K * sizeof(abea_kpar_t), 16) + align_up((size_t)r.E * 4 + 256, 16) +
+    return align_up((size_t)r.K * (sizeof(abea_kpar_t) + 4), 16) + align_up((size_t)r.E * 4 + 256, 16) +      /* kpar + the rank array behind it */
            align_up(((size_t)(r.E + r.K) / 16 + 2) * 4, 16) + n_groups * 64 * sizeof(uint4) +
            sizeof(abea_read_desc);
 }

@@ -117,13 +117,14 @@ extern "C" __global__ __launch_bounds__(256)
 void abea_pre_kernel(const abea_read_desc* __restrict__ descs,
                      const char* __restrict__ reads, const abea_event_t* __restrict__ events,
                      const abea_model_t* __restrict__ model, int kmer_size,
-                     abea_kpar_t* __restrict__ kpar_all, float* __restrict__ evm_all) {
+                     abea_kpar_t* __restrict__ kpar_all, float* __restrict__ evm_all, uint32_t* __restrict__ krank_all) {
     const abea_read_desc* d = descs + blockIdx.x;
     if (d->n_groups == 0) return;                      /* skipped read */
     const int K = d->n_kmers, E = d->n_events;
     const float scale = d->scale, shift = d->shift;
     const char* seq = reads + d->read_off;
     abea_kpar_t* kp = kpar_all + d->kpar_off;
+    uint32_t* const kr = krank_all ? krank_all + d->kpar_off : nullptr;     /* the ranks, for phase 4 of a fused launch */
     const int L = K + kmer_size - 1;
     for (int i = threadIdx.x; i < K; i += blockDim.x) {
         const uint32_t rank = kmer_rank_at(seq, i, L, kmer_size);
@@ -133,6 +134,7 @@ void abea_pre_kernel(const abea_read_desc* __restrict__ descs,
         p.ck   = __fsub_rn(-0.918938f, m.level_log_stdv);            /* align.c:111-113 */
         p.istd = 1.0 / (double)m.level_stdv;
         kp[i] = p;
+        if (kr) kr[i] = rank;
     }
     if (!events) return;                               /* host path: the means were uploaded straight into evm */
     const abea_event_t* ev = events + d->event_off;
@@ -224,17 +226,16 @@ static __device__ __forceinline__ double chain64(const double* col, int cnt, dou
  * Round 6 (the "diet"): rounds 4-5 swept the k-mers twice, and each sweep recomputed every k-mer's rank base by base (the compiler
  * had made four branches and a full memory wait out of every base), reloaded the map and gathered the model again.  Now the first
  * sweep leaves one 16-byte record {level_mean, level_stdv, event mean} per 'M' state, in 'M'-state order, in the trace scratch,
- * and the variance pass reads those records DENSELY, 64 'M' states per step — no ranks, no map, no ballots —, the ranks of the first
- * sweep come from one 12-byte load per lane, and every chain takes its terms from LDS 16 bytes at a time. */
+ * and the variance pass reads those records DENSELY, 64 'M' states per step — no ranks, no map, no ballots —; the ranks come from
+ * the array align-pre leaves behind the k-mer parameters (it has every rank in a register anyway), the three normal-equation
+ * terms that depend on the model alone from a table built at abea_init with the reference's expressions, and every chain takes
+ * its terms from LDS 16 bytes at a time. */
 #define ABEA_P4_COL 66            /* doubles per column: 5 columns start 4 banks apart */
 static __device__ void abea_scaling_single_wave(const abea_read_desc* d, const abea_fused_scaling& fs, int lane, int event_span,
                                                 const float* __restrict__ evm, double* lds, uint4* __restrict__ recs) {
     const int out_idx = d->out_idx;
     const int K = d->n_kmers;
-    const int kmer_size = fs.kmer_size;
-    const int L = K + kmer_size - 1;
     const abea_index_pair_t* map = fs.b2e + d->kmer_off;
-    const char* __restrict__ seq = fs.reads + d->read_off;
     const abea_model_t* __restrict__ model = fs.model;
     const double events_per_base = (double)event_span / K;   /* align.c:602 */
 
@@ -246,51 +247,27 @@ static __device__ void abea_scaling_single_wave(const abea_read_desc* d, const a
      *      the wavefront orders its own LDS traffic without workgroup barriers (one wavefront = the workgroup; its LDS operations
      *      execute in issue order), which also keeps the prefetched loads in flight: __syncthreads() waits for every outstanding
      *      global load. ---- */
-    struct blk_in { abea_index_pair_t m; uint32_t d[4], sh; };            /* stage A: map entry + the 4 aligned dwords around the window */
-    struct blk_st { abea_index_pair_t m; int rank; bool valid, isM; int pos, cnt; abea_model_t mo; float raw; };
-    /* unconditional loads from clamped addresses (always inside the read's own map and its L + 1 sequence bytes): nothing for the
-     * compiler to wait for at the point of issue; lanes past K - 1, and windows that would cross the read's end, are sorted out in
-     * stage() */
-    /* The sequence window comes up as four ALIGNED dwords by relaxed atomic loads and is shifted into place (v_alignbyte): plain
-     * loads are sunk by the optimizer down to their first use, a block and a half later — the opposite of a prefetch —, atomic
-     * loads stay where they are written.  The window [kc, kc + 16) is clamped inside the read's own L + 1 bytes; an aligned dword
-     * that holds a valid byte cannot cross into an unmapped page.  Reads shorter than 16 bytes take the base-by-base path. */
-    const bool has_window = L + 1 >= 16;                                   /* wave-uniform */
-    const int win_last = L + 1 - 16;
+    struct blk_in { abea_index_pair_t m; uint32_t rank; };                /* stage A: map entry + the k-mer's rank (left by align-pre) */
+    struct blk_st { abea_index_pair_t m; int rank; bool valid, isM; int pos, cnt; abea_model_t mo; double t0, t1, t2; float raw; };
+    /* unconditional loads from clamped addresses: nothing for the compiler to wait for at the point of issue; lanes past K - 1 are
+     * sorted out in stage().  Relaxed atomic loads: a plain load is sunk by the optimizer down to its first use, a block and a half
+     * later — the opposite of a prefetch —, atomic loads stay where they are written. */
+    const uint32_t* __restrict__ krank = fs.krank + d->kpar_off;
+    const double* __restrict__ mterms = fs.mterms;
     auto load_in = [&](int k0) {
-        blk_in a; a.d[0] = a.d[1] = a.d[2] = a.d[3] = 0u; a.sh = 0u;
+        blk_in a;
         const int k = min(k0 + lane, K - 1);
         a.m = load_map_l2(map + k);
-        if (has_window) {
-            const char* p = seq + min(k, win_last);
-            a.sh = (uint32_t)(reinterpret_cast<uintptr_t>(p) & 3);
-            const uint32_t* q = reinterpret_cast<const uint32_t*>(p - a.sh);
-            a.d[0] = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            a.d[1] = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            a.d[2] = __hip_atomic_load(q + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            a.d[3] = __hip_atomic_load(q + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
+        a.rank = __hip_atomic_load(krank + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         return a;
     };
     int n_M = 0, n_align = 0;
     int carry_rank = -1;
-    auto stage = [&](const blk_in& a, int k0) {                           /* stage B: rank, 'M' states, gathers issued (not waited for) */
-        blk_st b; b.m = a.m; b.rank = 0; b.mo.level_mean = b.mo.level_stdv = b.mo.level_log_stdv = 0.f; b.raw = 0.f;
+    auto stage = [&](const blk_in& a, int k0) {                           /* stage B: 'M' states, gathers issued (not waited for) */
+        blk_st b; b.m = a.m; b.rank = (int)a.rank; b.mo.level_mean = b.mo.level_stdv = b.mo.level_log_stdv = 0.f; b.raw = 0.f;
+        b.t0 = b.t1 = b.t2 = 0.0;
         const int k = k0 + lane;
         if (k >= K) { b.m.start = -1; b.m.stop = -1; }                    /* the clamped load fetched entry K - 1 again */
-        if (k < K) {
-            if (has_window && k <= win_last) {
-                const uint32_t w[3] = {__builtin_amdgcn_alignbyte(a.d[1], a.d[0], a.sh), __builtin_amdgcn_alignbyte(a.d[2], a.d[1], a.sh),
-                                       __builtin_amdgcn_alignbyte(a.d[3], a.d[2], a.sh)};
-                uint32_t rank = 0;
-                #pragma unroll
-                for (int j = 0; j < ABEA_MAX_KMER_SIZE; ++j)
-                    if (j < kmer_size) rank = (rank << 2) | base_code((w[j >> 2] >> (8 * (j & 3))) & 0xFFu);
-                b.rank = (int)rank;
-            } else {
-                b.rank = (int)kmer_rank_at(seq, k, L, kmer_size);        /* the last few k-mers of the read: base by base */
-            }
-        }
         b.valid = b.m.start != -1;
         /* the map's entries tile the events of the path in k order (every event is new for exactly one k-mer), so the number
          * of events per k-mer IS the map: one byte per k-mer for the host entry instead of eight (255 = "255 or more": the
@@ -306,7 +283,10 @@ static __device__ void abea_scaling_single_wave(const abea_read_desc* d, const a
         const unsigned long long mm = __ballot(b.isM);
         b.cnt = __popcll(mm);
         b.pos = __popcll(mm & ((1ull << lane) - 1ull));   /* this 'M' state's place among the block's */
-        if (b.isM) { b.mo = model[b.rank]; b.raw = evm[b.m.start]; }
+        if (b.isM) {
+            b.mo = model[b.rank]; b.raw = evm[b.m.start];
+            b.t0 = mterms[3 * b.rank]; b.t1 = mterms[3 * b.rank + 1]; b.t2 = mterms[3 * b.rank + 2];
+        }
         n_align += b.valid ? (b.m.stop - b.m.start + 1) : 0;
         if (vm) carry_rank = __shfl(b.rank, 63 - __clzll(vm), 64);
         return b;
@@ -320,11 +300,10 @@ static __device__ void abea_scaling_single_wave(const abea_read_desc* d, const a
             a2 = load_in(k0 + 128);
             if (cur.isM) {
                 recs[n_M + cur.pos] = make_uint4(__float_as_uint(cur.mo.level_mean), __float_as_uint(cur.mo.level_stdv), __float_as_uint(cur.raw), 0u);
-                const double level_stdv = cur.mo.level_stdv, mu = cur.mo.level_mean, e = cur.raw;
-                const double inv_var = 1. / (level_stdv * level_stdv);
+                const double mu = cur.mo.level_mean, e = cur.raw, inv_var = cur.t0;     /* inv_var = 1. / (level_stdv * level_stdv), from the table */
                 lds[0 * ABEA_P4_COL + cur.pos] = inv_var;
-                lds[1 * ABEA_P4_COL + cur.pos] = mu * inv_var;
-                lds[2 * ABEA_P4_COL + cur.pos] = mu * mu * inv_var;
+                lds[1 * ABEA_P4_COL + cur.pos] = cur.t1;               /* mu * inv_var */
+                lds[2 * ABEA_P4_COL + cur.pos] = cur.t2;               /* mu * mu * inv_var */
                 lds[3 * ABEA_P4_COL + cur.pos] = e * inv_var;
                 lds[4 * ABEA_P4_COL + cur.pos] = mu * e * inv_var;
             }

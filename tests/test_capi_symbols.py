@@ -77,3 +77,39 @@ def test_static_pmc_counters_belong_to_these_kernel_sources():
     for config in ("r9_10k_8kb", "r9_100k_mixed"):
         assert t[config]["code_sha256"] == sha, config
         assert bench.pmc_entry(config) is not None and bench.pmc_traffic(config, 1000, 1) == int(t[config]["hbm_bytes_per_event"] * 1000)
+
+
+def test_hw_queue_setenv_opt_out():
+    """abea_init asks for 16 hardware queues by setenv before its first HIP call unless the caller set the variable — and not at all
+    with ABEA_KEEP_HW_QUEUES set (round-5 advisor finding: a library writing the environment of a multi-threaded host).  Runs in
+    a subprocess without a GPU: abea_init fails with ABEA_ENODEV AFTER that decision, which is all this test needs."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import ctypes, os, sys
+sys.path.insert(0, %r)
+os.environ["ABEA_KEEP_HW_QUEUES"] = "1"           # keeps f5c_amd/__init__.py from exporting the variable itself
+os.environ.pop("GPU_MAX_HW_QUEUES", None)
+from f5c_amd import abea
+if sys.argv[1] == "default":
+    os.environ.pop("ABEA_KEEP_HW_QUEUES")
+lib = abea.load_library()
+libc = ctypes.CDLL(None); libc.getenv.restype = ctypes.c_char_p
+class Cfg(ctypes.Structure):
+    _fields_ = [("device_id", ctypes.c_int32), ("kmer_size", ctypes.c_uint32), ("model", ctypes.c_void_p), ("mem_frac", ctypes.c_float),
+                ("max_arena_bytes", ctypes.c_uint64), ("verbosity", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+model = (ctypes.c_float * (3 * 4096))()
+cfg = Cfg(0, 6, ctypes.addressof(model), 0.5, 1 << 20, 0, 0)
+h = ctypes.c_void_p()
+rc = lib.abea_init(ctypes.byref(h), ctypes.byref(cfg))
+print(rc, libc.getenv(b"GPU_MAX_HW_QUEUES"))
+"""
+    env = {k_: v for k_, v in os.environ.items() if k_ not in ("GPU_MAX_HW_QUEUES", "ABEA_KEEP_HW_QUEUES")}
+    env["HIP_VISIBLE_DEVICES"] = "-1"                  # no device even on a GPU box: the decision comes before the device check
+    out = {}
+    for mode in ("default", "keep"):
+        r = subprocess.run([sys.executable, "-c", code % root, mode], capture_output=True, text=True, env=env, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out[mode] = r.stdout.strip().splitlines()[-1].split()
+    assert out["default"][0] != "0" and out["default"][1] == "b'16'", out        # no device: an error code, after the setenv
+    assert out["keep"][0] != "0" and out["keep"][1] == "None", out

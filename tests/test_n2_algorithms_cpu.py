@@ -79,3 +79,56 @@ def test_exponent_range_rule_implies_order_independent_sums():
         elif total_seq != total_perm or total_seq != float(pair[0]):
             n_fail_caught += 1
     assert n_pass >= 100 and n_fail_caught >= 5                 # the rule accepts ordinary signals and rejects ones that do round
+
+
+def test_float_sums_in_double_are_order_free_under_the_exponent_test():
+    """The criterion abea_ev_scalings_kernel uses (round 6) before it lets 64 lanes add strided subsets of a read's event means /
+    k-mer levels and finish with a butterfly: all terms are floats, so multiples of the smallest term's ulp 2^(emin-150), and any
+    partial sum is below n * 2^(emax-126); when ceil(log2 n) + emax - emin <= 29 no double addition can round, in ANY order —
+    the strided / butterfly sum is the sequential sum of estimate_scalings_using_mom (align.c:66-81) bit for bit.  Checked here on
+    random inputs on both sides of the bound: inside it every order agrees exactly; outside it a counter-example exists."""
+    import numpy as np
+    rng = np.random.default_rng(99)
+
+    def expo(x):
+        e = (x.view(np.uint32) >> 23) & 0xFF
+        nz = x != 0
+        return (int(np.maximum(e[nz], 1).min()), int(e[nz].max())) if nz.any() else (255, 0)
+
+    def clog2(n):
+        return int(n - 1).bit_length() if n > 1 else 0
+
+    def seq(x):
+        s = 0.0
+        for v in x.astype(np.float64):
+            s += v
+        return s
+
+    def lanes(x):                                         # 64 strided partial sums, then a butterfly
+        p = [seq(x[i::64]) for i in range(64)]
+        off = 32
+        while off:
+            p = [p[i] + p[i ^ off] for i in range(64)]
+            off >>= 1
+        return p[0]
+
+    n_exact = 0
+    for trial in range(60):
+        n = int(rng.integers(1, 5000))
+        kind = trial % 3
+        if kind == 0:       x = rng.normal(90.0, 15.0, n)                          # event means in pA
+        elif kind == 1:     x = rng.uniform(-1.0, 1.0, n) * 10.0 ** rng.integers(-3, 6)
+        else:               x = np.concatenate([rng.normal(100.0, 10.0, n), [0.0, -0.0]])
+        x = x.astype(np.float32)
+        lo, hi = expo(x)
+        if hi < 255 and clog2(len(x)) + hi - lo <= 29:
+            n_exact += 1
+            assert seq(x) == lanes(x) == seq(x[::-1]) == float(np.sum(x.astype(np.float64)))
+    assert n_exact >= 30
+    # outside the bound the orders can differ: one tiny term next to large ones
+    x = np.array([1e-9] + [100.0] * 4095, dtype=np.float32)
+    lo, hi = expo(x)
+    assert clog2(len(x)) + hi - lo > 29
+    y = np.array([2.0 ** -30, 2.0 ** 30, -2.0 ** 30] * 64, dtype=np.float32)     # the classic: cancellation order matters
+    lo, hi = expo(y)
+    assert clog2(len(y)) + hi - lo > 29 and seq(y) != lanes(y)
