@@ -95,11 +95,8 @@ if sys.argv[1] == "default":
     os.environ.pop("ABEA_KEEP_HW_QUEUES")
 lib = abea.load_library()
 libc = ctypes.CDLL(None); libc.getenv.restype = ctypes.c_char_p
-class Cfg(ctypes.Structure):
-    _fields_ = [("device_id", ctypes.c_int32), ("kmer_size", ctypes.c_uint32), ("model", ctypes.c_void_p), ("mem_frac", ctypes.c_float),
-                ("max_arena_bytes", ctypes.c_uint64), ("verbosity", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 model = (ctypes.c_float * (3 * 4096))()
-cfg = Cfg(0, 6, ctypes.addressof(model), 0.5, 1 << 20, 0, 0)
+cfg = abea._Cfg(0, 6, ctypes.addressof(model), 0.5, 1 << 20, 0, 0)
 h = ctypes.c_void_p()
 rc = lib.abea_init(ctypes.byref(h), ctypes.byref(cfg))
 print(rc, libc.getenv(b"GPU_MAX_HW_QUEUES"))
