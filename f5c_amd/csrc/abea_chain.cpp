@@ -813,26 +813,35 @@ int abea_chain_run(abea_ctx* c, const abea_chain_job* J, const int32_t* mine, in
     /* pinned staging sized once for the largest chunk of the call (the slot a chunk lands on depends on what has completed: growing
      * a slot's blocks when a larger chunk arrives re-pinned hundreds of MB in the middle of the pipeline, 10-15 ms a time) */
     {
-        size_t up_max = 0, tab_max = 0, cnt_max = 0;
+        size_t up_max = 0, tab_max = 0, cnt_max = 0, desc_max = 0, dn_max = 0;
         for (const std::pair<size_t, size_t>& ck : chunks) {
-            size_t n_sig = 0, n_seq = 0, n_slot = 0;
+            size_t n_sig = 0, n_seq = 0, n_slot = 0, n_code = 0, n_kmer = 0;
             for (size_t q = ck.first; q < ck.second; ++q) {
                 const int32_t i = todo[q];
                 const int64_t ns = J->n_samples[i];
                 n_sig += (size_t)((ns + 7) / 8 * 8);
                 n_seq += align_up((size_t)(want_sc ? J->read_len[i] : (int32_t)c->k) + 1, 16);
-                n_slot += std::min<size_t>((size_t)ns / S.opt.cap_div + 16, INT32_MAX / 2);
+                const size_t cap = std::min<size_t>((size_t)ns / S.opt.cap_div + 16, INT32_MAX / 2);
+                n_slot += cap;
+                if (J->align) {                                   /* walk codes (2 bit per step, <= E + K steps) and the count byte per k-mer */
+                    const size_t K = (size_t)std::max(J->read_len[i] - (int32_t)c->k + 1, 0);
+                    n_code += (cap + K) / 16 + 8; n_kmer += K;
+                }
             }
             const size_t m = ck.second - ck.first;
             up_max = std::max(up_max, align_up(align_up(n_sig * 2, 256) + n_seq, 256));
             tab_max = std::max(tab_max, align_up((n_slot + 3 * m) * (S.opt.packed ? 12 : sizeof(abea_event_t)), 16) + 256);
             cnt_max = std::max(cnt_max, align_up(align_up(m * 4, 256) + m * sizeof(abea_scalings_t), 256));
+            desc_max = std::max(desc_max, m * 24 + 256 + (J->align ? align_up(m * sizeof(abea_read_desc), 256) + align_up(m * sizeof(abea_scalings_t), 256) + align_up(m * 4, 256) : 0));
+            if (J->align) dn_max = std::max(dn_max, m * (4 + sizeof(abea_read_diag) + sizeof(abea_scalings_t) + 8 + 4 + 4 + 8) + n_code * 4 + n_kmer + 10 * 256);
         }
         for (int q = 0; q < std::min<int>(n_slots, (int)chunks.size()); ++q) {
             abea_chain_slot& sl = *c->chain_slots[(size_t)q];
             int rc = sl.up.need(up_max);
             if (!rc) rc = sl.tab.need(tab_max);
             if (!rc) rc = sl.cnt.need(cnt_max);
+            if (!rc) rc = sl.desc.need(desc_max);
+            if (!rc && dn_max) rc = sl.dn.need(dn_max);
             if (rc) return rc;
         }
     }
