@@ -746,12 +746,11 @@ struct abea_evdet {
     float peak_value; int peak_pos; long long masked_to; bool valid;
 };
 
-static __device__ __forceinline__ float abea_tstat(double s_lo, double s_mid, double s_hi, double q_lo, double q_mid,
-                                                   double q_hi, float wf) {
-    /* events.c:343-366 */
-    const double sum1 = s_mid - s_lo, sumsq1 = q_mid - q_lo;
-    const float sum2 = (float)(s_hi - s_mid);
-    const float sumsq2 = (float)(q_hi - q_mid);
+/* events.c:343-366 on the four window sums: sum1 / sumsq1 = left window (kept in double), sum2d / sumsq2d = right window
+ * (rounded to float first, as the reference's float locals do) */
+static __device__ __forceinline__ float abea_tstat_w(double sum1, double sum2d, double sumsq1, double sumsq2d, float wf) {
+    const float sum2 = (float)sum2d;
+    const float sumsq2 = (float)sumsq2d;
     const float mean1 = (float)(sum1 / (double)wf);
     const float mean2 = sum2 / wf;
     float combined_var = (float)(((sumsq1 / (double)wf - (double)(mean1 * mean1)) + (double)(sumsq2 / wf)) -
@@ -759,6 +758,10 @@ static __device__ __forceinline__ float abea_tstat(double s_lo, double s_mid, do
     combined_var = fmaxf(combined_var, 1.17549435e-38f);            /* FLT_MIN */
     const float delta_mean = mean2 - mean1;
     return fabsf(delta_mean) / sqrtf(combined_var / wf);
+}
+static __device__ __forceinline__ float abea_tstat(double s_lo, double s_mid, double s_hi, double q_lo, double q_mid,
+                                                   double q_hi, float wf) {
+    return abea_tstat_w(s_mid - s_lo, s_hi - s_mid, q_mid - q_lo, q_hi - q_mid, wf);
 }
 
 /* ---- pass 1, parallel form.  S and Q are sequential fp64 sums (events.c:303-313), but when every sample of a read is a
@@ -770,6 +773,17 @@ static __device__ __forceinline__ float abea_tstat(double s_lo, double s_mid, do
 #define ABEA_EV_SEG_SUM 512
 static __device__ __forceinline__ float abea_pa(int raw, float offset, float raw_unit) {
     return __fmul_rn(__fadd_rn((float)raw, offset), raw_unit);       /* f5c.c:694-696 */
+}
+
+/* lo / hi = smallest nonzero / largest |value| of n floats as bit patterns (biased exponents; the quantum of a float with
+ * exponent field e is 2^(max(e,1) - 150)); the sum of n values below 2^(emax + 1 - 127) stays below 2^(emax - 126 + nbits):
+ * true = every partial sum of any subset, in any order, is exactly representable in a double */
+static __device__ __forceinline__ bool abea_ev_sum_exact(uint32_t lo, uint32_t hi, int n) {
+    if (hi == 0u) return true;                                       /* all zeros */
+    if (hi >= 0x7f800000u) return false;                             /* inf / NaN: leave it to the sequential form */
+    const int nbits = 32 - __clz(n);
+    const int emin = max((int)(lo >> 23), 1), emax = max((int)(hi >> 23), 1);
+    return (emax - emin) + nbits + 24 <= 53;
 }
 
 extern "C" __global__ __launch_bounds__(256)
@@ -836,16 +850,7 @@ void abea_ev_pscan_kernel(int n_reads, const int32_t* __restrict__ order, const 
         xmin = min(xmin, se[0]); xmax = max(xmax, se[64]); ymin = min(ymin, se[128]); ymax = max(ymax, se[192]);
         ss += 2 * 64; se += 4 * 64;
     }
-    /* biased exponents; quantum of a float with exponent field e is 2^(max(e,1) - 150); the sum of n values below
-     * 2^(emax + 1 - 127) stays below 2^(emax - 126 + nbits) */
-    const int nbits = 32 - __clz(n);
-    auto exact = [&](uint32_t lo, uint32_t hi) {
-        if (hi == 0u) return true;                                   /* all zeros */
-        if (hi >= 0x7f800000u) return false;                         /* inf / NaN: leave it to the sequential form */
-        const int emin = max((int)(lo >> 23), 1), emax = max((int)(hi >> 23), 1);
-        return (emax - emin) + nbits + 24 <= 53;
-    };
-    need_seq[r] = (exact(xmin, xmax) && exact(ymin, ymax)) ? 0 : 1;
+    need_seq[r] = (abea_ev_sum_exact(xmin, xmax, n) && abea_ev_sum_exact(ymin, ymax, n)) ? 0 : 1;
 }
 
 extern "C" __global__ __launch_bounds__(256)
@@ -964,12 +969,14 @@ template <int W1, int W2, int POS>
 static __device__ __forceinline__ void tstat_body(int n_reads, const int32_t* __restrict__ order, const int32_t* __restrict__ n_samples,
                           const int64_t* __restrict__ wave_base, const int32_t* __restrict__ wave_len,
                           const double* __restrict__ S_all, const double* __restrict__ Q_all,
-                          float* __restrict__ t1_all, float* __restrict__ t2_all) {
+                          float* __restrict__ t1_all, float* __restrict__ t2_all, const int32_t* __restrict__ need) {
     /* grid.y = wave, grid.x tiles the positions of that wave; a 256-thread block covers 4 positions x 64 lanes */
     const int w = blockIdx.y;
     const int lane = threadIdx.x & 63;
     const int slot = w * 64 + lane;
-    const int n = slot < n_reads ? n_samples[order[slot]] : 0;
+    /* need != NULL: this is the array form behind the fused common path — only flagged reads have prefix sums at all */
+    if (slot >= n_reads || (need && !need[order[slot]])) return;
+    const int n = n_samples[order[slot]];
     const int64_t base = wave_base[w];
     const int len = wave_len[w];
     (void)Q_all;
@@ -1004,9 +1011,10 @@ extern "C" __global__ __launch_bounds__(256)
 void abea_ev_tstat_kernel(int n_reads, const int32_t* __restrict__ order, const int32_t* __restrict__ n_samples,
                           const int64_t* __restrict__ wave_base, const int32_t* __restrict__ wave_len,
                           const double* __restrict__ S_all, const double* __restrict__ Q_all,
-                          float* __restrict__ t1_all, float* __restrict__ t2_all, int rna) {
-    if (rna) tstat_body<7, 14, 4>(n_reads, order, n_samples, wave_base, wave_len, S_all, Q_all, t1_all, t2_all);
-    else tstat_body<3, 6, 8>(n_reads, order, n_samples, wave_base, wave_len, S_all, Q_all, t1_all, t2_all);
+                          float* __restrict__ t1_all, float* __restrict__ t2_all, int rna,
+                          const int32_t* __restrict__ need) {
+    if (rna) tstat_body<7, 14, 4>(n_reads, order, n_samples, wave_base, wave_len, S_all, Q_all, t1_all, t2_all, need);
+    else tstat_body<3, 6, 8>(n_reads, order, n_samples, wave_base, wave_len, S_all, Q_all, t1_all, t2_all, need);
 }
 
 /* ---- pass 3: segment-parallel automaton ---- */
@@ -1181,7 +1189,8 @@ void abea_ev_fix_kernel(int n_reads, const int32_t* __restrict__ order, const in
 extern "C" __global__ __launch_bounds__(64)
 void abea_ev_scan_kernel(int n_reads, const int32_t* __restrict__ order, const int32_t* __restrict__ n_samples,
                          const int64_t* __restrict__ seg_base, int32_t* __restrict__ segrec_all,
-                         int32_t* __restrict__ n_events) {
+                         int32_t* __restrict__ n_events, const uint32_t* __restrict__ segexp_all,
+                         int32_t* __restrict__ need) {
     const int lane = threadIdx.x;
     const int slot = blockIdx.x * 64 + lane;
     if (slot >= n_reads) return;
@@ -1198,6 +1207,17 @@ void abea_ev_scan_kernel(int n_reads, const int32_t* __restrict__ order, const i
         rec += 12 * 64;
     }
     n_events[r] = run + 1;                                           /* events.c:491-497: one more event than peaks */
+    if (!segexp_all) return;
+    /* fused common path: the window and event sums were taken straight from the samples, which is the reference's
+     * S[b] - S[a] bit for bit only if no prefix sum of the read can round (the test of abea_ev_pscan_kernel, on the
+     * exponent ranges abea_ev_spec2_kernel recorded); a read that fails it is redone through the prefix-sum arrays */
+    const uint32_t* __restrict__ se = segexp_all + seg_base[blockIdx.x] * 4 * 64 + lane;
+    uint32_t xmin = 0x7f800000u, xmax = 0u, ymin = 0x7f800000u, ymax = 0u;
+    for (int j = 0; j < nseg; ++j) {
+        xmin = min(xmin, se[0]); xmax = max(xmax, se[64]); ymin = min(ymin, se[128]); ymax = max(ymax, se[192]);
+        se += 4 * 64;
+    }
+    if (!(abea_ev_sum_exact(xmin, xmax, n) && abea_ev_sum_exact(ymin, ymax, n))) need[r] = 1;
 }
 
 extern "C" __global__ __launch_bounds__(256)
@@ -1205,7 +1225,8 @@ void abea_ev_gather_kernel(int n_reads, const int32_t* __restrict__ order, const
                            const int64_t* __restrict__ seg_base, const int32_t* __restrict__ wave_nseg,
                            const uint16_t* __restrict__ spec_all, const int32_t* __restrict__ fix_all,
                            const int32_t* __restrict__ segrec_all, const int64_t* __restrict__ peak_base,
-                           const int32_t* __restrict__ event_cap, int32_t* __restrict__ peaks_all) {
+                           const int32_t* __restrict__ event_cap, int32_t* __restrict__ peaks_all,
+                           const int32_t* __restrict__ wave_cap, int linear) {
     const int w = blockIdx.y;
     const int lane = threadIdx.x & 63;
     const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -1219,11 +1240,14 @@ void abea_ev_gather_kernel(int n_reads, const int32_t* __restrict__ order, const
     const int32_t* __restrict__ rec = segrec_all + seg * 12 * 64 + lane;
     const uint16_t* __restrict__ sp = spec_all + seg * ABEA_EV_SEG * 64 + lane;
     const int32_t* __restrict__ fx = fix_all + seg * ABEA_EV_FIXCAP * 64 + lane;
-    int32_t* __restrict__ pk = peaks_all + peak_base[w] + lane;
+    /* linear != 0: one list per read (lane l of the wave at peak_base + l * wave_cap), what abea_ev_create2_kernel walks with
+     * a wavefront per read; else interleaved over the wave's lanes like the sequential kernels' lists */
+    int32_t* __restrict__ pk = peaks_all + peak_base[w] + (linear ? (int64_t)lane * wave_cap[w] : (int64_t)lane);
+    const size_t ps = linear ? 1 : 64;
     const int nspec = rec[0], nfix = min(rec[64], ABEA_EV_FIXCAP), skip = rec[128];
     int at = rec[3 * 64];
-    for (int e = 0; e < nfix; ++e, ++at) if (at < cap) pk[(size_t)at * 64] = fx[(size_t)e * 64];
-    for (int e = skip; e < nspec; ++e, ++at) if (at < cap) pk[(size_t)at * 64] = j * ABEA_EV_SEG + (int)sp[(size_t)e * 64];
+    for (int e = 0; e < nfix; ++e, ++at) if (at < cap) pk[(size_t)at * ps] = fx[(size_t)e * 64];
+    for (int e = skip; e < nspec; ++e, ++at) if (at < cap) pk[(size_t)at * ps] = j * ABEA_EV_SEG + (int)sp[(size_t)e * 64];
 }
 
 extern "C" __global__ __launch_bounds__(64)
@@ -1315,6 +1339,281 @@ void abea_ev_detect_kernel(int n_reads, const int32_t* __restrict__ order, const
     n_events[r] = n_pk + 1;                                          /* events.c:491-497: one more event than peaks */
 }
 
+/* ================================================================ the common path without the arrays (round 6)
+ * Rounds 3-5 moved 128 bytes of HBM traffic per sample for 6.6 algorithmic (profiles/pmc_traffic.json -> detector): the fp64 prefix
+ * sums {S, Q} written once (16 B per sample) and fetched back by the t-statistics and by the event creation, the two float
+ * t-statistics (8 B) written and fetched by the automaton.  None of that is needed where the prefix sums are EXACT (every real
+ * read; the test of abea_ev_pscan_kernel): a difference S[b] - S[a] of two exact prefix sums is the exact sum of the samples in
+ * [a, b), which any order of fp64 additions reproduces bit for bit as long as no partial sum can round — so
+ *   abea_ev_spec2_kernel   a lane walks its (read, segment) once, straight from the 2-byte samples: the four window sums slide
+ *                          (+ entering sample, - leaving sample, all exact), the two t-statistics come from them with the very
+ *                          expressions of events.c:343-366 (abea_tstat_w) and go into the automaton in the same step — no
+ *                          prefix-sum array, no t-statistic array;
+ *   abea_ev_fix2_kernel    the replay window of abea_ev_fix_kernel with the t-statistics recomputed the same way;
+ *   abea_ev_scan_kernel    also reduces the exponent ranges spec2 recorded and flags a read whose sums may round;
+ *   abea_ev_create2_kernel a wavefront per read, a lane per event: the event's sums are added up from its samples.
+ * A flagged read (sums may round, or a segment that never met its replay) goes through the array kernels above, which run
+ * behind the common path on flagged reads only: sequential prefix sums, t-statistic arrays, the sequential automaton, events
+ * from the prefix sums.  ABEA_EV_PATH=arrays selects the array form for every read (the A/B of profiles/r06).
+ * Samples reach a lane through a private LDS row: a lane is in the middle of ITS read, 64 lanes of a wavefront in 64 different
+ * reads, so a load touches 64 cache lines; fetching a whole 128-byte line per lane at a time (eight 16-byte loads back to back)
+ * uses every byte of a line while it is hot — the lane-per-read kernels that take 16 bytes per line and come back for the next
+ * 16 a microsecond later re-fetch lines (abea_ev_psum_kernel: 10 B per sample counted for 2 read). */
+template <int W1, int W2>
+struct abea_ev_win {
+    float x[2 * W2];                      /* samples p - W2 .. p + W2 - 1 in pA (0 outside the read) when position p is evaluated */
+    double sl1, sr1, sl2, sr2, ql1, qr1, ql2, qr2;     /* sums over [p-W1,p), [p,p+W1), [p-W2,p), [p,p+W2): samples / float squares */
+    __device__ __forceinline__ void init() {
+        sl1 = sr1 = sl2 = sr2 = ql1 = qr1 = ql2 = qr2 = 0.0;
+        #pragma unroll
+        for (int i = 0; i < 2 * W2; ++i) {
+            const double xd = (double)x[i], yd = (double)__fmul_rn(x[i], x[i]);
+            if (i < W2) { sl2 += xd; ql2 += yd; } else { sr2 += xd; qr2 += yd; }
+            if (i >= W2 - W1 && i < W2) { sl1 += xd; ql1 += yd; }
+            if (i >= W2 && i < W2 + W1) { sr1 += xd; qr1 += yd; }
+        }
+    }
+    /* p -> p + 1; xin = sample p + W2 */
+    __device__ __forceinline__ void advance(float xin) {
+        const float xo2 = x[0], xo1 = x[W2 - W1], xm = x[W2], xi1 = x[W2 + W1];
+        const double dm = (double)xm, ym = (double)__fmul_rn(xm, xm);
+        sl2 = (sl2 + dm) - (double)xo2;          ql2 = (ql2 + ym) - (double)__fmul_rn(xo2, xo2);
+        sr2 = (sr2 + (double)xin) - dm;          qr2 = (qr2 + (double)__fmul_rn(xin, xin)) - ym;
+        sl1 = (sl1 + dm) - (double)xo1;          ql1 = (ql1 + ym) - (double)__fmul_rn(xo1, xo1);
+        sr1 = (sr1 + (double)xi1) - dm;          qr1 = (qr1 + (double)__fmul_rn(xi1, xi1)) - ym;
+        #pragma unroll
+        for (int i = 0; i + 1 < 2 * W2; ++i) x[i] = x[i + 1];
+        x[2 * W2 - 1] = xin;
+    }
+    /* events.c:336-347: zero where a window does not fit the read */
+    __device__ __forceinline__ void tstats(int p, int n, float& a, float& b) const {
+        const float ta = abea_tstat_w(sl1, sr1, ql1, qr1, (float)W1);
+        const float tb = abea_tstat_w(sl2, sr2, ql2, qr2, (float)W2);
+        a = (n >= 2 * W1 && p >= W1 && p <= n - W1) ? ta : 0.f;
+        b = (n >= 2 * W2 && p >= W2 && p <= n - W2) ? tb : 0.f;
+    }
+};
+
+#define ABEA_EV_ROW 132      /* uint16 per staged row: two 64-sample blocks + pad (264 bytes = 66 dwords: neighbouring rows 2 banks apart) */
+
+template <int W1, int W2>
+static __device__ __forceinline__ void spec2_body(int n_reads, const int32_t* __restrict__ order, const int16_t* __restrict__ signal,
+                          const int64_t* __restrict__ sig_ptr, const int32_t* __restrict__ n_samples,
+                          const float* __restrict__ scaling, const int64_t* __restrict__ seg_base,
+                          const int32_t* __restrict__ wave_nseg, uint16_t* __restrict__ spec_all,
+                          int32_t* __restrict__ segrec_all, uint32_t* __restrict__ segexp_all, const abea_ev_par P,
+                          uint16_t* __restrict__ rows) {
+    const int w = blockIdx.y;
+    const int lane = threadIdx.x;
+    const int j = blockIdx.x;
+    const int slot = w * 64 + lane;
+    if (j >= wave_nseg[w] || slot >= n_reads) return;
+    const int r = order[slot];
+    const int n = n_samples[r];
+    const int seg_lo = j * ABEA_EV_SEG;
+    const int lo = max(seg_lo, 1);                                   /* masked_to starts at 0: position 0 is skipped */
+    const int hi = min(seg_lo + ABEA_EV_SEG, n);
+    if (lo >= hi && j > 0) return;
+    const int16_t* __restrict__ sig = signal + sig_ptr[r];
+    const float offset = scaling[3 * r], raw_unit = scaling[3 * r + 1] / scaling[3 * r + 2];   /* f5c.c:693 */
+    const int64_t seg = seg_base[w] + j;
+    uint16_t* __restrict__ out = spec_all + seg * ABEA_EV_SEG * 64 + lane;
+    int32_t* __restrict__ rec = segrec_all + seg * 12 * 64 + lane;
+    uint32_t* __restrict__ se = segexp_all + seg * 4 * 64 + lane;
+    uint16_t* __restrict__ my = rows + lane * ABEA_EV_ROW;
+
+    /* the row is a ring of two 64-sample blocks; block b holds the samples i0 + 64 b .. i0 + 64 b + 63, i0 = the sample at the
+     * 16-byte boundary at or below the first one needed */
+    const int q0 = lo - W2;
+    const int sh = (int)(((uintptr_t)sig + (uintptr_t)(2 * (int64_t)q0)) & 15u) >> 1;
+    const int i0 = q0 - sh;
+    auto load_block = [&](int b) {
+        const int b0 = i0 + 64 * b;
+        if (b0 >= n || b0 + 64 <= 0) return;                         /* nothing of the read in it */
+        uint4 c[8];
+        if (b0 >= 0 && b0 + 64 <= n) {
+            #pragma unroll
+            for (int u = 0; u < 8; ++u) c[u] = *reinterpret_cast<const uint4*>(sig + b0 + 8 * u);
+        } else {                                                     /* a block across an end of the read: never a byte outside it */
+            #pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                uint32_t h[8];
+                #pragma unroll
+                for (int v = 0; v < 8; ++v) {
+                    const int i = b0 + 8 * u + v;
+                    h[v] = (i >= 0 && i < n) ? (uint32_t)(uint16_t)sig[i] : 0u;
+                }
+                c[u] = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
+            }
+        }
+        uint2* __restrict__ d = reinterpret_cast<uint2*>(my + ((64 * b) & 127));
+        #pragma unroll
+        for (int u = 0; u < 8; ++u) { d[2 * u] = make_uint2(c[u].x, c[u].y); d[2 * u + 1] = make_uint2(c[u].z, c[u].w); }
+    };
+    uint32_t xmin = 0x7f800000u, xmax = 0u, ymin = 0x7f800000u, ymax = 0u;
+    auto fetch = [&](int i) -> float {
+        const int raw = (int)(short)my[(i - i0) & 127];
+        const float x = (i >= 0 && i < n) ? abea_pa(raw, offset, raw_unit) : 0.f;
+        if (i >= seg_lo && i < hi) {                                 /* this segment's own samples: the exactness test's input */
+            const float y = __fmul_rn(x, x);
+            const uint32_t ax = __float_as_uint(x) & 0x7fffffffu, ay = __float_as_uint(y);
+            xmax = max(xmax, ax); ymax = max(ymax, ay);
+            xmin = min(xmin, ax ? ax : 0x7f800000u); ymin = min(ymin, ay ? ay : 0x7f800000u);
+        }
+        return x;
+    };
+    load_block(0); load_block(1);
+    abea_ev_win<W1, W2> wn;
+    #pragma unroll
+    for (int i = 0; i < 2 * W2; ++i) wn.x[i] = fetch(q0 + i);
+    wn.init();
+    abea_det2 s; det2_reset(s);
+    int cnt = 0;
+    const int steps = hi - lo;
+    for (int t = 0; t < steps; ++t) {
+        if (t != 0 && (t & 63) == 0) load_block((t >> 6) + 1);       /* samples up to i0 + t + 2 W2 + 7 < 64 ((t >> 6) + 2) */
+        const int p = lo + t;
+        float a, b;
+        wn.tstats(p, n, a, b);
+        int f0, f1;
+        const int fired = det2_step(s, p, a, b, f0, f1, P);
+        if (fired & 1) { out[(size_t)cnt * 64] = (uint16_t)(f0 - seg_lo); ++cnt; }
+        if (fired & 2) { out[(size_t)cnt * 64] = (uint16_t)(f1 - seg_lo); ++cnt; }
+        wn.advance(fetch(p + W2));
+    }
+    rec[0 * 64] = cnt;                                               /* as abea_ev_spec_kernel */
+    rec[1 * 64] = 0;
+    rec[2 * 64] = 0;
+    rec[4 * 64] = __float_as_int(s.pv0); rec[5 * 64] = __float_as_int(s.pv1);
+    rec[6 * 64] = s.pp0; rec[7 * 64] = s.pp1; rec[8 * 64] = s.v0; rec[9 * 64] = s.v1; rec[10 * 64] = s.masked;
+    se[0] = xmin; se[64] = xmax; se[128] = ymin; se[192] = ymax;
+}
+
+extern "C" __global__ __launch_bounds__(64)
+void abea_ev_spec2_kernel(int n_reads, const int32_t* __restrict__ order, const int16_t* __restrict__ signal,
+                          const int64_t* __restrict__ sig_ptr, const int32_t* __restrict__ n_samples,
+                          const float* __restrict__ scaling, const int64_t* __restrict__ seg_base,
+                          const int32_t* __restrict__ wave_nseg, uint16_t* __restrict__ spec_all,
+                          int32_t* __restrict__ segrec_all, uint32_t* __restrict__ segexp_all, int rna) {
+    __shared__ __attribute__((aligned(16))) uint16_t rows[64 * ABEA_EV_ROW];
+    const abea_ev_par P = ev_par(rna);
+    if (rna) spec2_body<7, 14>(n_reads, order, signal, sig_ptr, n_samples, scaling, seg_base, wave_nseg, spec_all, segrec_all, segexp_all, P, rows);
+    else spec2_body<3, 6>(n_reads, order, signal, sig_ptr, n_samples, scaling, seg_base, wave_nseg, spec_all, segrec_all, segexp_all, P, rows);
+}
+
+template <int W1, int W2>
+static __device__ __forceinline__ void fix2_body(int n_reads, const int32_t* __restrict__ order, const int16_t* __restrict__ signal,
+                         const int64_t* __restrict__ sig_ptr, const int32_t* __restrict__ n_samples,
+                         const float* __restrict__ scaling, const int64_t* __restrict__ seg_base,
+                         const int32_t* __restrict__ wave_nseg, int32_t* __restrict__ fix_all,
+                         int32_t* __restrict__ segrec_all, int32_t* __restrict__ need_seq, const abea_ev_par P, int window) {
+    const int w = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6) + 1;           /* segment 0 starts from the true state already */
+    const int slot = w * 64 + lane;
+    if (j >= wave_nseg[w] || slot >= n_reads) return;
+    const int r = order[slot];
+    const int n = n_samples[r];
+    const int lo = j * ABEA_EV_SEG;
+    const int hi = min(lo + ABEA_EV_SEG, n);
+    if (lo >= hi) return;
+    const int16_t* __restrict__ sig = signal + sig_ptr[r];
+    const float offset = scaling[3 * r], raw_unit = scaling[3 * r + 1] / scaling[3 * r + 2];
+    const int64_t seg = seg_base[w] + j;
+    int32_t* __restrict__ out = fix_all + seg * ABEA_EV_FIXCAP * 64 + lane;
+    int32_t* __restrict__ rec = segrec_all + seg * 12 * 64 + lane;
+    const int32_t* __restrict__ prev = rec - 12 * 64;
+    abea_det2 tr, sp;
+    tr.pv0 = __int_as_float(prev[4 * 64]); tr.pv1 = __int_as_float(prev[5 * 64]);
+    tr.pp0 = prev[6 * 64]; tr.pp1 = prev[7 * 64]; tr.v0 = prev[8 * 64]; tr.v1 = prev[9 * 64]; tr.masked = prev[10 * 64];
+    det2_reset(sp);
+    int nfix = 0, skip = 0, p = lo;
+    bool met = det2_equal(tr, sp, lo - 1);
+    const int stop = min(hi, lo + window);
+    if (!met) {
+        auto fetch = [&](int i) -> float { return (i >= 0 && i < n) ? abea_pa((int)sig[i], offset, raw_unit) : 0.f; };
+        abea_ev_win<W1, W2> wn;
+        #pragma unroll
+        for (int i = 0; i < 2 * W2; ++i) wn.x[i] = fetch(lo - W2 + i);
+        wn.init();
+        while (!met && p < stop) {
+            float c0, c1;
+            wn.tstats(p, n, c0, c1);
+            int f0, f1, g0, g1;
+            const int ft = det2_step(tr, p, c0, c1, f0, f1, P);
+            const int fs = det2_step(sp, p, c0, c1, g0, g1, P);
+            if (ft & 1) { if (nfix < ABEA_EV_FIXCAP) out[(size_t)nfix * 64] = f0; ++nfix; }
+            if (ft & 2) { if (nfix < ABEA_EV_FIXCAP) out[(size_t)nfix * 64] = f1; ++nfix; }
+            skip += (fs & 1) + ((fs >> 1) & 1);
+            met = det2_equal(tr, sp, p);
+            wn.advance(fetch(p + W2));
+            ++p;
+        }
+    }
+    /* as abea_ev_fix_kernel */
+    if ((!met && p < hi) || nfix > ABEA_EV_FIXCAP) need_seq[r] = 1;
+    if (!met && p >= hi) skip = rec[0 * 64];
+    rec[1 * 64] = nfix;
+    rec[2 * 64] = skip;
+}
+
+extern "C" __global__ __launch_bounds__(256)
+void abea_ev_fix2_kernel(int n_reads, const int32_t* __restrict__ order, const int16_t* __restrict__ signal,
+                         const int64_t* __restrict__ sig_ptr, const int32_t* __restrict__ n_samples,
+                         const float* __restrict__ scaling, const int64_t* __restrict__ seg_base,
+                         const int32_t* __restrict__ wave_nseg, int32_t* __restrict__ fix_all,
+                         int32_t* __restrict__ segrec_all, int32_t* __restrict__ need_seq, int rna) {
+    const abea_ev_par P = ev_par(rna);
+    if (rna) fix2_body<7, 14>(n_reads, order, signal, sig_ptr, n_samples, scaling, seg_base, wave_nseg, fix_all, segrec_all, need_seq, P, ABEA_EV_FIX_RNA);
+    else fix2_body<3, 6>(n_reads, order, signal, sig_ptr, n_samples, scaling, seg_base, wave_nseg, fix_all, segrec_all, need_seq, P, ABEA_EV_FIX);
+}
+
+/* events of the unflagged reads (events.c:466-513): a wavefront per read, a lane per event, the event's two sums added up from
+ * its own samples (exact, see above: the reference's sums[end] - sums[start]).  Neighbouring lanes read neighbouring samples and
+ * write neighbouring event_t. */
+extern "C" __global__ __launch_bounds__(64)
+void abea_ev_create2_kernel(int n_reads, const int32_t* __restrict__ order, const int16_t* __restrict__ signal,
+                            const int64_t* __restrict__ sig_ptr, const int32_t* __restrict__ n_samples,
+                            const float* __restrict__ scaling, const int64_t* __restrict__ peak_base,
+                            const int32_t* __restrict__ wave_cap, const int32_t* __restrict__ peaks_lin,
+                            const int32_t* __restrict__ n_events, const int32_t* __restrict__ event_cap,
+                            abea_event_t* __restrict__ events, const int64_t* __restrict__ event_ptr,
+                            float* __restrict__ mean_all, const int32_t* __restrict__ need, int rna) {
+    const int slot = blockIdx.x;                                     /* grid.x = reads, grid.y = tiles of 64 events */
+    if (slot >= n_reads) return;
+    const int r = order[slot];
+    if (need[r]) return;
+    const int n = n_samples[r];
+    const int n_ev = n_events[r], cap = event_cap[r], ne = min(n_ev, cap);
+    if (n <= 0 || ne <= 0) return;
+    const int lane = threadIdx.x;
+    const int64_t lin = peak_base[slot >> 6] + (int64_t)(slot & 63) * wave_cap[slot >> 6];
+    const int32_t* __restrict__ pk = peaks_lin + lin;
+    float* __restrict__ mean = mean_all + lin;                       /* detection order: the scalings kernel's input */
+    const int16_t* __restrict__ sig = signal + sig_ptr[r];
+    const float offset = scaling[3 * r], raw_unit = scaling[3 * r + 1] / scaling[3 * r + 2];
+    abea_event_t* __restrict__ ev = events + event_ptr[r];
+    for (int e = blockIdx.y * 64 + lane; e < ne; e += gridDim.y * 64) {
+        const int start = e ? pk[e - 1] : 0;
+        const int end = (e >= n_ev - 1) ? n : pk[e];
+        double S = 0.0, Q = 0.0;
+        for (int i = start; i < end; ++i) {
+            const float x = abea_pa((int)sig[i], offset, raw_unit);
+            S += (double)x; Q += (double)__fmul_rn(x, x);
+        }
+        abea_event_t o;                                              /* events.c:497-513 */
+        o.start = (unsigned long long)start;
+        o.length = (float)((unsigned long long)end - (unsigned long long)start);
+        o.mean = (float)S / o.length;
+        const float deltasqr = (float)Q;
+        const float var = deltasqr / o.length - o.mean * o.mean;
+        o.stdv = sqrtf(fmaxf(var, 0.0f));
+        const int at = rna ? n_ev - 1 - e : e;                       /* RNA tables go out 3'->5' (f5c.c:711-719), the means stay in order */
+        if (at < cap) ev[at] = o;
+        mean[e] = o.mean;
+    }
+}
+
 /* pass 4: events from consecutive peaks (events.c:466-513), fully parallel: one thread per (read, event) */
 extern "C" __global__ __launch_bounds__(256)
 void abea_ev_create_kernel(int n_reads, const int32_t* __restrict__ order, const int32_t* __restrict__ n_samples,
@@ -1323,12 +1622,13 @@ void abea_ev_create_kernel(int n_reads, const int32_t* __restrict__ order, const
                            const int32_t* __restrict__ wave_cap, const int32_t* __restrict__ peaks_all,
                            const int32_t* __restrict__ n_events, const int32_t* __restrict__ event_cap,
                            abea_event_t* __restrict__ events, const int64_t* __restrict__ event_ptr,
-                           float* __restrict__ mean_all, int rna) {
+                           float* __restrict__ mean_all, int rna, const int32_t* __restrict__ need) {
     const int w = blockIdx.y;
     const int lane = threadIdx.x & 63;
     const int slot = w * 64 + lane;
     if (slot >= n_reads) return;
     const int r = order[slot];
+    if (need && !need[r]) return;                                    /* behind the fused common path: flagged reads only */
     const int n = n_samples[r];
     const int ne = min(n_events[r], event_cap[r]);
     const int64_t base = wave_base[w] + lane;

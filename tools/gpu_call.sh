@@ -42,6 +42,11 @@ case $STAGE in
     step n2_write 300 rocprofv3 --kernel-trace --output-format csv -d $O/n2_write -o n2 --pmc WRITE_SIZE -- python tools/n2_profile.py 2048
     find $O -name "*.csv" | head
     ;;
+  n2ab)       # the detector alone, no profiler: the fused common path against the array form (ABEA_EV_PATH=arrays), same process layout
+    step n2_fused 200 python tools/n2_profile.py 2048
+    ABEA_EV_PATH=arrays step n2_arrays 200 python tools/n2_profile.py 2048
+    grep -H "parameters" $O/n2_fused.log $O/n2_arrays.log
+    ;;
   tests)      # the whole GPU suite at the stamped commit (the round's gate: parity tests first, infrastructure last — tests/conftest.py)
     stamp $O/gpu_tests_tree.txt; cat $O/gpu_tests_tree.txt
     step gpu_tests ${SUITE_TIMEOUT:-1500} python -m pytest tests -m gpu -x -q --durations=12 -p no:cacheprovider
