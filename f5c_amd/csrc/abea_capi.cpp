@@ -38,11 +38,12 @@ __global__ void abea_ev_spec_kernel(int, const int32_t*, const int32_t*, const i
                                     const int64_t*, const int32_t*, uint16_t*, int32_t*, int);
 __global__ void abea_ev_fix_kernel(int, const int32_t*, const int32_t*, const int64_t*, const float*, const float*,
                                    const int64_t*, const int32_t*, int32_t*, int32_t*, int32_t*, int);
-__global__ void abea_ev_scan_kernel(int, const int32_t*, const int32_t*, const int64_t*, int32_t*, int32_t*, const uint32_t*,
-                                    int32_t*);
+__global__ void abea_ev_scan_kernel(int, const int32_t*, const int32_t*, const int64_t*, int32_t*, int32_t*);
 __global__ void abea_ev_gather_kernel(int, const int32_t*, const int32_t*, const int64_t*, const int32_t*,
                                       const uint16_t*, const int32_t*, const int32_t*, const int64_t*, const int32_t*,
-                                      int32_t*, const int32_t*, int);
+                                      int32_t*);
+__global__ void abea_ev_scan2_kernel(int, const int32_t*, const int32_t*, const int64_t*, int32_t*, const uint16_t*, const int32_t*,
+                                     const uint32_t*, int32_t*, int32_t*);
 __global__ void abea_ev_create_kernel(int, const int32_t*, const int32_t*, const int64_t*, const double*, const double*,
                                       const int64_t*, const int32_t*, const int32_t*, const int32_t*, const int32_t*,
                                       abea_event_t*, const int64_t*, float*, int, const int32_t*);
@@ -50,9 +51,10 @@ __global__ void abea_ev_spec2_kernel(int, const int32_t*, const int16_t*, const 
                                      const int64_t*, const int32_t*, uint16_t*, int32_t*, uint32_t*, int);
 __global__ void abea_ev_fix2_kernel(int, const int32_t*, const int16_t*, const int64_t*, const int32_t*, const float*,
                                     const int64_t*, const int32_t*, int32_t*, int32_t*, int32_t*, int);
-__global__ void abea_ev_create2_kernel(int, const int32_t*, const int16_t*, const int64_t*, const int32_t*, const float*,
-                                       const int64_t*, const int32_t*, const int32_t*, const int32_t*, const int32_t*,
-                                       abea_event_t*, const int64_t*, float*, const int32_t*, int);
+__global__ void abea_ev_create3_kernel(int, const int32_t*, const int16_t*, const int64_t*, const int32_t*, const float*,
+                                       const int64_t*, const int32_t*, const uint16_t*, const int32_t*, const int64_t*,
+                                       const int32_t*, const int32_t*, const int32_t*, abea_event_t*, const int64_t*, float*,
+                                       const int32_t*, int);
 __global__ void abea_ev_scalings_kernel(int, const int32_t*, const int64_t*, const int32_t*, const float*, const int32_t*,
                                         const int32_t*, const char*, const int64_t*, const int32_t*, const abea_model_t*, int,
                                         abea_scalings_t*);
@@ -427,7 +429,7 @@ size_t abea_detect_scratch_bytes(const int32_t* n_samples, const int32_t* event_
             if (n_kmers) wk = std::max(wk, n_kmers[order[q]]);
         }
         const size_t nseg = std::max<size_t>(1, ((size_t)std::max(len - 1, 0) + EV_SEG - 1) / EV_SEG);
-        bytes += (size_t)std::max(len, 1) * 64 * 24 + (size_t)cap * 64 * 12 + (size_t)wk * 64 * 4 + nseg * SEG_BYTES;
+        bytes += (size_t)std::max(len, 1) * 64 * 24 + (size_t)cap * 64 * 8 + (size_t)wk * 64 * 4 + nseg * SEG_BYTES;
     }
     return bytes + (1u << 20);
 }
@@ -466,8 +468,8 @@ int abea_detect_events_on(abea_ctx* c, const abea_signal_batch* B, const abea_ev
     int w0 = 0;
     while (w0 < n_waves_all) {
         /* ---- carve waves whose interleaved scratch fits the arena: per sample S,Q fp64 + two float t-statistics
-         *      (24 B: touched by flagged reads only since the fused common path), per event slot a peak position twice
-         *      (interleaved list of the sequential kernels, linear list of the common path) + a mean (12 B) ---- */
+         *      (24 B: touched by flagged reads only since the fused common path), per event slot a peak position + a mean
+         *      (8 B) ---- */
         const size_t idx_bytes = N * (4 + 8 + 4 + 12 + 8 + 4 + 8 + 4 + 4 + 4) + (size_t)n_waves_all * 56 + 8192;
         if (idx_bytes + (1u << 20) > X.scratch_bytes) return abea_fail(ABEA_ENOMEM, "arena too small for %d index records", n);
         const size_t budget = X.scratch_bytes - idx_bytes - 4096;
@@ -484,7 +486,7 @@ int abea_detect_events_on(abea_ctx* c, const abea_signal_batch* B, const abea_ev
             }
             const size_t need = (size_t)std::max(len, 1) * 64, pneed = (size_t)cap * 64, kneed = (size_t)wk * 64;
             const size_t nseg = std::max<size_t>(1, ((size_t)std::max(len - 1, 0) + EV_SEG - 1) / EV_SEG);
-            if ((entries + need) * 24 + (pentries + pneed) * 12 + (kentries + kneed) * 4 + (segs + nseg) * SEG_BYTES + 4096 > budget) break;
+            if ((entries + need) * 24 + (pentries + pneed) * 8 + (kentries + kneed) * 4 + (segs + nseg) * SEG_BYTES + 4096 > budget) break;
             seg_base.push_back((int64_t)segs); wave_nseg.push_back((int32_t)nseg); segs += nseg;
             wave_base.push_back((int64_t)entries); wave_len.push_back(len);
             peak_base.push_back((int64_t)pentries); wave_cap.push_back(cap);
@@ -518,8 +520,7 @@ int abea_detect_events_on(abea_ctx* c, const abea_signal_batch* B, const abea_ev
         float* dMean = (float*)(dPk + pentries);
         /* kentries floats behind the means: the k-mer level array of rounds 3-5 (the scalings kernel derives the levels itself now);
          * the space stays in the arithmetic — abea_detect_scratch_bytes and the chunk carving charge it — as head-room */
-        int32_t* dPkLin = (int32_t*)(dMean + pentries + kentries);   /* per-read linear peak lists (abea_ev_create2_kernel) */
-        uint8_t* dSegs = (uint8_t*)(dPkLin + pentries);
+        uint8_t* dSegs = (uint8_t*)(dMean + pentries + kentries);
         dSegs += (256 - ((uintptr_t)dSegs & 255)) & 255;
         uint16_t* dSpec = (uint16_t*)dSegs;
         int32_t* dFix = (int32_t*)(dSpec + segs * EV_SEG * 64);
@@ -565,9 +566,9 @@ int abea_detect_events_on(abea_ctx* c, const abea_signal_batch* B, const abea_ev
                 hipLaunchKernelGGL(abea_ev_fix_kernel, fgrid, dim3(256), 0, X.stream, nr, dOrder, dNs, dWb, dT1, dT2, dSb, dWn, dFix,
                                    dRec, dNeed, rna);
             hipLaunchKernelGGL(abea_ev_scan_kernel, dim3((unsigned)nw), dim3(64), 0, X.stream, nr, dOrder, dNs, dSb, dRec,
-                               B->n_events, (const uint32_t*)nullptr, (int32_t*)nullptr);
+                               B->n_events);
             hipLaunchKernelGGL(abea_ev_gather_kernel, sgrid, dim3(256), 0, X.stream, nr, dOrder, dNs, dSb, dWn, dSpec, dFix, dRec,
-                               dPb, dEc, dPk, dWc, 0);
+                               dPb, dEc, dPk);
             hipLaunchKernelGGL(abea_ev_detect_kernel, dim3((unsigned)nw), dim3(64), 0, X.stream, nr, dOrder, dNs, dWb, dT1, dT2,
                                dPb, dEc, dPk, B->n_events, seq_only ? (const int32_t*)nullptr : (const int32_t*)dNeed, rna);
             hipLaunchKernelGGL(abea_ev_create_kernel, dim3(etiles, (unsigned)nw), dim3(256), 0, X.stream, nr, dOrder, dNs, dWb, dS,
@@ -579,10 +580,8 @@ int abea_detect_events_on(abea_ctx* c, const abea_signal_batch* B, const abea_ev
             if (max_nseg > 1)
                 hipLaunchKernelGGL(abea_ev_fix2_kernel, fgrid, dim3(256), 0, X.stream, nr, dOrder, B->signal, dSig, dNs, dSc, dSb,
                                    dWn, dFix, dRec, dNeed, rna);
-            hipLaunchKernelGGL(abea_ev_scan_kernel, dim3((unsigned)nw), dim3(64), 0, X.stream, nr, dOrder, dNs, dSb, dRec,
-                               B->n_events, (const uint32_t*)dSegExp, dNeed);
-            hipLaunchKernelGGL(abea_ev_gather_kernel, sgrid, dim3(256), 0, X.stream, nr, dOrder, dNs, dSb, dWn, dSpec, dFix, dRec,
-                               dPb, dEc, dPkLin, dWc, 1);
+            hipLaunchKernelGGL(abea_ev_scan2_kernel, dim3((unsigned)nr), dim3(64), 0, X.stream, nr, dOrder, dNs, dSb, dRec,
+                               (const uint16_t*)dSpec, (const int32_t*)dFix, (const uint32_t*)dSegExp, B->n_events, dNeed);
             /* ---- ... and the array form behind it for the reads it flagged (sums that may round, a segment that never met its
              *      replay): sequential prefix sums, t-statistics, the sequential automaton, events from the prefix sums.  With no
              *      read flagged these four launches return at once. ---- */
@@ -594,9 +593,9 @@ int abea_detect_events_on(abea_ctx* c, const abea_signal_batch* B, const abea_ev
                                dPb, dEc, dPk, B->n_events, (const int32_t*)dNeed, rna);
             hipLaunchKernelGGL(abea_ev_create_kernel, dim3(etiles, (unsigned)nw), dim3(256), 0, X.stream, nr, dOrder, dNs, dWb, dS,
                                dQ, dPb, dWc, dPk, B->n_events, dEc, B->events, dEp, dMean, rna, (const int32_t*)dNeed);
-            const unsigned ctiles = (unsigned)std::max<int64_t>(1, std::min<int64_t>(16, (wave_cap[0] + 63) / 64));
-            hipLaunchKernelGGL(abea_ev_create2_kernel, dim3((unsigned)nr, ctiles), dim3(64), 0, X.stream, nr, dOrder, B->signal, dSig,
-                               dNs, dSc, dPb, dWc, (const int32_t*)dPkLin, (const int32_t*)B->n_events, dEc, B->events, dEp, dMean,
+            hipLaunchKernelGGL(abea_ev_create3_kernel, dim3((unsigned)nr, (unsigned)((max_nseg + 7) / 8)), dim3(64), 0, X.stream, nr,
+                               dOrder, B->signal, dSig, dNs, dSc, dSb, (const int32_t*)dRec, (const uint16_t*)dSpec,
+                               (const int32_t*)dFix, dPb, dWc, (const int32_t*)B->n_events, dEc, B->events, dEp, dMean,
                                (const int32_t*)dNeed, rna);
         }
         if (B->scalings)                                     /* one wavefront per read (round 6): grid = reads of this pass */

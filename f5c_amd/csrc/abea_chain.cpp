@@ -172,7 +172,7 @@ struct chunk_charge {
     static size_t wave_bytes(size_t len, int32_t cap, int32_t wk) {
         const size_t EV_SEG = 512, EV_FIXCAP = 48, SEG_BYTES = 64 * (EV_SEG * 2 + EV_FIXCAP * 4 + 12 * 4 + 2 * 8 + 4 * 4);   /* abea_capi.cpp */
         const size_t nseg = std::max<size_t>(1, (len - 1 + EV_SEG - 1) / EV_SEG);
-        return len * 64 * 24 + (size_t)cap * 64 * 12 + (size_t)wk * 64 * 4 + nseg * SEG_BYTES;
+        return len * 64 * 24 + (size_t)cap * 64 * 8 + (size_t)wk * 64 * 4 + nseg * SEG_BYTES;
     }
     /* total with the read added; commit = keep it */
     size_t with(int64_t ns, int32_t cap, int32_t L, int32_t K, bool commit) {

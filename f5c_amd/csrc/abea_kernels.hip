@@ -1189,8 +1189,7 @@ void abea_ev_fix_kernel(int n_reads, const int32_t* __restrict__ order, const in
 extern "C" __global__ __launch_bounds__(64)
 void abea_ev_scan_kernel(int n_reads, const int32_t* __restrict__ order, const int32_t* __restrict__ n_samples,
                          const int64_t* __restrict__ seg_base, int32_t* __restrict__ segrec_all,
-                         int32_t* __restrict__ n_events, const uint32_t* __restrict__ segexp_all,
-                         int32_t* __restrict__ need) {
+                         int32_t* __restrict__ n_events) {
     const int lane = threadIdx.x;
     const int slot = blockIdx.x * 64 + lane;
     if (slot >= n_reads) return;
@@ -1207,17 +1206,6 @@ void abea_ev_scan_kernel(int n_reads, const int32_t* __restrict__ order, const i
         rec += 12 * 64;
     }
     n_events[r] = run + 1;                                           /* events.c:491-497: one more event than peaks */
-    if (!segexp_all) return;
-    /* fused common path: the window and event sums were taken straight from the samples, which is the reference's
-     * S[b] - S[a] bit for bit only if no prefix sum of the read can round (the test of abea_ev_pscan_kernel, on the
-     * exponent ranges abea_ev_spec2_kernel recorded); a read that fails it is redone through the prefix-sum arrays */
-    const uint32_t* __restrict__ se = segexp_all + seg_base[blockIdx.x] * 4 * 64 + lane;
-    uint32_t xmin = 0x7f800000u, xmax = 0u, ymin = 0x7f800000u, ymax = 0u;
-    for (int j = 0; j < nseg; ++j) {
-        xmin = min(xmin, se[0]); xmax = max(xmax, se[64]); ymin = min(ymin, se[128]); ymax = max(ymax, se[192]);
-        se += 4 * 64;
-    }
-    if (!(abea_ev_sum_exact(xmin, xmax, n) && abea_ev_sum_exact(ymin, ymax, n))) need[r] = 1;
 }
 
 extern "C" __global__ __launch_bounds__(256)
@@ -1225,8 +1213,7 @@ void abea_ev_gather_kernel(int n_reads, const int32_t* __restrict__ order, const
                            const int64_t* __restrict__ seg_base, const int32_t* __restrict__ wave_nseg,
                            const uint16_t* __restrict__ spec_all, const int32_t* __restrict__ fix_all,
                            const int32_t* __restrict__ segrec_all, const int64_t* __restrict__ peak_base,
-                           const int32_t* __restrict__ event_cap, int32_t* __restrict__ peaks_all,
-                           const int32_t* __restrict__ wave_cap, int linear) {
+                           const int32_t* __restrict__ event_cap, int32_t* __restrict__ peaks_all) {
     const int w = blockIdx.y;
     const int lane = threadIdx.x & 63;
     const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -1240,14 +1227,11 @@ void abea_ev_gather_kernel(int n_reads, const int32_t* __restrict__ order, const
     const int32_t* __restrict__ rec = segrec_all + seg * 12 * 64 + lane;
     const uint16_t* __restrict__ sp = spec_all + seg * ABEA_EV_SEG * 64 + lane;
     const int32_t* __restrict__ fx = fix_all + seg * ABEA_EV_FIXCAP * 64 + lane;
-    /* linear != 0: one list per read (lane l of the wave at peak_base + l * wave_cap), what abea_ev_create2_kernel walks with
-     * a wavefront per read; else interleaved over the wave's lanes like the sequential kernels' lists */
-    int32_t* __restrict__ pk = peaks_all + peak_base[w] + (linear ? (int64_t)lane * wave_cap[w] : (int64_t)lane);
-    const size_t ps = linear ? 1 : 64;
+    int32_t* __restrict__ pk = peaks_all + peak_base[w] + lane;
     const int nspec = rec[0], nfix = min(rec[64], ABEA_EV_FIXCAP), skip = rec[128];
     int at = rec[3 * 64];
-    for (int e = 0; e < nfix; ++e, ++at) if (at < cap) pk[(size_t)at * ps] = fx[(size_t)e * 64];
-    for (int e = skip; e < nspec; ++e, ++at) if (at < cap) pk[(size_t)at * ps] = j * ABEA_EV_SEG + (int)sp[(size_t)e * 64];
+    for (int e = 0; e < nfix; ++e, ++at) if (at < cap) pk[(size_t)at * 64] = fx[(size_t)e * 64];
+    for (int e = skip; e < nspec; ++e, ++at) if (at < cap) pk[(size_t)at * 64] = j * ABEA_EV_SEG + (int)sp[(size_t)e * 64];
 }
 
 extern "C" __global__ __launch_bounds__(64)
@@ -1350,8 +1334,9 @@ void abea_ev_detect_kernel(int n_reads, const int32_t* __restrict__ order, const
  *                          expressions of events.c:343-366 (abea_tstat_w) and go into the automaton in the same step — no
  *                          prefix-sum array, no t-statistic array;
  *   abea_ev_fix2_kernel    the replay window of abea_ev_fix_kernel with the t-statistics recomputed the same way;
- *   abea_ev_scan_kernel    also reduces the exponent ranges spec2 recorded and flags a read whose sums may round;
- *   abea_ev_create2_kernel a wavefront per read, a lane per event: the event's sums are added up from its samples.
+ *   abea_ev_scan2_kernel   a wavefront per read: where each segment's events start, and the exponent ranges spec2 recorded ->
+ *                          a read whose sums may round is flagged;
+ *   abea_ev_create3_kernel a lane per event, straight from the segments' peak lists: the event's sums are added up from its samples.
  * A flagged read (sums may round, or a segment that never met its replay) goes through the array kernels above, which run
  * behind the common path on flagged reads only: sequential prefix sums, t-statistic arrays, the sequential automaton, events
  * from the prefix sums.  ABEA_EV_PATH=arrays selects the array form for every read (the A/B of profiles/r06).
@@ -1568,49 +1553,136 @@ void abea_ev_fix2_kernel(int n_reads, const int32_t* __restrict__ order, const i
     else fix2_body<3, 6>(n_reads, order, signal, sig_ptr, n_samples, scaling, seg_base, wave_nseg, fix_all, segrec_all, need_seq, P, ABEA_EV_FIX);
 }
 
-/* events of the unflagged reads (events.c:466-513): a wavefront per read, a lane per event, the event's two sums added up from
- * its own samples (exact, see above: the reference's sums[end] - sums[start]).  Neighbouring lanes read neighbouring samples and
- * write neighbouring event_t. */
+/* The per-read part of the common path, one wavefront per READ (the lane-per-read abea_ev_scan_kernel walks a read's ~440 segment
+ * records one dependent load after the other: 0.57 ms per 2048 reads).  64 segments at a time: peak counts -> exclusive running sum
+ * (rec[3], where the segment's events start), the last peak of the nearest non-empty segment before it (rec[11]: where the segment's
+ * first event starts; the lists are walked in list order, never sorted), the exponent ranges abea_ev_spec2_kernel recorded -> the
+ * exactness test of abea_ev_pscan_kernel (a read that fails it is flagged for the array kernels), and n_events. */
 extern "C" __global__ __launch_bounds__(64)
-void abea_ev_create2_kernel(int n_reads, const int32_t* __restrict__ order, const int16_t* __restrict__ signal,
+void abea_ev_scan2_kernel(int n_reads, const int32_t* __restrict__ order, const int32_t* __restrict__ n_samples,
+                          const int64_t* __restrict__ seg_base, int32_t* __restrict__ segrec_all,
+                          const uint16_t* __restrict__ spec_all, const int32_t* __restrict__ fix_all,
+                          const uint32_t* __restrict__ segexp_all, int32_t* __restrict__ n_events, int32_t* __restrict__ need) {
+    const int slot = blockIdx.x, lane = threadIdx.x;
+    if (slot >= n_reads) return;
+    const int r = order[slot];
+    const int n = n_samples[r];
+    if (n <= 0) { if (lane == 0) n_events[r] = 0; return; }
+    const int nseg = (n + ABEA_EV_SEG - 1) / ABEA_EV_SEG;
+    const int w = slot >> 6, l = slot & 63;
+    int run = 0, prev = 0;                                           /* carried over the chunks of 64 segments (wave-uniform) */
+    uint32_t xmin = 0x7f800000u, xmax = 0u, ymin = 0x7f800000u, ymax = 0u;
+    for (int c0 = 0; c0 < nseg; c0 += 64) {
+        const int j = c0 + lane;
+        const bool live = j < nseg;
+        const int64_t seg = seg_base[w] + (live ? j : c0);
+        int32_t* __restrict__ rec = segrec_all + seg * 12 * 64 + l;
+        const int nspec = live ? rec[0] : 0, nfix_raw = live ? rec[64] : 0, skip = live ? rec[128] : 0;
+        const int cnt = nspec + nfix_raw - skip;                     /* as abea_ev_scan_kernel */
+        const int nfix = min(nfix_raw, ABEA_EV_FIXCAP);              /* more than the cap: the read is flagged, only the addressing must hold */
+        int last = 0;
+        if (live && nspec - skip > 0) last = j * ABEA_EV_SEG + (int)spec_all[seg * ABEA_EV_SEG * 64 + (int64_t)(nspec - 1) * 64 + l];
+        else if (live && nfix > 0) last = fix_all[seg * ABEA_EV_FIXCAP * 64 + (int64_t)(nfix - 1) * 64 + l];
+        if (live) {
+            const uint32_t* __restrict__ se = segexp_all + seg * 4 * 64 + l;
+            xmin = min(xmin, se[0]); xmax = max(xmax, se[64]); ymin = min(ymin, se[128]); ymax = max(ymax, se[192]);
+        }
+        /* inclusive scans over the 64 lanes: the running count, and the nearest lane at or below that has a peak */
+        int inc = cnt, src = cnt > 0 ? lane : -1;
+        #pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int a = __shfl_up(inc, off, 64), b = __shfl_up(src, off, 64);
+            if (lane >= off) { inc += a; src = max(src, b); }
+        }
+        const int src_ex = __shfl_up(src, 1, 64);                    /* exclusive: nearest lane BELOW with a peak */
+        const int from = lane > 0 ? src_ex : -1;
+        const int got = __shfl(last, max(from, 0), 64);
+        if (live) {
+            rec[3 * 64] = run + inc - cnt;
+            rec[11 * 64] = from >= 0 ? got : prev;
+        }
+        const int src_all = __shfl(src, 63, 64);
+        if (src_all >= 0) prev = __shfl(last, src_all, 64);
+        run += __shfl(inc, 63, 64);
+    }
+    #pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        xmin = min(xmin, (uint32_t)__shfl_xor((int)xmin, off, 64)); xmax = max(xmax, (uint32_t)__shfl_xor((int)xmax, off, 64));
+        ymin = min(ymin, (uint32_t)__shfl_xor((int)ymin, off, 64)); ymax = max(ymax, (uint32_t)__shfl_xor((int)ymax, off, 64));
+    }
+    if (lane != 0) return;
+    n_events[r] = run + 1;                                           /* events.c:491-497: one more event than peaks */
+    if (!(abea_ev_sum_exact(xmin, xmax, n) && abea_ev_sum_exact(ymin, ymax, n))) need[r] = 1;
+}
+
+/* Events of the unflagged reads (events.c:466-513) straight from the segments' peak lists and the samples: a wavefront per (read,
+ * group of ABEA_EV_CGRP segments), a lane per event.  An event ends at one peak of the segment (replay peaks first, then the
+ * speculative run's from `skip` on — what abea_ev_gather_kernel copies into a per-read list in the array form; that list no longer
+ * exists here) and starts at the peak before it, the neighbouring lane's or rec[11] for the segment's first; the read's last event
+ * ends at n.  The two sums are added up from the event's own samples (exact, see above: the reference's sums[end] - sums[start]).
+ * grid.x = reads: the 64 reads whose lists share cache lines run side by side. */
+#define ABEA_EV_CGRP 8
+extern "C" __global__ __launch_bounds__(64)
+void abea_ev_create3_kernel(int n_reads, const int32_t* __restrict__ order, const int16_t* __restrict__ signal,
                             const int64_t* __restrict__ sig_ptr, const int32_t* __restrict__ n_samples,
-                            const float* __restrict__ scaling, const int64_t* __restrict__ peak_base,
-                            const int32_t* __restrict__ wave_cap, const int32_t* __restrict__ peaks_lin,
-                            const int32_t* __restrict__ n_events, const int32_t* __restrict__ event_cap,
-                            abea_event_t* __restrict__ events, const int64_t* __restrict__ event_ptr,
-                            float* __restrict__ mean_all, const int32_t* __restrict__ need, int rna) {
-    const int slot = blockIdx.x;                                     /* grid.x = reads, grid.y = tiles of 64 events */
+                            const float* __restrict__ scaling, const int64_t* __restrict__ seg_base,
+                            const int32_t* __restrict__ segrec_all, const uint16_t* __restrict__ spec_all,
+                            const int32_t* __restrict__ fix_all, const int64_t* __restrict__ peak_base,
+                            const int32_t* __restrict__ wave_cap, const int32_t* __restrict__ n_events,
+                            const int32_t* __restrict__ event_cap, abea_event_t* __restrict__ events,
+                            const int64_t* __restrict__ event_ptr, float* __restrict__ mean_all,
+                            const int32_t* __restrict__ need, int rna) {
+    const int slot = blockIdx.x, lane = threadIdx.x;
     if (slot >= n_reads) return;
     const int r = order[slot];
     if (need[r]) return;
     const int n = n_samples[r];
     const int n_ev = n_events[r], cap = event_cap[r], ne = min(n_ev, cap);
     if (n <= 0 || ne <= 0) return;
-    const int lane = threadIdx.x;
-    const int64_t lin = peak_base[slot >> 6] + (int64_t)(slot & 63) * wave_cap[slot >> 6];
-    const int32_t* __restrict__ pk = peaks_lin + lin;
-    float* __restrict__ mean = mean_all + lin;                       /* detection order: the scalings kernel's input */
+    const int nseg = (n + ABEA_EV_SEG - 1) / ABEA_EV_SEG;
+    const int w = slot >> 6, l = slot & 63;
+    float* __restrict__ mean = mean_all + peak_base[w] + (int64_t)l * wave_cap[w];   /* detection order: the scalings kernel's input */
     const int16_t* __restrict__ sig = signal + sig_ptr[r];
     const float offset = scaling[3 * r], raw_unit = scaling[3 * r + 1] / scaling[3 * r + 2];
     abea_event_t* __restrict__ ev = events + event_ptr[r];
-    for (int e = blockIdx.y * 64 + lane; e < ne; e += gridDim.y * 64) {
-        const int start = e ? pk[e - 1] : 0;
-        const int end = (e >= n_ev - 1) ? n : pk[e];
-        double S = 0.0, Q = 0.0;
-        for (int i = start; i < end; ++i) {
-            const float x = abea_pa((int)sig[i], offset, raw_unit);
-            S += (double)x; Q += (double)__fmul_rn(x, x);
+    for (int j = blockIdx.y * ABEA_EV_CGRP; j < min(nseg, (int)(blockIdx.y + 1) * ABEA_EV_CGRP); ++j) {
+        const int64_t seg = seg_base[w] + j;
+        const int32_t* __restrict__ rec = segrec_all + seg * 12 * 64 + l;
+        const uint16_t* __restrict__ sp = spec_all + seg * ABEA_EV_SEG * 64 + l;
+        const int32_t* __restrict__ fx = fix_all + seg * ABEA_EV_FIXCAP * 64 + l;
+        const int nspec = rec[0], nfix = min(rec[64], ABEA_EV_FIXCAP), skip = rec[128], run = rec[3 * 64];
+        int before = rec[11 * 64];                                   /* the last peak before this segment (0: none) */
+        const int c = nfix + nspec - skip;
+        const int todo = c + (j == nseg - 1 ? 1 : 0);                /* the read's last event ends at n */
+        for (int i0 = 0; i0 < todo; i0 += 64) {
+            const int i = i0 + lane;
+            int end = n;
+            if (i < nfix) end = fx[(size_t)i * 64];
+            else if (i < c) end = j * ABEA_EV_SEG + (int)sp[(size_t)(skip + i - nfix) * 64];
+            const int up = __shfl_up(end, 1, 64);
+            const int start = lane ? up : before;
+            before = __shfl(end, 63, 64);
+            const int e = run + i;
+            if (i >= todo || e >= ne) continue;
+            /* sums[end] - sums[start]: the samples of [start, end); a list that ran backwards would give the negated sum of [end, start) */
+            const int a = min(start, end), b = max(start, end);
+            double S = 0.0, Q = 0.0;
+            for (int q = a; q < b; ++q) {
+                const float x = abea_pa((int)sig[q], offset, raw_unit);
+                S += (double)x; Q += (double)__fmul_rn(x, x);
+            }
+            if (end < start) { S = 0.0 - S; Q = 0.0 - Q; }
+            abea_event_t o;                                          /* events.c:497-513 */
+            o.start = (unsigned long long)start;
+            o.length = (float)((unsigned long long)end - (unsigned long long)start);
+            o.mean = (float)S / o.length;
+            const float deltasqr = (float)Q;
+            const float var = deltasqr / o.length - o.mean * o.mean;
+            o.stdv = sqrtf(fmaxf(var, 0.0f));
+            const int at = rna ? n_ev - 1 - e : e;                   /* RNA tables go out 3'->5' (f5c.c:711-719), the means stay in order */
+            if (at < cap) ev[at] = o;
+            mean[e] = o.mean;
         }
-        abea_event_t o;                                              /* events.c:497-513 */
-        o.start = (unsigned long long)start;
-        o.length = (float)((unsigned long long)end - (unsigned long long)start);
-        o.mean = (float)S / o.length;
-        const float deltasqr = (float)Q;
-        const float var = deltasqr / o.length - o.mean * o.mean;
-        o.stdv = sqrtf(fmaxf(var, 0.0f));
-        const int at = rna ? n_ev - 1 - e : e;                       /* RNA tables go out 3'->5' (f5c.c:711-719), the means stay in order */
-        if (at < cap) ev[at] = o;
-        mean[e] = o.mean;
     }
 }
 

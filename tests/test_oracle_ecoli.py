@@ -133,6 +133,56 @@ def test_gpu_event_detection_adversarial_signals(ctx, orc):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("rna", [False, True])
+def test_gpu_detector_common_path_equals_the_array_and_sequential_forms(ctx, r9, monkeypatch, rna):
+    """Round 6: the common path takes window and event sums straight from the samples (abea_ev_spec2 / fix2 / create2 kernels, no
+    prefix-sum or t-statistic arrays) and hands flagged reads — sums that may round, segments that never meet their replay — to the
+    array kernels behind it.  Its tables and scalings must equal, byte for byte, the array form of rounds 3-5 (ABEA_EV_PATH=arrays)
+    and the fully sequential form (ABEA_EV_SEQUENTIAL), on real reads, synthetic reads, signals that take either fallback, reads
+    shorter than a window and reads ending one sample into a segment."""
+    from f5c_amd import synth
+    k, model = r9
+    r = np.random.default_rng(17)
+    reads = list(_reads())
+    sigs = [x["sig"] for x in reads]
+    scal = [[x["offset"], x["range"], x["digitisation"]] for x in reads]
+    seqs = [x["seq"] for x in reads]
+    b = synth.make_batch(70, model, k, seed=92, law=3000, bad_frac=0.0)
+    s_sigs, s_scal = synth.make_signals(b, seed=4)
+    sigs += s_sigs; scal += [list(x) for x in s_scal]
+    seqs += [b["reads"][int(b["read_ptr"][i]):int(b["read_ptr"][i]) + int(b["read_len"][i])].tobytes() for i in range(70)]
+    extra = [np.full(5000, 500, np.int16), np.full(1, 500, np.int16), np.full(2, 300, np.int16), np.full(13, 500, np.int16),
+             r.integers(300, 700, 512).astype(np.int16), r.integers(300, 700, 513).astype(np.int16),
+             r.integers(300, 700, 1025).astype(np.int16), r.integers(300, 700, 100000).astype(np.int16),
+             np.repeat(r.integers(300, 700, 400), 250).astype(np.int16),
+             (500 + 100 * np.sin(np.arange(200000) / 50.0)).astype(np.int16),
+             r.integers(-32768, 32767, 30000).astype(np.int16)]
+    sigs += extra; scal += [[10.0, 1467.61, 8192.0]] * len(extra)
+    sigs.append(r.integers(495, 700, 60000).astype(np.int16)); scal.append([-499.999, 1467.61, 8192.0])   # samples next to 0 pA: sums may round
+    sigs.append(np.zeros(3000, np.int16)); scal.append([0.0, 1467.61, 8192.0])                               # all samples exactly 0 pA
+    seqs += [bytes(r.choice(list(b"ACGT"), 700).astype(np.uint8))] * (len(extra) + 2)
+    scal = np.array(scal, dtype=np.float32)
+
+    def run(**env):
+        for name in ("ABEA_EV_PATH", "ABEA_EV_SEQUENTIAL"):
+            monkeypatch.delenv(name, raising=False)
+        for name, v in env.items():
+            monkeypatch.setenv(name, v)
+        return ctx.detect_events_device(sigs, scal, seqs=seqs, rna=rna, cap_div=1)
+    evs, ne, sc = run()
+    for form in (dict(ABEA_EV_PATH="arrays"), dict(ABEA_EV_SEQUENTIAL="1")):
+        evs2, ne2, sc2 = run(**form)
+        assert (ne == ne2).all(), form
+        for i in range(len(sigs)):
+            for f in ("start", "length", "mean", "stdv"):                # field by field: event_t has 4 bytes of tail padding
+                a, b2 = evs[i][f], evs2[i][f]
+                assert a.tobytes() == b2.tobytes(), (form, i, f, len(sigs[i]))
+        for f in ("scale", "shift"):
+            assert (sc[f].view(np.uint32) == sc2[f].view(np.uint32)).all(), (form, f)
+    assert ne.sum() > 100000
+
+
+@pytest.mark.gpu
 def test_gpu_raw_signal_to_recalibrated_scalings(ctx, orc, r9):
     """Whole device chain on real reads: raw signal -> events -> scalings -> ABEA -> scaling_single; the printed
     recalib_scalings.exp / adaptive.exp values of the reference come out of the GPU."""
