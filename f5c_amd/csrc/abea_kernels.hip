@@ -1344,6 +1344,40 @@ void abea_ev_detect_kernel(int n_reads, const int32_t* __restrict__ order, const
  * reads, so a load touches 64 cache lines; fetching a whole 128-byte line per lane at a time (eight 16-byte loads back to back)
  * uses every byte of a line while it is hot — the lane-per-read kernels that take 16 bytes per line and come back for the next
  * 16 a microsecond later re-fetch lines (abea_ev_psum_kernel: 10 B per sample counted for 2 read). */
+/* The t-statistic with its five divisions by the window length W in 3 instructions each instead of the 10 (float) / 12 (double) of
+ * an IEEE division:    q0 = x * rc;  r = fma(-q0, W, x);  q = fma(r, rc, q0),  rc = RN(1 / W)    — the correctly rounded x / W for
+ * W in {3, 6, 7, 14} (events.c:52-65) and every x the guard below lets through:
+ *   - r is x - q0 W exactly (q0 is within 2^-52 of x / W relative, so the difference fits the format) and the value the last fma
+ *     rounds, v = q0 + r rc, is within |r| |rc - 1/W| <= 2^-51 ulp of x / W = q0 + r / W;
+ *   - x / W, in units of its own ulp, is an integer multiple of 1/3 or 1/7 (W = 2^s 3 or 2^s 7): it is representable or at least 1/14
+ *     ulp away from every representable number and from every midpoint between two — so v lies on the same side of every rounding
+ *     boundary as x / W and RN(v) = RN(x / W).
+ * That needs q0, r and q normal.  Doubles here are exact sums of <= 14 floats: finite is enough.  Floats: all 2^32 inputs were
+ * checked against x / W per divisor (tools/proto/div_const_check.c): the only mismatches are x = +-inf (the sequence makes NaN) and
+ * |x / W| < 4 FLT_MIN (double rounding among subnormals) — those, NaN and the FLT_MIN clamp of a zero variance take the IEEE
+ * divisions of abea_tstat_w, a branch that real signals do not enter. */
+template <int W>
+static __device__ __forceinline__ float abea_tstat_fast(double sum1, double sum2d, double sumsq1, double sumsq2d) {
+    constexpr float wf = (float)W, rcf = 1.0f / (float)W;
+    constexpr double wd = (double)W, rcd = 1.0 / (double)W;
+    auto divf = [&](float x) { const float q0 = __fmul_rn(x, rcf); return __fmaf_rn(__fmaf_rn(-q0, wf, x), rcf, q0); };
+    auto divd = [&](double x) { const double q0 = __dmul_rn(x, rcd); return __fma_rn(__fma_rn(-q0, wd, x), rcd, q0); };
+    const float sum2 = (float)sum2d;
+    const float sumsq2 = (float)sumsq2d;
+    const float mean1 = (float)divd(sum1);
+    const float mean2 = divf(sum2);
+    float combined_var = (float)(((divd(sumsq1) - (double)(mean1 * mean1)) + (double)divf(sumsq2)) - (double)(mean2 * mean2));
+    combined_var = fmaxf(combined_var, 1.17549435e-38f);            /* FLT_MIN */
+    const float delta_mean = mean2 - mean1;
+    float t = fabsf(delta_mean) / sqrtf(divf(combined_var));
+    constexpr float tiny = 0x1p-118f, inf = __builtin_inff();
+    const float a2 = fabsf(sum2), aq = fabsf(sumsq2);
+    const bool ok = a2 >= tiny && a2 < inf && aq >= tiny && aq < inf && combined_var >= tiny && combined_var < inf &&
+                    fabs(sum1) < (double)inf && fabs(sumsq1) < (double)inf;     /* zeros too go the IEEE way (-0 / W = -0, the sequence +0) */
+    if (!ok) t = abea_tstat_w(sum1, sum2d, sumsq1, sumsq2d, wf);
+    return t;
+}
+
 template <int W1, int W2>
 struct abea_ev_win {
     float x[2 * W2];                      /* samples p - W2 .. p + W2 - 1 in pA (0 outside the read) when position p is evaluated */
@@ -1372,8 +1406,8 @@ struct abea_ev_win {
     }
     /* events.c:336-347: zero where a window does not fit the read */
     __device__ __forceinline__ void tstats(int p, int n, float& a, float& b) const {
-        const float ta = abea_tstat_w(sl1, sr1, ql1, qr1, (float)W1);
-        const float tb = abea_tstat_w(sl2, sr2, ql2, qr2, (float)W2);
+        const float ta = abea_tstat_fast<W1>(sl1, sr1, ql1, qr1);
+        const float tb = abea_tstat_fast<W2>(sl2, sr2, ql2, qr2);
         a = (n >= 2 * W1 && p >= W1 && p <= n - W1) ? ta : 0.f;
         b = (n >= 2 * W2 && p >= W2 && p <= n - W2) ? tb : 0.f;
     }
