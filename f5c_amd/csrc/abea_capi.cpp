@@ -48,7 +48,9 @@ __global__ void abea_ev_create_kernel(int, const int32_t*, const int32_t*, const
                                       const int64_t*, const int32_t*, const int32_t*, const int32_t*, const int32_t*,
                                       abea_event_t*, const int64_t*, float*, int, const int32_t*);
 __global__ void abea_ev_spec2_kernel(int, const int32_t*, const int16_t*, const int64_t*, const int32_t*, const float*,
-                                     const int64_t*, const int32_t*, uint16_t*, int32_t*, uint32_t*, int);
+                                     const int64_t*, const int32_t*, uint16_t*, int32_t*, uint32_t*);
+__global__ void abea_ev_spec2_rna_kernel(int, const int32_t*, const int16_t*, const int64_t*, const int32_t*, const float*,
+                                         const int64_t*, const int32_t*, uint16_t*, int32_t*, uint32_t*);
 __global__ void abea_ev_fix2_kernel(int, const int32_t*, const int16_t*, const int64_t*, const int32_t*, const float*,
                                     const int64_t*, const int32_t*, int32_t*, int32_t*, int32_t*, int);
 __global__ void abea_ev_create3_kernel(int, const int32_t*, const int16_t*, const int64_t*, const int32_t*, const float*,
@@ -57,7 +59,7 @@ __global__ void abea_ev_create3_kernel(int, const int32_t*, const int16_t*, cons
                                        const int32_t*, int);
 __global__ void abea_ev_scalings_kernel(int, const int32_t*, const int64_t*, const int32_t*, const float*, const int32_t*,
                                         const int32_t*, const char*, const int64_t*, const int32_t*, const abea_model_t*, int,
-                                        abea_scalings_t*);
+                                        abea_scalings_t*, float*, const int64_t*, const int32_t*);
 }
 
 /* ------------------------------------------------------------------ errors */
@@ -508,7 +510,7 @@ int abea_detect_events_on(abea_ctx* c, const abea_signal_batch* B, const abea_ev
         const size_t o_ec = put(B->event_cap, N * 4), o_rp = put(B->read_ptr, N * 8), o_rl = put(B->read_len, N * 4);
         const size_t o_wb = put(wave_base.data(), (size_t)nw * 8), o_wl = put(wave_len.data(), (size_t)nw * 4);
         const size_t o_pb = put(peak_base.data(), (size_t)nw * 8), o_wc = put(wave_cap.data(), (size_t)nw * 4);
-        put(kmer_base.data(), (size_t)nw * 8); put(wave_k.data(), (size_t)nw * 4);      /* unused since round 6 (see dSegs below); the index block keeps its layout */
+        const size_t o_kb = put(kmer_base.data(), (size_t)nw * 8), o_wk = put(wave_k.data(), (size_t)nw * 4);   /* the scalings kernel's rows of k-mer levels */
         const size_t o_sb = put(seg_base.data(), (size_t)nw * 8), o_wn = put(wave_nseg.data(), (size_t)nw * 4);
         const size_t o_need = put(nullptr, N * 4);                    /* per-read "segments never met" flags, zeroed */
         const size_t o_need_s = put(nullptr, N * 4);                  /* per-read "prefix sums may round" flags */
@@ -518,8 +520,7 @@ int abea_detect_events_on(abea_ctx* c, const abea_signal_batch* B, const abea_ev
         float* dT2 = dT1 + entries;
         int32_t* dPk = (int32_t*)(dT2 + entries);
         float* dMean = (float*)(dPk + pentries);
-        /* kentries floats behind the means: the k-mer level array of rounds 3-5 (the scalings kernel derives the levels itself now);
-         * the space stays in the arithmetic — abea_detect_scratch_bytes and the chunk carving charge it — as head-room */
+        /* kentries floats behind the means: a row of k-mer levels per read, written and read back by the scalings kernel */
         uint8_t* dSegs = (uint8_t*)(dMean + pentries + kentries);
         dSegs += (256 - ((uintptr_t)dSegs & 255)) & 255;
         uint16_t* dSpec = (uint16_t*)dSegs;
@@ -575,8 +576,8 @@ int abea_detect_events_on(abea_ctx* c, const abea_signal_batch* B, const abea_ev
                                dQ, dPb, dWc, dPk, B->n_events, dEc, B->events, dEp, dMean, rna, (const int32_t*)nullptr);
         } else {
             /* ---- the common path straight from the samples (round 6; abea_kernels.hip) ... ---- */
-            hipLaunchKernelGGL(abea_ev_spec2_kernel, dim3((unsigned)max_nseg, (unsigned)nw), dim3(64), 0, X.stream, nr, dOrder,
-                               B->signal, dSig, dNs, dSc, dSb, dWn, dSpec, dRec, dSegExp, rna);
+            hipLaunchKernelGGL(rna ? abea_ev_spec2_rna_kernel : abea_ev_spec2_kernel, dim3((unsigned)max_nseg, (unsigned)nw), dim3(64), 0,
+                               X.stream, nr, dOrder, B->signal, dSig, dNs, dSc, dSb, dWn, dSpec, dRec, dSegExp);
             if (max_nseg > 1)
                 hipLaunchKernelGGL(abea_ev_fix2_kernel, fgrid, dim3(256), 0, X.stream, nr, dOrder, B->signal, dSig, dNs, dSc, dSb,
                                    dWn, dFix, dRec, dNeed, rna);
@@ -602,7 +603,8 @@ int abea_detect_events_on(abea_ctx* c, const abea_signal_batch* B, const abea_ev
             hipLaunchKernelGGL(abea_ev_scalings_kernel, dim3((unsigned)nr), dim3(64), 0, X.stream,
                                nr, (const int32_t*)(d + o_order), (const int64_t*)(d + o_pb), (const int32_t*)(d + o_wc), dMean,
                                B->n_events, (const int32_t*)(d + o_ec), B->reads, (const int64_t*)(d + o_rp),
-                               (const int32_t*)(d + o_rl), c->d_model, (int)c->k, B->scalings);
+                               (const int32_t*)(d + o_rl), c->d_model, (int)c->k, B->scalings, dMean + pentries,
+                               (const int64_t*)(d + o_kb), (const int32_t*)(d + o_wk));
         if (X.e1) HIP_TRY(hipEventRecord(X.e1, X.stream));
         HIP_TRY(hipGetLastError());
         if (X.async) {

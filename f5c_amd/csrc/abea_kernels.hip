@@ -113,6 +113,26 @@ static __device__ __forceinline__ uint32_t kmer_rank_at(const char* __restrict__
     return rank;
 }
 
+/* the two halves of it, for callers that want the load in flight before they need the rank: the 12 bytes at seq[i] (assembled
+ * base by base, zero-filled, where the window would pass the read's terminator), and the rank from those words */
+static __device__ __forceinline__ void kmer_window_at(const char* __restrict__ seq, int i, int L, int kmer_size, uint32_t w[3]) {
+    if (i + 12 <= L + 1) {
+        __builtin_memcpy(w, seq + i, 12);
+    } else {
+        w[0] = w[1] = w[2] = 0u;
+        #pragma unroll                                               /* static indices: a dynamically indexed w[] is moved to LDS by the compiler */
+        for (int j = 0; j < ABEA_MAX_KMER_SIZE; ++j)
+            if (j < kmer_size) w[j >> 2] |= (uint32_t)(unsigned char)seq[i + j] << (8 * (j & 3));
+    }
+}
+static __device__ __forceinline__ uint32_t kmer_rank_of_window(const uint32_t w[3], int kmer_size) {
+    uint32_t rank = 0;
+    #pragma unroll
+    for (int j = 0; j < ABEA_MAX_KMER_SIZE; ++j)
+        if (j < kmer_size) rank = (rank << 2) | base_code((w[j >> 2] >> (8 * (j & 3))) & 0xFFu);
+    return rank;
+}
+
 extern "C" __global__ __launch_bounds__(256)
 void abea_pre_kernel(const abea_read_desc* __restrict__ descs,
                      const char* __restrict__ reads, const abea_event_t* __restrict__ events,
@@ -1413,9 +1433,12 @@ struct abea_ev_win {
     }
 };
 
-#define ABEA_EV_ROW 132      /* uint16 per staged row: two 64-sample blocks + pad (264 bytes = 66 dwords: neighbouring rows 2 banks apart) */
-
-template <int W1, int W2>
+/* BLK = samples per staged block (a lane fetches BLK / 8 16-byte chunks back to back); a lane's LDS row is a ring of two blocks + 4
+ * samples of padding.  The newest sample a step needs is at most 2 W2 + 7 + (BLK - 1) samples past the start of the block the step
+ * began in, which must stay below 2 BLK: RNA (W2 = 14) takes whole 128-byte lines (BLK = 64, 264-byte rows, 9 wavefronts per CU);
+ * DNA (W2 = 6) gets by with half lines (BLK = 32, 136-byte rows) and fits twice the wavefronts — the loop is a long dependent
+ * chain per lane (two t-statistics, an automaton step) and lives on occupancy. */
+template <int W1, int W2, int BLK>
 static __device__ __forceinline__ void spec2_body(int n_reads, const int32_t* __restrict__ order, const int16_t* __restrict__ signal,
                           const int64_t* __restrict__ sig_ptr, const int32_t* __restrict__ n_samples,
                           const float* __restrict__ scaling, const int64_t* __restrict__ seg_base,
@@ -1439,23 +1462,25 @@ static __device__ __forceinline__ void spec2_body(int n_reads, const int32_t* __
     uint16_t* __restrict__ out = spec_all + seg * ABEA_EV_SEG * 64 + lane;
     int32_t* __restrict__ rec = segrec_all + seg * 12 * 64 + lane;
     uint32_t* __restrict__ se = segexp_all + seg * 4 * 64 + lane;
-    uint16_t* __restrict__ my = rows + lane * ABEA_EV_ROW;
+    static_assert(2 * W2 + 7 + BLK - 1 < 2 * BLK, "the ring must hold the newest sample of every step");
+    constexpr int ROW = 2 * BLK + 4, RING = 2 * BLK - 1;
+    uint16_t* __restrict__ my = rows + lane * ROW;
 
-    /* the row is a ring of two 64-sample blocks; block b holds the samples i0 + 64 b .. i0 + 64 b + 63, i0 = the sample at the
+    /* the row is a ring of two BLK-sample blocks; block b holds the samples i0 + BLK b .. i0 + BLK b + BLK - 1, i0 = the sample at the
      * 16-byte boundary at or below the first one needed */
     const int q0 = lo - W2;
     const int sh = (int)(((uintptr_t)sig + (uintptr_t)(2 * (int64_t)q0)) & 15u) >> 1;
     const int i0 = q0 - sh;
     auto load_block = [&](int b) {
-        const int b0 = i0 + 64 * b;
-        if (b0 >= n || b0 + 64 <= 0) return;                         /* nothing of the read in it */
-        uint4 c[8];
-        if (b0 >= 0 && b0 + 64 <= n) {
+        const int b0 = i0 + BLK * b;
+        if (b0 >= n || b0 + BLK <= 0) return;                        /* nothing of the read in it */
+        uint4 c[BLK / 8];
+        if (b0 >= 0 && b0 + BLK <= n) {
             #pragma unroll
-            for (int u = 0; u < 8; ++u) c[u] = *reinterpret_cast<const uint4*>(sig + b0 + 8 * u);
+            for (int u = 0; u < BLK / 8; ++u) c[u] = *reinterpret_cast<const uint4*>(sig + b0 + 8 * u);
         } else {                                                     /* a block across an end of the read: never a byte outside it */
             #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < BLK / 8; ++u) {
                 uint32_t h[8];
                 #pragma unroll
                 for (int v = 0; v < 8; ++v) {
@@ -1465,13 +1490,13 @@ static __device__ __forceinline__ void spec2_body(int n_reads, const int32_t* __
                 c[u] = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
             }
         }
-        uint2* __restrict__ d = reinterpret_cast<uint2*>(my + ((64 * b) & 127));
+        uint2* __restrict__ d = reinterpret_cast<uint2*>(my + ((BLK * b) & RING));
         #pragma unroll
-        for (int u = 0; u < 8; ++u) { d[2 * u] = make_uint2(c[u].x, c[u].y); d[2 * u + 1] = make_uint2(c[u].z, c[u].w); }
+        for (int u = 0; u < BLK / 8; ++u) { d[2 * u] = make_uint2(c[u].x, c[u].y); d[2 * u + 1] = make_uint2(c[u].z, c[u].w); }
     };
     uint32_t xmin = 0x7f800000u, xmax = 0u, ymin = 0x7f800000u, ymax = 0u;
     auto fetch = [&](int i) -> float {
-        const int raw = (int)(short)my[(i - i0) & 127];
+        const int raw = (int)(short)my[(i - i0) & RING];
         const float x = (i >= 0 && i < n) ? abea_pa(raw, offset, raw_unit) : 0.f;
         if (i >= seg_lo && i < hi) {                                 /* this segment's own samples: the exactness test's input */
             const float y = __fmul_rn(x, x);
@@ -1490,7 +1515,7 @@ static __device__ __forceinline__ void spec2_body(int n_reads, const int32_t* __
     int cnt = 0;
     const int steps = hi - lo;
     for (int t = 0; t < steps; ++t) {
-        if (t != 0 && (t & 63) == 0) load_block((t >> 6) + 1);       /* samples up to i0 + t + 2 W2 + 7 < 64 ((t >> 6) + 2) */
+        if (t != 0 && (t & (BLK - 1)) == 0) load_block(t / BLK + 1);  /* samples up to i0 + t + 2 W2 + 7 < BLK (t / BLK + 2) */
         const int p = lo + t;
         float a, b;
         wn.tstats(p, n, a, b);
@@ -1508,16 +1533,24 @@ static __device__ __forceinline__ void spec2_body(int n_reads, const int32_t* __
     se[0] = xmin; se[64] = xmax; se[128] = ymin; se[192] = ymax;
 }
 
+/* one kernel per parameter set: a shared one is allocated the registers and the LDS of the larger (RNA) body */
 extern "C" __global__ __launch_bounds__(64)
 void abea_ev_spec2_kernel(int n_reads, const int32_t* __restrict__ order, const int16_t* __restrict__ signal,
                           const int64_t* __restrict__ sig_ptr, const int32_t* __restrict__ n_samples,
                           const float* __restrict__ scaling, const int64_t* __restrict__ seg_base,
                           const int32_t* __restrict__ wave_nseg, uint16_t* __restrict__ spec_all,
-                          int32_t* __restrict__ segrec_all, uint32_t* __restrict__ segexp_all, int rna) {
-    __shared__ __attribute__((aligned(16))) uint16_t rows[64 * ABEA_EV_ROW];
-    const abea_ev_par P = ev_par(rna);
-    if (rna) spec2_body<7, 14>(n_reads, order, signal, sig_ptr, n_samples, scaling, seg_base, wave_nseg, spec_all, segrec_all, segexp_all, P, rows);
-    else spec2_body<3, 6>(n_reads, order, signal, sig_ptr, n_samples, scaling, seg_base, wave_nseg, spec_all, segrec_all, segexp_all, P, rows);
+                          int32_t* __restrict__ segrec_all, uint32_t* __restrict__ segexp_all) {
+    __shared__ __attribute__((aligned(16))) uint16_t rows[64 * (2 * 32 + 4)];
+    spec2_body<3, 6, 32>(n_reads, order, signal, sig_ptr, n_samples, scaling, seg_base, wave_nseg, spec_all, segrec_all, segexp_all, ev_par(0), rows);
+}
+extern "C" __global__ __launch_bounds__(64)
+void abea_ev_spec2_rna_kernel(int n_reads, const int32_t* __restrict__ order, const int16_t* __restrict__ signal,
+                              const int64_t* __restrict__ sig_ptr, const int32_t* __restrict__ n_samples,
+                              const float* __restrict__ scaling, const int64_t* __restrict__ seg_base,
+                              const int32_t* __restrict__ wave_nseg, uint16_t* __restrict__ spec_all,
+                              int32_t* __restrict__ segrec_all, uint32_t* __restrict__ segexp_all) {
+    __shared__ __attribute__((aligned(16))) uint16_t rows[64 * (2 * 64 + 4)];
+    spec2_body<7, 14, 64>(n_reads, order, signal, sig_ptr, n_samples, scaling, seg_base, wave_nseg, spec_all, segrec_all, segexp_all, ev_par(1), rows);
 }
 
 template <int W1, int W2>
@@ -1701,9 +1734,23 @@ void abea_ev_create3_kernel(int n_reads, const int32_t* __restrict__ order, cons
             /* sums[end] - sums[start]: the samples of [start, end); a list that ran backwards would give the negated sum of [end, start) */
             const int a = min(start, end), b = max(start, end);
             double S = 0.0, Q = 0.0;
-            for (int q = a; q < b; ++q) {
-                const float x = abea_pa((int)sig[q], offset, raw_unit);
-                S += (double)x; Q += (double)__fmul_rn(x, x);
+            for (int q = a; q < b; q += 8) {                          /* 8 samples per load (any alignment): one memory latency per 8, not per sample */
+                uint32_t v[4];
+                if (q + 8 <= n) {
+                    __builtin_memcpy(v, sig + q, 16);
+                } else {
+                    v[0] = v[1] = v[2] = v[3] = 0u;
+                    #pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        if (q + u < n) v[u >> 1] |= (uint32_t)(uint16_t)sig[q + u] << (16 * (u & 1));
+                }
+                #pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    if (q + u < b) {
+                        const float x = abea_pa((int)(short)(v[u >> 1] >> (16 * (u & 1))), offset, raw_unit);
+                        S += (double)x; Q += (double)__fmul_rn(x, x);
+                    }
+                }
             }
             if (end < start) { S = 0.0 - S; Q = 0.0 - Q; }
             abea_event_t o;                                          /* events.c:497-513 */
@@ -1849,7 +1896,8 @@ void abea_ev_scalings_kernel(int n_reads, const int32_t* __restrict__ order, con
                              const int32_t* __restrict__ n_events, const int32_t* __restrict__ event_cap,
                              const char* __restrict__ reads, const int64_t* __restrict__ read_ptr,
                              const int32_t* __restrict__ read_len, const abea_model_t* __restrict__ model, int kmer_size,
-                             abea_scalings_t* __restrict__ scalings) {
+                             abea_scalings_t* __restrict__ scalings, float* __restrict__ level_all,
+                             const int64_t* __restrict__ kmer_base, const int32_t* __restrict__ wave_k) {
     __shared__ __attribute__((aligned(16))) double lds[2][2][64];       /* [buffer][chain][term] */
     const int lane = threadIdx.x, slot = blockIdx.x;
     if (slot >= n_reads) return;
@@ -1859,6 +1907,10 @@ void abea_ev_scalings_kernel(int n_reads, const int32_t* __restrict__ order, con
     const float* __restrict__ mean = mean_lin + peak_base[slot >> 6] + (int64_t)(slot & 63) * wave_cap[slot >> 6];
     const char* __restrict__ seq = reads + read_ptr[r];
     auto level = [&](int i) { return model[kmer_rank_at(seq, i, L, kmer_size)].level_mean; };
+    /* the k-mer levels are derived ONCE, by the strided pass below, and parked in the read's own scratch row: the chains' tiles
+     * then cost a float load per term instead of a rank (50 instructions) and a dependent gather — a lone wavefront issues one
+     * instruction every ~5 cycles, and what the 62 idle lanes execute between two tiles is time the two chain lanes wait */
+    float* __restrict__ lvl = level_all + kmer_base[slot >> 6] + (int64_t)(slot & 63) * wave_k[slot >> 6];
     /* ---- the two float sums: strided partial sums + the exponent range of the terms ---- */
     double ps_e = 0.0, ps_k = 0.0;
     int lo_e = 255, hi_e = 0, lo_k = 255, hi_k = 0;
@@ -1866,21 +1918,31 @@ void abea_ev_scalings_kernel(int n_reads, const int32_t* __restrict__ order, con
         const int e = (int)((__float_as_uint(x) >> 23) & 0xFFu);
         if (x != 0.0f) { lo = min(lo, max(e, 1)); hi = max(hi, e); }      /* NaN / Inf: e = 255 -> never "exact" */
     };
-    {   /* four loads in flight per lane: a lone wavefront per read is latency-bound, not bandwidth-bound */
-        int i = lane;
-        for (; i + 192 < ne; i += 256) {
-            const float m0 = mean[i], m1 = mean[i + 64], m2 = mean[i + 128], m3 = mean[i + 192];
-            ps_e += (double)m0; ps_e += (double)m1; ps_e += (double)m2; ps_e += (double)m3;
-            range(m0, lo_e, hi_e); range(m1, lo_e, hi_e); range(m2, lo_e, hi_e); range(m3, lo_e, hi_e);
+    {   /* a lone wavefront per read is latency-bound, not bandwidth-bound: 32 means per lane and trip in flight (two 16-byte loads of
+         * any alignment), four k-mer windows and then their four model gathers */
+        int i = 0;
+        for (; i + 512 <= ne; i += 512) {
+            float m[8];
+            __builtin_memcpy(m, mean + i + 4 * lane, 16);
+            __builtin_memcpy(m + 4, mean + i + 256 + 4 * lane, 16);
+            #pragma unroll
+            for (int u = 0; u < 8; ++u) { ps_e += (double)m[u]; range(m[u], lo_e, hi_e); }
         }
-        for (; i < ne; i += 64) { const float m = mean[i]; ps_e += (double)m; range(m, lo_e, hi_e); }
+        for (i += lane; i < ne; i += 64) { const float m = mean[i]; ps_e += (double)m; range(m, lo_e, hi_e); }
         i = lane;
-        for (; i + 64 < K; i += 128) {
-            const float l0 = level(i), l1 = level(i + 64);
-            ps_k += (double)l0; ps_k += (double)l1; range(l0, lo_k, hi_k); range(l1, lo_k, hi_k);
+        for (; i + 192 < K; i += 256) {
+            uint32_t w0[3], w1[3], w2[3], w3[3];
+            kmer_window_at(seq, i, L, kmer_size, w0); kmer_window_at(seq, i + 64, L, kmer_size, w1);
+            kmer_window_at(seq, i + 128, L, kmer_size, w2); kmer_window_at(seq, i + 192, L, kmer_size, w3);
+            const float l0 = model[kmer_rank_of_window(w0, kmer_size)].level_mean, l1 = model[kmer_rank_of_window(w1, kmer_size)].level_mean;
+            const float l2 = model[kmer_rank_of_window(w2, kmer_size)].level_mean, l3 = model[kmer_rank_of_window(w3, kmer_size)].level_mean;
+            ps_k += (double)l0; ps_k += (double)l1; ps_k += (double)l2; ps_k += (double)l3;
+            range(l0, lo_k, hi_k); range(l1, lo_k, hi_k); range(l2, lo_k, hi_k); range(l3, lo_k, hi_k);
+            lvl[i] = l0; lvl[i + 64] = l1; lvl[i + 128] = l2; lvl[i + 192] = l3;
         }
-        for (; i < K; i += 64) { const float l = level(i); ps_k += (double)l; range(l, lo_k, hi_k); }
+        for (; i < K; i += 64) { const float l = level(i); ps_k += (double)l; range(l, lo_k, hi_k); lvl[i] = l; }
     }
+    __syncthreads();                                                    /* the level stores are complete before the tiles read them back */
     for (int off = 32; off > 0; off >>= 1) {
         ps_e += __shfl_xor(ps_e, off, 64); ps_k += __shfl_xor(ps_k, off, 64);
         lo_e = min(lo_e, __shfl_xor(lo_e, off, 64)); hi_e = max(hi_e, __shfl_xor(hi_e, off, 64));
@@ -1895,24 +1957,43 @@ void abea_ev_scalings_kernel(int n_reads, const int32_t* __restrict__ order, con
     double shift = 0.0;
     auto run = [&](int kind0, int kind1, double& out0, double& out1) {
         auto count = [&](int kind) { return kind == NONE ? 0 : (kind == KM_SUM || kind == KM_SQ) ? K : ne; };
-        auto term = [&](int kind, int i) -> double {
+        /* a term in stages, its load two tiles ahead of its addition, so that no memory latency sits between two tiles of the chains:
+         *   A  the raw input: the k-mer's level (parked above) or the event mean              (a load)
+         *   B  (was: rank -> model gather, before the levels were parked)
+         *   C  the double that is added                                                        (arithmetic) */
+        struct raw { float m; };
+        auto stage_a = [&](int kind, int i, raw& R) {
+            R.m = 0.f;
+            if (i >= count(kind)) return;
+            R.m = (kind == KM_SUM || kind == KM_SQ) ? lvl[i] : mean[i];
+        };
+        auto stage_b = [&](int kind, int i, const raw& R) -> float { return i < count(kind) ? R.m : 0.f; };
+        auto stage_c = [&](int kind, int i, float v) -> double {
             if (i >= count(kind)) return 0.0;
-            if (kind == KM_SUM) return (double)level(i);
-            if (kind == KM_SQ) { const double l = (double)level(i); return l * l; }                       /* align.c:80-81 */
-            if (kind == EV_SUM) return (double)mean[i];                                                    /* align.c:70 */
-            const double d = (double)mean[i] - shift; return d * d;                                       /* align.c:91-92 */
+            if (kind == KM_SUM || kind == EV_SUM) return (double)v;                                       /* align.c:70 */
+            if (kind == KM_SQ) { const double lv = (double)v; return lv * lv; }                           /* align.c:80-81 */
+            const double d = (double)v - shift; return d * d;                                             /* align.c:91-92 */
         };
         const int n_it = max(count(kind0), count(kind1));
         double acc = 0.0;
-        /* software pipeline: the terms of tile t + 1 are loaded and computed while the two chain lanes add tile t (64 dependent
-         * v_add_f64 ~ 0.3 us, about the latency of the loads); two LDS buffers, one barrier per tile */
-        double t0 = term(kind0, lane), t1 = term(kind1, lane);
+        /* tile t is added while B of tile t + 1 and A of tile t + 2 are in flight.  The block is ONE wavefront: its LDS instructions execute in
+         * order, so the stores of a tile are visible to the chain lanes without a workgroup barrier — and __syncthreads() would also wait
+         * for every outstanding global load, i.e. for the very stages that are meant to stay in flight across tiles */
+        raw a0, a1;
+        stage_a(kind0, lane, a0); stage_a(kind1, lane, a1);
+        float b0 = stage_b(kind0, lane, a0), b1 = stage_b(kind1, lane, a1);
+        stage_a(kind0, 64 + lane, a0); stage_a(kind1, 64 + lane, a1);
+        double t0 = stage_c(kind0, lane, b0), t1 = stage_c(kind1, lane, b1);
+        b0 = stage_b(kind0, 64 + lane, a0); b1 = stage_b(kind1, 64 + lane, a1);
+        stage_a(kind0, 128 + lane, a0); stage_a(kind1, 128 + lane, a1);
         int buf = 0;
         for (int i0 = 0; i0 < n_it; i0 += 64, buf ^= 1) {
             lds[buf][0][lane] = t0;
             lds[buf][1][lane] = t1;
-            __syncthreads();
-            if (i0 + 64 < n_it) { t0 = term(kind0, i0 + 64 + lane); t1 = term(kind1, i0 + 64 + lane); }
+            __builtin_amdgcn_wave_barrier();
+            const float c0 = b0, c1 = b1;                                                                 /* B of tile i0 + 64: issued one tile ago */
+            if (i0 + 128 < n_it) { b0 = stage_b(kind0, i0 + 128 + lane, a0); b1 = stage_b(kind1, i0 + 128 + lane, a1); }
+            if (i0 + 192 < n_it) { stage_a(kind0, i0 + 192 + lane, a0); stage_a(kind1, i0 + 192 + lane, a1); }
             if (lane < 2) {
                 const double2* col = reinterpret_cast<const double2*>(lds[buf][lane]);
                 #pragma unroll
@@ -1921,8 +2002,9 @@ void abea_ev_scalings_kernel(int n_reads, const int32_t* __restrict__ order, con
                     acc += a.x; acc += a.y; acc += b.x; acc += b.y; acc += c2.x; acc += c2.y; acc += d2.x; acc += d2.y;
                 }
             }
+            if (i0 + 64 < n_it) { t0 = stage_c(kind0, i0 + 64 + lane, c0); t1 = stage_c(kind1, i0 + 64 + lane, c1); }
         }
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();
         out0 = __shfl(acc, 0, 64); out1 = __shfl(acc, 1, 64);
     };
     double ev_sum = ps_e, km_sum = ps_k, unused = 0.0;
