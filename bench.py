@@ -598,12 +598,12 @@ def detector_roofline(ctx, sub, sig, sp, ns, sc, n_reads=2048):
         achieved = a / (ms * 1e-3) / 1e9
         t = detector_pmc()
         traffic = t["hbm_bytes_per_sample"] * n_smp if t else None
-        return {"bound": "hbm", "kernels": "abea_ev_* (psum, pscan, pwrite, sums, tstat, spec, fix, scan, gather, detect, create, scalings)",
-                "bound_note": "achieved / frac price the ALGORITHMIC bytes (2 B per sample in, 24 B per event out) as the contract asks; the "
-                              "kernels move ~19 x that — the fp64 prefix sums {S, Q} are written once (16 B per sample) and read back by the "
-                              "t-statistics and the event creation, the t-statistics by the peak automaton — and it is that traffic which sits "
-                              "near the roofline: traffic_frac of the peak for the detector as a whole, 0.54-0.59 for its two streaming kernels "
-                              "(dominant_kernels)",
+        return {"bound": "valu", "kernels": "abea_ev_* (spec2, fix2, scan2, create3, scalings; behind them, on flagged reads only: sums, tstat, detect, create)",
+                "bound_note": "achieved / frac price the ALGORITHMIC bytes (2 B per sample in, 24 B per event out) against the HBM peak, as the "
+                              "contract asks.  Since round 6 the common path takes window and event sums straight from the 2-byte samples (no fp64 "
+                              "prefix-sum array, no t-statistic array): the kernels move traffic_over_algorithmic x the algorithmic bytes (rounds 3-5: "
+                              "19 x) = traffic_frac of the HBM peak, and the dominant kernel (abea_ev_spec2_kernel: two t-statistics and an automaton "
+                              "step per sample, ~280 VALU instructions) is bound by VALU issue, not by memory (dominant_kernels: wave_time_split)",
                 "traffic_frac": round(traffic / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                 "reads": m, "samples": n_smp, "events": n_ev, "kernels_ms": round(ms, 3), "gsamples_per_s": round(n_smp / ms / 1e6, 2),
@@ -617,20 +617,23 @@ def detector_roofline(ctx, sub, sig, sp, ns, sc, n_reads=2048):
 
 
 def detector_kernel_rooflines(t):
-    """The two streaming kernels of the detector against the HBM roofline, from the committed passes alone (static): algorithmic bytes
-    per sample (abea_ev_pwrite_kernel: 2 B of signal in, the 16-byte {S, Q} prefix-sum pair out; abea_ev_tstat_kernel: that pair in,
-    two float t-statistics out), counter bytes per sample (FETCH_SIZE x 2 + WRITE_SIZE) and the rate the counters imply over the
-    kernel's duration in the same passes."""
+    """The detector's three long kernels from the committed passes alone (static): counter bytes per sample (FETCH_SIZE x 2 + WRITE_SIZE), the
+    HBM rate they imply over the kernel's duration in the same passes, and — from the SQ passes — what the wavefronts' time went into."""
     out = {}
-    for name, alg in (("abea_ev_pwrite_kernel", 18.0), ("abea_ev_tstat_kernel", 24.0)):
+    for name, what in (("abea_ev_spec2_kernel", "samples -> sliding window sums -> two t-statistics -> automaton, a lane per 512-sample segment"),
+                       ("abea_ev_create3_kernel", "peak lists + samples -> event_t, a lane per event"),
+                       ("abea_ev_scalings_kernel", "method-of-moments sums, a wavefront per read (sequential fp64 chains)")):
         k_ = t["per_kernel"].get(name)
         if not k_:
             continue
         moved = k_["fetch_x2_bytes_per_sample"] + k_["write_bytes_per_sample"]
         gbs = moved * t["samples_per_call"] / (k_["kernel_ms"] * 1e-3) / 1e9
-        out[name] = {"bound": "hbm", "algorithmic_bytes_per_sample": alg, "counter_bytes_per_sample": round(moved, 2),
-                     "kernel_ms": k_["kernel_ms"], "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(gbs / HBM_PEAK_GBS, 4), "static": True}
+        split = k_.get("wave_time_split") or {}
+        bound = "valu" if split.get("issuing", 0) + split.get("issue_stalled", 0) >= 0.6 else "latency"
+        out[name] = {"what": what, "bound": bound, "counter_bytes_per_sample": round(moved, 2), "kernel_ms": k_["kernel_ms"],
+                     "hbm_achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "hbm_frac": round(gbs / HBM_PEAK_GBS, 4),
+                     "valu_wave_instr_per_64_samples": k_.get("valu_wave_instr_per_64_samples"), "wave_time_split": split or None,
+                     "lds_bank_conflict_cycle_frac": k_.get("lds_bank_conflict_cycle_frac"), "static": True}
     return out
 
 

@@ -113,26 +113,6 @@ static __device__ __forceinline__ uint32_t kmer_rank_at(const char* __restrict__
     return rank;
 }
 
-/* the two halves of it, for callers that want the load in flight before they need the rank: the 12 bytes at seq[i] (assembled
- * base by base, zero-filled, where the window would pass the read's terminator), and the rank from those words */
-static __device__ __forceinline__ void kmer_window_at(const char* __restrict__ seq, int i, int L, int kmer_size, uint32_t w[3]) {
-    if (i + 12 <= L + 1) {
-        __builtin_memcpy(w, seq + i, 12);
-    } else {
-        w[0] = w[1] = w[2] = 0u;
-        #pragma unroll                                               /* static indices: a dynamically indexed w[] is moved to LDS by the compiler */
-        for (int j = 0; j < ABEA_MAX_KMER_SIZE; ++j)
-            if (j < kmer_size) w[j >> 2] |= (uint32_t)(unsigned char)seq[i + j] << (8 * (j & 3));
-    }
-}
-static __device__ __forceinline__ uint32_t kmer_rank_of_window(const uint32_t w[3], int kmer_size) {
-    uint32_t rank = 0;
-    #pragma unroll
-    for (int j = 0; j < ABEA_MAX_KMER_SIZE; ++j)
-        if (j < kmer_size) rank = (rank << 2) | base_code((w[j >> 2] >> (8 * (j & 3))) & 0xFFu);
-    return rank;
-}
-
 extern "C" __global__ __launch_bounds__(256)
 void abea_pre_kernel(const abea_read_desc* __restrict__ descs,
                      const char* __restrict__ reads, const abea_event_t* __restrict__ events,
@@ -1871,6 +1851,26 @@ void abea_ev_pack_kernel(int n_reads, const abea_event_t* __restrict__ src, cons
         d[(size_t)g * 3 + 1] = make_uint4(w[4], w[5], w[6], w[7]);
         d[(size_t)g * 3 + 2] = make_uint4(w[8], w[9], w[10], w[11]);
     }
+}
+
+/* kmer_rank_at in two halves, for callers that want the load in flight before they need the rank: the 12 bytes at seq[i] (assembled
+ * base by base, zero-filled, where the window would pass the read's terminator), and the rank from those words */
+static __device__ __forceinline__ void kmer_window_at(const char* __restrict__ seq, int i, int L, int kmer_size, uint32_t w[3]) {
+    if (i + 12 <= L + 1) {
+        __builtin_memcpy(w, seq + i, 12);
+    } else {
+        w[0] = w[1] = w[2] = 0u;
+        #pragma unroll                                               /* static indices: a dynamically indexed w[] is moved to LDS by the compiler */
+        for (int j = 0; j < ABEA_MAX_KMER_SIZE; ++j)
+            if (j < kmer_size) w[j >> 2] |= (uint32_t)(unsigned char)seq[i + j] << (8 * (j & 3));
+    }
+}
+static __device__ __forceinline__ uint32_t kmer_rank_of_window(const uint32_t w[3], int kmer_size) {
+    uint32_t rank = 0;
+    #pragma unroll
+    for (int j = 0; j < ABEA_MAX_KMER_SIZE; ++j)
+        if (j < kmer_size) rank = (rank << 2) | base_code((w[j >> 2] >> (8 * (j & 3))) & 0xFFu);
+    return rank;
 }
 
 /* pass 5: estimate_scalings_using_mom (align.c:58-106), one wavefront per READ (round 6).

@@ -94,37 +94,65 @@ def main(prefix):
 
 def detector(prefix, samples_per_call):
     """pmc_traffic.json["detector"]: HBM bytes per SAMPLE of every abea_ev_* kernel of one DNA call of tools/n2_profile.py (2048 reads)
-    from its FETCH_SIZE / WRITE_SIZE passes: `prefix`n2_fetch_counter_collection.csv, `prefix`n2_write_counter_collection.csv.  The
-    script runs the DNA parameters twice, then the RNA parameters twice: the first two dispatches of each kernel are averaged."""
-    def first_two(path, counter):
-        acc = collections.defaultdict(list)
-        for r in csv.DictReader(open(path)):
-            if r["Kernel_Name"].startswith("abea_ev_") and r["Counter_Name"] == counter:
-                acc[r["Kernel_Name"].split("(")[0]].append((int(r["Dispatch_Id"]), float(r["Counter_Value"]),
-                                                           (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6))
-        out = {}
-        for k, v in acc.items():
-            v.sort()
-            per_call = len(v) // 4                       # launches per detector call (sub-batches)
-            take = v[:2 * per_call]
-            out[k] = (sum(x[1] for x in take) / 2, sum(x[2] for x in take) / 2)
-        return out
-    f, w = first_two(prefix + "n2_fetch_counter_collection.csv", "FETCH_SIZE"), first_two(prefix + "n2_write_counter_collection.csv", "WRITE_SIZE")
+    from its FETCH_SIZE / WRITE_SIZE passes (`prefix`n2_fetch_counter_collection.csv, `prefix`n2_write_counter_collection.csv) and, when
+    the SQ passes are there (`prefix`n2_sqa_..., `prefix`n2_sqb_...), the instruction counts and the wave-time split of each kernel.
+    The script runs the DNA parameters twice, then the RNA parameters twice: the DNA calls are the dispatches in front of the first
+    RNA-only kernel (abea_ev_spec2_rna_kernel); a kernel's counters are summed over the two DNA calls and halved."""
+    def dna_calls(path):
+        rows = [r for r in csv.DictReader(open(path)) if r["Kernel_Name"].startswith("abea_ev_")]
+        rna = [int(r["Dispatch_Id"]) for r in rows if r["Kernel_Name"].startswith("abea_ev_spec2_rna_kernel")]
+        cut = min(rna) if rna else None
+        acc = collections.defaultdict(lambda: collections.defaultdict(float)); ms = collections.defaultdict(float)
+        seen = set()
+        ids = sorted({int(r["Dispatch_Id"]) for r in rows})
+        if cut is None:                                  # no RNA-only kernel in the trace (the array form): first half of the dispatches
+            cut = ids[len(ids) // 2]
+        for r in rows:
+            d = int(r["Dispatch_Id"])
+            if d >= cut:
+                continue
+            k = r["Kernel_Name"].split("(")[0]
+            acc[k][r["Counter_Name"]] += float(r["Counter_Value"]) / 2
+            if (k, d) not in seen:
+                seen.add((k, d)); ms[k] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 / 2
+        return acc, ms
+    f, fms = dna_calls(prefix + "n2_fetch_counter_collection.csv")
+    w, _ = dna_calls(prefix + "n2_write_counter_collection.csv")
+    sqa = sqb = None
+    if os.path.exists(prefix + "n2_sqa_counter_collection.csv") and os.path.exists(prefix + "n2_sqb_counter_collection.csv"):
+        sqa, _ = dna_calls(prefix + "n2_sqa_counter_collection.csv")
+        sqb, sqb_ms = dna_calls(prefix + "n2_sqb_counter_collection.csv")
     per = {}
     for k in sorted(set(f) | set(w)):
-        fb, wb = f.get(k, (0, 0))[0] * 2048, w.get(k, (0, 0))[0] * 1024
-        per[k] = {"fetch_x2_bytes_per_sample": round(fb / samples_per_call, 3), "write_bytes_per_sample": round(wb / samples_per_call, 3),
-                  "kernel_ms": round(f.get(k, w.get(k))[1], 3)}
+        fb, wb = f[k].get("FETCH_SIZE", 0.0) * 2048, w[k].get("WRITE_SIZE", 0.0) * 1024
+        e = {"fetch_x2_bytes_per_sample": round(fb / samples_per_call, 3), "write_bytes_per_sample": round(wb / samples_per_call, 3),
+             "kernel_ms": round(fms[k], 3)}
+        if sqa and k in sqa and k in sqb and sqb[k].get("SQ_WAVE_CYCLES"):
+            a_, b_ = sqa[k], sqb[k]
+            wc = b_["SQ_WAVE_CYCLES"]
+            e["valu_wave_instr_per_64_samples"] = round(a_["SQ_INSTS_VALU"] / (samples_per_call / 64), 2)
+            e["salu_wave_instr_per_64_samples"] = round(a_["SQ_INSTS_SALU"] / (samples_per_call / 64), 2)
+            e["lds_wave_instr_per_64_samples"] = round(a_["SQ_INSTS_LDS"] / (samples_per_call / 64), 2)
+            e["lds_bank_conflict_cycle_frac"] = round(a_["SQ_LDS_BANK_CONFLICT"] / a_["SQ_LDS_IDX_ACTIVE"], 3) if a_.get("SQ_LDS_IDX_ACTIVE") else None
+            e["wavefronts"] = int(a_["SQ_WAVES"])
+            e["wave_time_split"] = {"issuing": round(b_["SQ_ACTIVE_INST_ANY"] / wc, 3), "issue_stalled": round(b_["SQ_WAIT_INST_ANY"] / wc, 3),
+                                    "parked_on_waitcnt": round(b_["SQ_WAIT_ANY"] / wc, 3)}
+            e["valu_share_of_issued_cycles"] = round(b_["SQ_ACTIVE_INST_VALU"] / b_["SQ_ACTIVE_INST_ANY"], 3)
+            e["shader_clock_ghz"] = round(b_["GRBM_GUI_ACTIVE"] / N_XCD / (sqb_ms[k] * 1e6), 2)
+        per[k] = e
     import hashlib
     data = open(os.path.join(ROOT, "f5c_amd/csrc/abea_kernels.hip"), "rb").read()
     sha = hashlib.sha256(data[data.find(ALIGN_SECTION_END):]).hexdigest()
     total = sum(v["fetch_x2_bytes_per_sample"] + v["write_bytes_per_sample"] for v in per.values())
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "pmc_traffic.json")
     j = json.load(open(path))
-    j["detector"] = {"kernels": "abea_ev_*", "samples_per_call": samples_per_call, "hbm_bytes_per_sample": round(total, 3), "per_kernel": per,
+    passes = {"fetch": prefix + "n2_fetch_counter_collection.csv", "write": prefix + "n2_write_counter_collection.csv"}
+    if sqa:
+        passes.update({"sq_a": prefix + "n2_sqa_counter_collection.csv", "sq_b": prefix + "n2_sqb_counter_collection.csv"})
+    j["detector"] = {"kernels": "abea_ev_*", "samples_per_call": samples_per_call, "hbm_bytes_per_sample": round(total, 3),
+                     "kernels_ms_per_call": round(sum(v["kernel_ms"] for v in per.values()), 3), "per_kernel": per,
                      "code_sha256": sha, "code_sha256_of": "f5c_amd/csrc/abea_kernels.hip from the event-detection banner to the end",
-                     "passes": {"fetch": prefix + "n2_fetch_counter_collection.csv", "write": prefix + "n2_write_counter_collection.csv"},
-                     "command": "tools/n2_profile.py 2048 (DNA parameters, first two calls)"}
+                     "passes": passes, "command": "tools/n2_profile.py 2048 (DNA parameters: the two calls in front of the first RNA kernel)"}
     json.dump(j, open(path, "w"), indent=1)
     print("detector", round(total, 2), "B per sample;", {k: round(v["fetch_x2_bytes_per_sample"] + v["write_bytes_per_sample"], 2) for k, v in per.items()})
 

@@ -40,6 +40,8 @@ case $STAGE in
     grep "parameters" $O/n2_kt.log
     step n2_fetch 300 rocprofv3 --kernel-trace --output-format csv -d $O/n2_fetch -o n2 --pmc FETCH_SIZE -- python tools/n2_profile.py 2048
     step n2_write 300 rocprofv3 --kernel-trace --output-format csv -d $O/n2_write -o n2 --pmc WRITE_SIZE -- python tools/n2_profile.py 2048
+    step n2_sqa 300 rocprofv3 --kernel-trace --output-format csv -d $O/n2_sqa -o n2 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE -- python tools/n2_profile.py 2048
+    step n2_sqb 300 rocprofv3 --kernel-trace --output-format csv -d $O/n2_sqb -o n2 --pmc SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VALU SQ_BUSY_CU_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA SQ_WAVE_CYCLES GRBM_GUI_ACTIVE -- python tools/n2_profile.py 2048
     find $O -name "*.csv" | head
     ;;
   n2ab)       # the detector alone, no profiler: the fused common path against the array form (ABEA_EV_PATH=arrays), same process layout
