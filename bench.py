@@ -561,14 +561,22 @@ def process_chain(ctx, batch, model, k, check_cpu=True, n_reads=10000):
 def chain_bound(ms, host, gpu_busy_ms, pcie_bytes, link):
     """What bounds a raw-signal call: `pcie` = achieved GB/s of each direction over the call against the link's own ceiling with both
     directions busy (abea_link_probe on this box: host->device by copy engine while device->host runs — by copy engine too, the
-    mover the tables use), frac = the larger of the two shares; `bound` = "pcie" when that share is >= 0.8, "host" when the caller's
+    mover the tables use), frac = the link's floor for the call's bytes (both directions at their both-busy rates, the remainder of the
+    longer one alone) over the call's time; `bound` = "pcie" when that share is >= 0.8, "host" when the caller's
     thread works (flatten + scatter + plan) >= 0.85 of the call, "detector" when the GPU's kernels cover >= 0.8 of it by its own clock,
     else "ramp" (no resource saturated: the pipeline fills and drains)."""
     t = ms * 1e-3
     h2d, d2h = pcie_bytes["h2d"] / t / 1e9, pcie_bytes["d2h"] / t / 1e9
     up_peak = min(link["both_h2d_copy"], link["both_copy_h2d"]) if os.environ.get("ABEA_CHAIN_TABLE_COPY", "engine") == "engine" else link["both_h2d_copy"]
     dn_peak = link["both_copy_d2h"] if os.environ.get("ABEA_CHAIN_TABLE_COPY", "engine") == "engine" else link["both_d2h_kernel"]
-    frac = max(h2d / max(up_peak, 1e-9), d2h / max(dn_peak, 1e-9))
+    # the link's floor for these bytes: both directions run at their both-busy rates until the shorter one is through, the rest of the
+    # longer one alone at its one-direction rate; frac = that floor / the call (the larger of the two both-busy shares exceeded 1 on a
+    # call whose download ran partly alone: 28.5 GB/s down against a both-busy ceiling of 28.4)
+    up1, dn1 = max(link["h2d_copy"], up_peak), max(link["d2h_copy"], dn_peak)
+    t_up, t_dn = pcie_bytes["h2d"] / (max(up_peak, 1e-9) * 1e9), pcie_bytes["d2h"] / (max(dn_peak, 1e-9) * 1e9)
+    floor_s = (t_up + (pcie_bytes["d2h"] - dn_peak * 1e9 * t_up) / (dn1 * 1e9)) if t_up < t_dn else \
+              (t_dn + (pcie_bytes["h2d"] - up_peak * 1e9 * t_dn) / (up1 * 1e9))
+    frac = min(1.0, floor_s / t)
     host_frac = sum(v for k_, v in host.items() if k_ != "wait_for_gpu") / ms
     gpu_frac = gpu_busy_ms / ms
     bound = "pcie" if frac >= 0.8 else "host" if host_frac >= 0.85 else "detector" if gpu_frac >= 0.8 else "ramp"

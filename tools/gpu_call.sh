@@ -49,6 +49,13 @@ case $STAGE in
     ABEA_EV_PATH=arrays step n2_arrays 200 python tools/n2_profile.py 2048
     grep -H "parameters" $O/n2_fused.log $O/n2_arrays.log
     ;;
+  fuzz)       # long randomised sweeps of the detector against the oracle: device entry and host entry, two seeds each
+    for seed in ${FUZZ_SEEDS:-61 62}; do
+      step fuzz_dev_$seed $(( ${FUZZ_S:-150} + 120 )) python tools/fuzz_events.py ${FUZZ_S:-150} $seed
+      step fuzz_host_$seed $(( ${FUZZ_S:-150} + 120 )) python tools/fuzz_events.py ${FUZZ_S:-150} $seed host
+    done
+    grep -h "fuzz OK\|Error\|assert" $O/fuzz_*.log | tee $O/fuzz_sweeps.txt
+    ;;
   tests)      # the whole GPU suite at the stamped commit (the round's gate: parity tests first, infrastructure last — tests/conftest.py)
     stamp $O/gpu_tests_tree.txt; cat $O/gpu_tests_tree.txt
     step gpu_tests ${SUITE_TIMEOUT:-1500} python -m pytest tests -m gpu -x -q --durations=12 -p no:cacheprovider
