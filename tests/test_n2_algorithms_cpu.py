@@ -132,3 +132,98 @@ def test_float_sums_in_double_are_order_free_under_the_exponent_test():
     y = np.array([2.0 ** -30, 2.0 ** 30, -2.0 ** 30] * 64, dtype=np.float32)     # the classic: cancellation order matters
     lo, hi = expo(y)
     assert clog2(len(y)) + hi - lo > 29 and seq(y) != lanes(y)
+
+
+def test_sliding_window_and_event_sums_equal_the_prefix_sum_differences():
+    """What the common path of the device detector rests on (abea_ev_spec2_kernel / abea_ev_create3_kernel, round 6): where the
+    exponent-range rule holds for a read — for the samples AND for their float squares — the reference's sums[b] - sums[a]
+    (events.c:303-313, 343-366, 497-513: sequential fp64 prefix sums, then a difference) is, bit for bit, (1) the window sum kept by
+    sliding (+ entering sample, - leaving sample) and (2) the plain sum of the samples of [a, b) — so neither the prefix-sum array
+    nor the t-statistic array has to exist.  Real reads, synthetic steps and noise; DNA and RNA window lengths."""
+    g = np.load(os.path.join(ROOT, "tests/golden/ecoli_reads.npz"), allow_pickle=True)
+    r = np.random.default_rng(23)
+    sigs = [(g[f"sig{i}"], g["scaling"][i]) for i in range(min(4, int(g["n"])))]
+    sigs.append((np.repeat(r.integers(350, 750, 3000), r.integers(1, 12, 3000))[:20000].astype(np.int16), (10.0, 1467.61, 8192.0)))
+    sigs.append((r.integers(-32768, 32767, 20000).astype(np.int16), (3.0, 748.58, 2048.0)))
+    checked = 0
+    for raw, sc in sigs:
+        x = _pa(raw, sc)
+        y = (x * x).astype(np.float32)                            # the float product of events.c:312
+        if not (_exact_by_rule(x) and _exact_by_rule(y)):
+            continue
+        for v in (x, y):
+            d = v.astype(np.float64)
+            S = np.concatenate([[0.0], np.cumsum(d)])                # sequential, like the reference
+            n = len(v)
+            for w in (3, 6, 7, 14):
+                if n < 2 * w + 2:
+                    continue
+                ref_left = S[w:n - w + 1] - S[0:n - 2 * w + 1]         # sum over [p - w, p) for p = w .. n - w
+                ref_right = S[2 * w:n + 1] - S[w:n - w + 1]            # sum over [p, p + w)
+                left = d[0:w].sum(); right = d[w:2 * w].sum()
+                got_l, got_r = [left], [right]
+                for p in range(w, n - w):                              # p -> p + 1
+                    left = (left + d[p]) - d[p - w]
+                    right = (right + d[p + w]) - d[p]
+                    got_l.append(left); got_r.append(right)
+                assert np.array_equal(np.array(got_l).view(np.uint64), ref_left.view(np.uint64)), w
+                assert np.array_equal(np.array(got_r).view(np.uint64), ref_right.view(np.uint64)), w
+            cuts = np.sort(r.choice(np.arange(1, n), size=min(2000, n - 1), replace=False))
+            bounds = np.concatenate([[0], cuts, [n]])
+            for a, b in zip(bounds[:-1], bounds[1:]):                  # "events"
+                s = 0.0
+                for t in d[a:b]:
+                    s += t
+                assert s == S[b] - S[a]
+            checked += 1
+    assert checked >= 8
+
+
+def test_division_by_the_window_length_in_three_instructions(tmp_path):
+    """tools/proto/div_const_check.c, thinned to a test: q0 = x * rc; r = fma(-q0, c, x); q = fma(r, rc, q0) with rc = RN(1 / c) is
+    the IEEE quotient x / c for c in {3, 6, 7, 14} on every 61st float bit pattern (the full 2^32 sweep: 73 s, 0 mismatches outside
+    x = +-inf and quotients below 4 FLT_MIN — the cases the kernel sends to the IEEE division) and on 2^24 sampled doubles per
+    divisor and exponent."""
+    src = tmp_path / "divc.c"
+    src.write_text(r'''
+#include <stdio.h>
+#include <stdint.h>
+#include <string.h>
+#include <math.h>
+int main(void) {
+    const float cs[4] = {3.f, 6.f, 7.f, 14.f};
+    unsigned long long bad = 0, guarded = 0, n = 0;
+    for (int k = 0; k < 4; ++k) {
+        const float c = cs[k]; volatile float one = 1.0f; const float rc = one / c;
+        for (uint64_t i = 0; i < (1ull << 32); i += 61) {
+            uint32_t u = (uint32_t)i; float x; memcpy(&x, &u, 4);
+            if (x != x) continue;
+            const float ax = fabsf(x);
+            if (!(ax >= 0x1p-118f && ax < INFINITY)) { ++guarded; continue; }      /* abea_tstat_fast's guard */
+            const float ref = x / c, q0 = x * rc, r = fmaf(-q0, c, x), q = fmaf(r, rc, q0);
+            if (memcmp(&q, &ref, 4)) ++bad;
+            ++n;
+        }
+        const double cd = c; volatile double oned = 1.0; const double rcd = oned / cd;
+        static const int ex[5] = {1023 - 149, 1023 - 20, 1023, 1023 + 20, 1023 + 132};
+        for (uint64_t i = 0; i < (1ull << 24); ++i) {
+            uint64_t z = i * 0x9E3779B97F4A7C15ull + k;
+            z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31;
+            for (int e = 0; e < 5; ++e) {
+                uint64_t u = ((uint64_t)ex[e] << 52) | (z & 0xFFFFFFFFFFFFFull) | ((z >> 63) << 63);
+                double x; memcpy(&x, &u, 8);
+                const double ref = x / cd, q0 = x * rcd, r = fma(-q0, cd, x), q = fma(r, rcd, q0);
+                if (memcmp(&q, &ref, 8)) ++bad;
+                ++n;
+            }
+        }
+    }
+    printf("%llu %llu %llu\n", bad, guarded, n);
+    return 0;
+}
+''')
+    exe = tmp_path / "divc"
+    hw_fma = " fma " in open("/proc/cpuinfo").read().replace("\n", " ")       # without it libm's fma() is exact too, only slower
+    subprocess.check_call(["gcc", "-O2", "-ffp-contract=off"] + (["-mfma"] if hw_fma else []) + ["-o", str(exe), str(src), "-lm"])
+    bad, guarded, n = (int(t) for t in subprocess.check_output([str(exe)]).split())
+    assert bad == 0 and n > 500_000_000 and guarded > 1_000_000
