@@ -552,14 +552,15 @@ class AbeaContext:
                        dbatch["n_pairs"].data_ptr(), dbatch["diag"].data_ptr() if want_diag else None, *sc)
         self._chk(self._lib.abea_align_batch_device(self._h, C.byref(db)), "abea_align_batch_device")
 
-    def _detect(self, signals, scaling, seqs, cap_div, rna=False):
+    def _detect(self, signals, scaling, seqs, cap_div, rna=False, pad_to=8):
         """Shared plumbing of the N2 entry: flatten + upload the signals, run abea_detect_events_device, keep every
         output in HBM.  Returns a dict of the device tensors and host index arrays."""
         import torch
         dev = torch.device("cuda", torch.cuda.current_device())
         n = len(signals)
         ns = np.array([len(s) for s in signals], dtype=np.int32)
-        pad = (ns.astype(np.int64) + 7) // 8 * 8           # reads start on 16-byte boundaries: the sums passes load 8 samples at a time
+        # reads start on 16-byte boundaries by default (the fastest layout); pad_to=1 packs them back to back: any 2-byte alignment
+        pad = (ns.astype(np.int64) + pad_to - 1) // pad_to * pad_to
         sig_ptr = np.concatenate([[0], np.cumsum(pad)[:-1]]).astype(np.int64)
         cap = (ns // cap_div + 16).astype(np.int32)
         ev_ptr = np.concatenate([[0], np.cumsum(cap.astype(np.int64))[:-1]]).astype(np.int64)
@@ -600,12 +601,12 @@ class AbeaContext:
             raise AbeaError(f"event detection found more events than event_cap on {len(over)} read(s) (first: read "
                             f"{int(over[0])}: {int(n_events[over[0]])} > {int(cap[over[0]])}); call again with a smaller cap_div")
 
-    def detect_events_device(self, signals, scaling, seqs=None, cap_div=4, rna=False):
+    def detect_events_device(self, signals, scaling, seqs=None, cap_div=4, rna=False, pad_to=8):
         """Row N2: raw ADC signals -> event tables (+ method-of-moments scalings when `seqs` is given) on the
         device. signals: list of int16 arrays; scaling: float32 [n,3] (offset, range, digitisation); rna=True selects
         the RNA detector parameters and returns the tables reversed 3'->5' as event_single does (f5c.c:711-719).
         Returns (list of EVENT_DT arrays, n_events int32[n], scalings SCAL_DT[n] or None)."""
-        r = self._detect(signals, scaling, seqs, cap_div, rna)
+        r = self._detect(signals, scaling, seqs, cap_div, rna, pad_to)
         ne = r["d_ne"].cpu().numpy()
         self._check_event_cap(ne, r["cap"])
         allev = r["d_ev"].cpu().numpy().view(EVENT_DT)

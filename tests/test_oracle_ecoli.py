@@ -163,14 +163,16 @@ def test_gpu_detector_common_path_equals_the_array_and_sequential_forms(ctx, r9,
     seqs += [bytes(r.choice(list(b"ACGT"), 700).astype(np.uint8))] * (len(extra) + 2)
     scal = np.array(scal, dtype=np.float32)
 
-    def run(**env):
+    def run(pad_to=8, **env):
         for name in ("ABEA_EV_PATH", "ABEA_EV_SEQUENTIAL"):
             monkeypatch.delenv(name, raising=False)
         for name, v in env.items():
             monkeypatch.setenv(name, v)
-        return ctx.detect_events_device(sigs, scal, seqs=seqs, rna=rna, cap_div=1)
+        return ctx.detect_events_device(sigs, scal, seqs=seqs, rna=rna, cap_div=1, pad_to=pad_to)
     evs, ne, sc = run()
-    for form in (dict(ABEA_EV_PATH="arrays"), dict(ABEA_EV_SEQUENTIAL="1")):
+    # pad_to=1: the signals packed back to back, i.e. reads starting at every 2-byte alignment (the staging rows of the common
+    # path are filled from the 16-byte boundary below a lane's first sample, whatever that is)
+    for form in (dict(ABEA_EV_PATH="arrays"), dict(ABEA_EV_SEQUENTIAL="1"), dict(pad_to=1), dict(pad_to=1, ABEA_EV_PATH="arrays")):
         evs2, ne2, sc2 = run(**form)
         assert (ne == ne2).all(), form
         for i in range(len(sigs)):
