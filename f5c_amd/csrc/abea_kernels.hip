@@ -719,7 +719,11 @@ void abea_copy_out_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst
 /* ================================================================ event detection on the device (row N2)
  * event_single's front half (f5c.c:682-712): ADC -> pA, getevents() (events.c:562-582 = detect_events on the
  * whole signal; the trim result there is discarded) and estimate_scalings_using_mom (align.c:58-106).
- * Everything in it is order-dependent floating point, so nothing is re-associated; the work is split so that only
+ * Everything in it is order-dependent floating point, so nothing is re-associated where that could change a bit.
+ * Two forms share this section.  The COMMON PATH (round 6; "the common path without the arrays" below: abea_ev_spec2 / fix2 /
+ * scan2 / create3 kernels) works straight from the samples for every read whose prefix sums are provably exact; the ARRAY
+ * FORM listed here (rounds 3-5) keeps the prefix sums and t-statistics in HBM arrays: it runs behind the common path on the
+ * reads that path flagged, and for every read under ABEA_EV_PATH=arrays.  The array form splits the work so that only
  * what is inherently sequential runs sequentially:
  *   pass 1  abea_ev_sums_kernel    lane-per-read: x = (adc+offset)*raw_unit, S[i+1] = S[i] + x, Q[i+1] = Q[i] + x*x
  *                                  (fp64, sample order; events.c:303-313)                      ~12 instr / sample
