@@ -1417,8 +1417,8 @@ struct abea_ev_win {
     }
 };
 
-/* BLK = samples per staged block (a lane fetches BLK / 8 16-byte chunks back to back); a lane's LDS row is a ring of two blocks + 4
- * samples of padding.  The newest sample a step needs is at most 2 W2 + 7 + (BLK - 1) samples past the start of the block the step
+/* BLK = samples per staged block (a lane fetches BLK / 8 16-byte chunks back to back); a lane's LDS row is a ring of two blocks + 8
+ * entries of pending peaks.  The newest sample a step needs is at most 2 W2 + 7 + (BLK - 1) samples past the start of the block the step
  * began in, which must stay below 2 BLK: RNA (W2 = 14) takes whole 128-byte lines (BLK = 64, 264-byte rows, 9 wavefronts per CU);
  * DNA (W2 = 6) gets by with half lines (BLK = 32, 136-byte rows) and fits twice the wavefronts — the loop is a long dependent
  * chain per lane (two t-statistics, an automaton step) and lives on occupancy. */
@@ -1443,11 +1443,16 @@ static __device__ __forceinline__ void spec2_body(int n_reads, const int32_t* __
     const int16_t* __restrict__ sig = signal + sig_ptr[r];
     const float offset = scaling[3 * r], raw_unit = scaling[3 * r + 1] / scaling[3 * r + 2];   /* f5c.c:693 */
     const int64_t seg = seg_base[w] + j;
-    uint16_t* __restrict__ out = spec_all + seg * ABEA_EV_SEG * 64 + lane;
+    /* the speculative run's peaks: ONE list per (read, segment), contiguous (the array form interleaves the 64 reads of a wave: fine
+     * for a lane-per-read reader, a 128-byte stride for abea_ev_create3_kernel's lane-per-event one).  A lane collects 8 entries in
+     * its LDS row and stores them as one 16-byte chunk.  Measured, 2048 reads, spec2 + create3 ms and FETCH x 2 + WRITE of the two
+     * per sample: interleaved 2.35 + 0.93, 18.4 B; contiguous with 2-byte stores 2.44 + 0.78, 20.0 B (each store dirties a line
+     * that is evicted long before it fills); contiguous in 16-byte chunks 2.52 + 0.73, 15.0 B — the same time, the least traffic */
+    uint16_t* __restrict__ out = spec_all + (seg * 64 + lane) * ABEA_EV_SEG;
     int32_t* __restrict__ rec = segrec_all + seg * 12 * 64 + lane;
     uint32_t* __restrict__ se = segexp_all + seg * 4 * 64 + lane;
     static_assert(2 * W2 + 7 + BLK - 1 < 2 * BLK, "the ring must hold the newest sample of every step");
-    constexpr int ROW = 2 * BLK + 4, RING = 2 * BLK - 1;
+    constexpr int ROW = 2 * BLK + 8, RING = 2 * BLK - 1;
     uint16_t* __restrict__ my = rows + lane * ROW;
 
     /* the row is a ring of two BLK-sample blocks; block b holds the samples i0 + BLK b .. i0 + BLK b + BLK - 1, i0 = the sample at the
@@ -1497,6 +1502,16 @@ static __device__ __forceinline__ void spec2_body(int n_reads, const int32_t* __
     wn.init();
     abea_det2 s; det2_reset(s);
     int cnt = 0;
+    uint16_t* __restrict__ pend = my + 2 * BLK;                      /* 8 pending entries behind the sample ring */
+    auto flush = [&](int at) {                                       /* entries at .. at + 7 of the list (16-byte aligned) */
+        const uint2 lo2 = reinterpret_cast<const uint2*>(pend)[0], hi2 = reinterpret_cast<const uint2*>(pend)[1];
+        *reinterpret_cast<uint4*>(out + at) = make_uint4(lo2.x, lo2.y, hi2.x, hi2.y);
+    };
+    auto emit = [&](int pos) {
+        pend[cnt & 7] = (uint16_t)(pos - seg_lo);
+        ++cnt;
+        if ((cnt & 7) == 0) flush(cnt - 8);
+    };
     const int steps = hi - lo;
     for (int t = 0; t < steps; ++t) {
         if (t != 0 && (t & (BLK - 1)) == 0) load_block(t / BLK + 1);  /* samples up to i0 + t + 2 W2 + 7 < BLK (t / BLK + 2) */
@@ -1505,10 +1520,11 @@ static __device__ __forceinline__ void spec2_body(int n_reads, const int32_t* __
         wn.tstats(p, n, a, b);
         int f0, f1;
         const int fired = det2_step(s, p, a, b, f0, f1, P);
-        if (fired & 1) { out[(size_t)cnt * 64] = (uint16_t)(f0 - seg_lo); ++cnt; }
-        if (fired & 2) { out[(size_t)cnt * 64] = (uint16_t)(f1 - seg_lo); ++cnt; }
+        if (fired & 1) emit(f0);
+        if (fired & 2) emit(f1);
         wn.advance(fetch(p + W2));
     }
+    if (cnt & 7) flush(cnt & ~7);                                    /* the last, partial chunk (its tail is never read) */
     rec[0 * 64] = cnt;                                               /* as abea_ev_spec_kernel */
     rec[1 * 64] = 0;
     rec[2 * 64] = 0;
@@ -1524,7 +1540,7 @@ void abea_ev_spec2_kernel(int n_reads, const int32_t* __restrict__ order, const 
                           const float* __restrict__ scaling, const int64_t* __restrict__ seg_base,
                           const int32_t* __restrict__ wave_nseg, uint16_t* __restrict__ spec_all,
                           int32_t* __restrict__ segrec_all, uint32_t* __restrict__ segexp_all) {
-    __shared__ __attribute__((aligned(16))) uint16_t rows[64 * (2 * 32 + 4)];
+    __shared__ __attribute__((aligned(16))) uint16_t rows[64 * (2 * 32 + 8)];
     spec2_body<3, 6, 32>(n_reads, order, signal, sig_ptr, n_samples, scaling, seg_base, wave_nseg, spec_all, segrec_all, segexp_all, ev_par(0), rows);
 }
 extern "C" __global__ __launch_bounds__(64)
@@ -1533,7 +1549,7 @@ void abea_ev_spec2_rna_kernel(int n_reads, const int32_t* __restrict__ order, co
                               const float* __restrict__ scaling, const int64_t* __restrict__ seg_base,
                               const int32_t* __restrict__ wave_nseg, uint16_t* __restrict__ spec_all,
                               int32_t* __restrict__ segrec_all, uint32_t* __restrict__ segexp_all) {
-    __shared__ __attribute__((aligned(16))) uint16_t rows[64 * (2 * 64 + 4)];
+    __shared__ __attribute__((aligned(16))) uint16_t rows[64 * (2 * 64 + 8)];
     spec2_body<7, 14, 64>(n_reads, order, signal, sig_ptr, n_samples, scaling, seg_base, wave_nseg, spec_all, segrec_all, segexp_all, ev_par(1), rows);
 }
 
@@ -1632,7 +1648,7 @@ void abea_ev_scan2_kernel(int n_reads, const int32_t* __restrict__ order, const 
         const int cnt = nspec + nfix_raw - skip;                     /* as abea_ev_scan_kernel */
         const int nfix = min(nfix_raw, ABEA_EV_FIXCAP);              /* more than the cap: the read is flagged, only the addressing must hold */
         int last = 0;
-        if (live && nspec - skip > 0) last = j * ABEA_EV_SEG + (int)spec_all[seg * ABEA_EV_SEG * 64 + (int64_t)(nspec - 1) * 64 + l];
+        if (live && nspec - skip > 0) last = j * ABEA_EV_SEG + (int)spec_all[(seg * 64 + l) * ABEA_EV_SEG + (nspec - 1)];
         else if (live && nfix > 0) last = fix_all[seg * ABEA_EV_FIXCAP * 64 + (int64_t)(nfix - 1) * 64 + l];
         if (live) {
             const uint32_t* __restrict__ se = segexp_all + seg * 4 * 64 + l;
@@ -1699,7 +1715,7 @@ void abea_ev_create3_kernel(int n_reads, const int32_t* __restrict__ order, cons
     for (int j = blockIdx.y * ABEA_EV_CGRP; j < min(nseg, (int)(blockIdx.y + 1) * ABEA_EV_CGRP); ++j) {
         const int64_t seg = seg_base[w] + j;
         const int32_t* __restrict__ rec = segrec_all + seg * 12 * 64 + l;
-        const uint16_t* __restrict__ sp = spec_all + seg * ABEA_EV_SEG * 64 + l;
+        const uint16_t* __restrict__ sp = spec_all + (seg * 64 + l) * ABEA_EV_SEG;        /* abea_ev_spec2_kernel's list of this (read, segment) */
         const int32_t* __restrict__ fx = fix_all + seg * ABEA_EV_FIXCAP * 64 + l;
         const int nspec = rec[0], nfix = min(rec[64], ABEA_EV_FIXCAP), skip = rec[128], run = rec[3 * 64];
         int before = rec[11 * 64];                                   /* the last peak before this segment (0: none) */
@@ -1709,7 +1725,7 @@ void abea_ev_create3_kernel(int n_reads, const int32_t* __restrict__ order, cons
             const int i = i0 + lane;
             int end = n;
             if (i < nfix) end = fx[(size_t)i * 64];
-            else if (i < c) end = j * ABEA_EV_SEG + (int)sp[(size_t)(skip + i - nfix) * 64];
+            else if (i < c) end = j * ABEA_EV_SEG + (int)sp[skip + i - nfix];
             const int up = __shfl_up(end, 1, 64);
             const int start = lane ? up : before;
             before = __shfl(end, 63, 64);
