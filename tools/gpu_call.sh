@@ -49,6 +49,13 @@ case $STAGE in
     ABEA_EV_PATH=arrays step n2_arrays 200 python tools/n2_profile.py 2048
     grep -H "parameters" $O/n2_fused.log $O/n2_arrays.log
     ;;
+  chainslots) # the raw-signal entries against the number of chunk slots (chunks in flight): long reads hold a slot for their serial band chain
+    step gen 300 python tools/chain_trace.py ${CHAIN_READS:-10000} /tmp/ct
+    for n in ${SLOT_COUNTS:-6 9 12 16}; do
+      ABEA_CHAIN_SLOTS=$n step chain_slots_$n 300 python tools/chain_trace.py ${CHAIN_READS:-10000} /tmp/ct packed:engine
+      echo "slots $n"; grep "rep [12]" $O/chain_slots_$n.log | cut -c1-200
+    done
+    ;;
   fuzz)       # long randomised sweeps of the detector against the oracle: device entry and host entry, two seeds each
     for seed in ${FUZZ_SEEDS:-61 62}; do
       step fuzz_dev_$seed $(( ${FUZZ_S:-150} + 120 )) python tools/fuzz_events.py ${FUZZ_S:-150} $seed
