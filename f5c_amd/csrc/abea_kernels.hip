@@ -1419,9 +1419,9 @@ struct abea_ev_win {
 
 /* BLK = samples per staged block (a lane fetches BLK / 8 16-byte chunks back to back); a lane's LDS row is a ring of two blocks + 8
  * entries of pending peaks.  The newest sample a step needs is at most 2 W2 + 7 + (BLK - 1) samples past the start of the block the step
- * began in, which must stay below 2 BLK: RNA (W2 = 14) takes whole 128-byte lines (BLK = 64, 264-byte rows, 9 wavefronts per CU);
- * DNA (W2 = 6) gets by with half lines (BLK = 32, 136-byte rows) and fits twice the wavefronts — the loop is a long dependent
- * chain per lane (two t-statistics, an automaton step) and lives on occupancy. */
+ * began in, which must stay below 2 BLK: RNA (W2 = 14) takes 96 bytes at a time (BLK = 48, 208-byte rows, 12 wavefronts per CU =
+ * what its 142 VGPRs allow), DNA (W2 = 6) half lines (BLK = 32, 144-byte rows, 17 per CU) — the loop is a long dependent chain
+ * per lane (two t-statistics, an automaton step) and lives on occupancy. */
 template <int W1, int W2, int BLK>
 static __device__ __forceinline__ void spec2_body(int n_reads, const int32_t* __restrict__ order, const int16_t* __restrict__ signal,
                           const int64_t* __restrict__ sig_ptr, const int32_t* __restrict__ n_samples,
@@ -1452,7 +1452,7 @@ static __device__ __forceinline__ void spec2_body(int n_reads, const int32_t* __
     int32_t* __restrict__ rec = segrec_all + seg * 12 * 64 + lane;
     uint32_t* __restrict__ se = segexp_all + seg * 4 * 64 + lane;
     static_assert(2 * W2 + 7 + BLK - 1 < 2 * BLK, "the ring must hold the newest sample of every step");
-    constexpr int ROW = 2 * BLK + 8, RING = 2 * BLK - 1;
+    constexpr int ROW = 2 * BLK + 8, RINGN = 2 * BLK;                /* ring positions: index modulo RINGN (a mask where BLK is a power of two) */
     uint16_t* __restrict__ my = rows + lane * ROW;
 
     /* the row is a ring of two BLK-sample blocks; block b holds the samples i0 + BLK b .. i0 + BLK b + BLK - 1, i0 = the sample at the
@@ -1479,13 +1479,13 @@ static __device__ __forceinline__ void spec2_body(int n_reads, const int32_t* __
                 c[u] = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
             }
         }
-        uint2* __restrict__ d = reinterpret_cast<uint2*>(my + ((BLK * b) & RING));
+        uint2* __restrict__ d = reinterpret_cast<uint2*>(my + (b & 1) * BLK);
         #pragma unroll
         for (int u = 0; u < BLK / 8; ++u) { d[2 * u] = make_uint2(c[u].x, c[u].y); d[2 * u + 1] = make_uint2(c[u].z, c[u].w); }
     };
     uint32_t xmin = 0x7f800000u, xmax = 0u, ymin = 0x7f800000u, ymax = 0u;
     auto fetch = [&](int i) -> float {
-        const int raw = (int)(short)my[(i - i0) & RING];
+        const int raw = (int)(short)my[(unsigned)(i - i0) % (unsigned)RINGN];
         const float x = (i >= 0 && i < n) ? abea_pa(raw, offset, raw_unit) : 0.f;
         if (i >= seg_lo && i < hi) {                                 /* this segment's own samples: the exactness test's input */
             const float y = __fmul_rn(x, x);
@@ -1514,7 +1514,7 @@ static __device__ __forceinline__ void spec2_body(int n_reads, const int32_t* __
     };
     const int steps = hi - lo;
     for (int t = 0; t < steps; ++t) {
-        if (t != 0 && (t & (BLK - 1)) == 0) load_block(t / BLK + 1);  /* samples up to i0 + t + 2 W2 + 7 < BLK (t / BLK + 2) */
+        if (t != 0 && t % BLK == 0) load_block(t / BLK + 1);        /* samples up to i0 + t + 2 W2 + 7 < BLK (t / BLK + 2) */
         const int p = lo + t;
         float a, b;
         wn.tstats(p, n, a, b);
@@ -1549,8 +1549,8 @@ void abea_ev_spec2_rna_kernel(int n_reads, const int32_t* __restrict__ order, co
                               const float* __restrict__ scaling, const int64_t* __restrict__ seg_base,
                               const int32_t* __restrict__ wave_nseg, uint16_t* __restrict__ spec_all,
                               int32_t* __restrict__ segrec_all, uint32_t* __restrict__ segexp_all) {
-    __shared__ __attribute__((aligned(16))) uint16_t rows[64 * (2 * 64 + 8)];
-    spec2_body<7, 14, 64>(n_reads, order, signal, sig_ptr, n_samples, scaling, seg_base, wave_nseg, spec_all, segrec_all, segexp_all, ev_par(1), rows);
+    __shared__ __attribute__((aligned(16))) uint16_t rows[64 * (2 * 48 + 8)];
+    spec2_body<7, 14, 48>(n_reads, order, signal, sig_ptr, n_samples, scaling, seg_base, wave_nseg, spec_all, segrec_all, segexp_all, ev_par(1), rows);
 }
 
 template <int W1, int W2>
