@@ -346,6 +346,7 @@ struct abea_async_job {
 
 struct abea_host_async {
     std::vector<host_thread_plan> plan; std::string plan_key = "?";     /* context_thread_plan's cache (top-level context) */
+    std::mutex plan_mu;                        /* ... which the lanes' threads of submitted batches consult at the same moment */
     int n_lanes = 2;
     abea_host_lane full;                       /* per device context */
     std::vector<abea_host_lane> lanes;         /* per device context */
@@ -369,6 +370,10 @@ static std::vector<host_thread_plan> context_thread_plan(abea_ctx* c) {
     const bool numa = host_numa_enabled();
     abea_host_async* a = async_of(c);
     const std::string key = std::string(e ? e : "") + "|" + (numa ? "1" : host_numa_spread() ? "s" : "0");
+    /* every batch in flight runs this on its own thread: the first batches after abea_init all find the cache empty and would
+     * fill it at once (round 6: one GPU suite in a dozen died here with a segmentation fault — a vector read while another
+     * thread re-assigned it) */
+    std::lock_guard<std::mutex> lk(a->plan_mu);
     if (a->plan_key == key && a->plan.size() == nodes.size()) return a->plan;
     /* Binding is OPT-IN at run time (ABEA_HOST_NUMA=1).  Measured on the MI355X box (2 sockets, bench.py, 100 k reads): with
      * the workers of the one device bound to its node, flatten went from 217 to 602 ms per step — the loop READS 24 B per

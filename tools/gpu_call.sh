@@ -56,6 +56,14 @@ case $STAGE in
       echo "slots $n"; grep "rep [12]" $O/chain_slots_$n.log | cut -c1-200
     done
     ;;
+  stress)     # a test file over and over in fresh processes (a data race shows once in N runs): STRESS_FILE, STRESS_N
+    ok=0; bad=0
+    for i in $(seq 1 ${STRESS_N:-20}); do
+      timeout -k 10 300 python -m pytest ${STRESS_FILE:-tests/test_host_plan_and_async.py} -m gpu -x -q -p no:cacheprovider > $O/stress_$i.log 2>&1
+      rc=$?; if [ $rc = 0 ]; then ok=$((ok+1)); rm -f $O/stress_$i.log; else bad=$((bad+1)); echo "run $i rc=$rc"; tail -5 $O/stress_$i.log; fi
+    done
+    echo "stress ${STRESS_FILE:-tests/test_host_plan_and_async.py}: $ok ok, $bad failed" | tee $O/stress.txt
+    ;;
   fuzz)       # long randomised sweeps of the detector against the oracle: device entry and host entry, two seeds each
     for seed in ${FUZZ_SEEDS:-61 62}; do
       step fuzz_dev_$seed $(( ${FUZZ_S:-150} + 120 )) python tools/fuzz_events.py ${FUZZ_S:-150} $seed
