@@ -131,4 +131,4 @@ case $STAGE in
     tail -40 $O/cmd.log
     ;;
 esac
-cat $O/steps.txt
+cat $O/steps.txt 2>/dev/null; true
