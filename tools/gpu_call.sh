@@ -64,6 +64,10 @@ case $STAGE in
     done
     echo "stress ${STRESS_FILE:-tests/test_host_plan_and_async.py}: $ok ok, $bad failed" | tee $O/stress.txt
     ;;
+  smoke)      # what the driver runs before the bench: __graft_entry__.build() (prebuilt files) and smoke()
+    step smoke 300 python -c "import __graft_entry__ as g; g.build(); g.smoke(); print('smoke ok')"
+    tail -3 $O/smoke.log
+    ;;
   fuzz)       # long randomised sweeps of the detector against the oracle: device entry and host entry, two seeds each
     for seed in ${FUZZ_SEEDS:-61 62}; do
       step fuzz_dev_$seed $(( ${FUZZ_S:-150} + 120 )) python tools/fuzz_events.py ${FUZZ_S:-150} $seed
